@@ -1,0 +1,192 @@
+/*
+ * strus_pattern_amd.h -- C-ABI of the MI355X-native two-level pattern engine.
+ *
+ * This is the drop-in boundary underneath strus's PatternLexerInterface / PatternMatcherInterface
+ * (the C++ shim in struspattern_amd/host/ implements those virtual interfaces on top of these
+ * entry points; the module load point stays `modstrus_analyzer_pattern`).
+ * Plain C: opaque handles, plain pointers and sizes, no C++ or torch types, no exceptions.
+ * Every call returns 0 on success or a negative SP_ERR_* code; the message is retrievable with
+ * sp_*_last_error(handle).  Buffers returned through `**out` parameters are owned by the caller
+ * and released with sp_free().  Each entry point cites the reference interface it replaces
+ * (paths relative to the strusPattern source tree).
+ */
+#ifndef STRUS_PATTERN_AMD_H
+#define STRUS_PATTERN_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK                    0
+#define SP_ERR_INVALID          -1   /* bad argument / call order (reference: std::runtime_error -> ErrorCodeRuntimeError) */
+#define SP_ERR_NOMEM            -2   /* reference: std::bad_alloc -> ErrorCodeOutOfMem */
+#define SP_ERR_DEVICE           -3   /* HIP runtime error, or no GPU / HIP extension unusable */
+#define SP_ERR_COMPILE          -4   /* rule / regex compilation failed */
+#define SP_ERR_MATCH            -5   /* at least one document failed, see per-document status */
+
+/* per-document status codes written by the kernels (0 = ok) */
+#define SP_DOC_OK                0
+#define SP_DOC_ERR_ORDER         1   /* lexems not in ascending ordpos   (src/patternMatcher.cpp:136-139) */
+#define SP_DOC_ERR_ARENA         2   /* per-document working set exceeded the arena (retry with a larger arena) */
+#define SP_DOC_ERR_KEYTRIGGERS   3   /* >32 identical key events in one pattern (src/ruleMatcherAutomaton.cpp:1213-1216) */
+#define SP_DOC_ERR_PASTFOLLOW    4   /* "encountered past trigger with follow" (src/ruleMatcherAutomaton.cpp:1328-1332) */
+#define SP_DOC_ERR_RANGE         5   /* origsize/origpos out of range    (src/patternMatcher.cpp:144-155) */
+#define SP_DOC_ERR_DATAREF       6   /* "illegal free of event data reference" (src/ruleMatcherAutomaton.cpp:726-731) */
+#define SP_DOC_ERR_LEXEMSIZE     7   /* matched lexem >= 65535 bytes    (src/patternLexer.cpp:727-730) */
+#define SP_DOC_ERR_INTERNAL      8   /* a list walk exceeded its bound: corrupted per-document state (bug) */
+#define SP_DOC_ERR_OUTPUT        9   /* result/item output buffer too small (host entry points grow it and rerun) */
+
+/* strus::PatternMatcherInstanceInterface::JoinOperation, in the order of the switch at
+ * src/patternMatcher.cpp:401-440 */
+enum sp_join_op {
+	SP_OP_SEQUENCE = 0, SP_OP_SEQUENCE_IMM = 1, SP_OP_SEQUENCE_STRUCT = 2,
+	SP_OP_WITHIN = 3, SP_OP_WITHIN_STRUCT = 4, SP_OP_ANY = 5, SP_OP_AND = 6
+};
+
+/* strus::analyzer::PositionBind (src/patternLexer.cpp:902-915) */
+enum sp_position_bind {
+	SP_BIND_CONTENT = 0, SP_BIND_SUCCESSOR = 1, SP_BIND_PREDECESSOR = 2, SP_BIND_UNIQUE = 3
+};
+
+/* analyzer::PatternLexem(id, ordpos, Position(seg, ofs), origsize)  (src/patternLexer.cpp:908).
+ * 16 bytes; the segment index travels in a parallel optional array (always 0 out of the lexer). */
+typedef struct sp_lexem {
+	uint32_t id;
+	uint32_t ordpos;
+	uint32_t origpos;
+	uint32_t origsize;
+} sp_lexem_t;
+
+/* analyzer::PatternMatcherResult minus strings = strus::Result (src/ruleMatcherAutomaton.hpp:273-289),
+ * 36 bytes.  `handle` maps to the pattern name with sp_matcher_pattern_name(). */
+typedef struct sp_result {
+	uint32_t handle;
+	uint32_t ordpos;
+	uint32_t ordend;
+	uint32_t origseg;
+	uint32_t origpos;
+	uint32_t origendseg;
+	uint32_t origend;
+	uint32_t item_begin;   /* index of the first item of this result in the items array */
+	uint32_t item_count;
+} sp_result_t;
+
+/* analyzer::PatternMatcherResultItem minus strings (src/patternMatcher.cpp:182) */
+typedef struct sp_result_item {
+	uint32_t variable;     /* maps to the variable name with sp_matcher_variable_name() */
+	uint32_t ordpos;
+	uint32_t ordend;
+	uint32_t origseg;
+	uint32_t origpos;
+	uint32_t origendseg;
+	uint32_t origend;
+} sp_result_item_t;
+
+/* analyzer::PatternMatcherStatistics items (src/patternMatcher.cpp:303-318) */
+typedef struct sp_matcher_stats {
+	double nofProgramsInstalled;
+	double nofAltKeyProgramsInstalled;
+	double nofSignalsFired;
+	double nofTriggersAvgActive;
+} sp_matcher_stats_t;
+
+typedef struct sp_matcher sp_matcher_t;          /* PatternMatcherInstanceInterface */
+typedef struct sp_matcher_ctx sp_matcher_ctx_t;  /* PatternMatcherContextInterface (+ batch mode) */
+typedef struct sp_lexer sp_lexer_t;              /* PatternLexerInstanceInterface */
+typedef struct sp_lexer_ctx sp_lexer_ctx_t;      /* PatternLexerContextInterface (+ batch mode) */
+
+/* ---- library ---- */
+const char* sp_version(void);
+/* number of usable HIP devices (0 when no GPU is visible); never initialises more than the runtime */
+int sp_device_count(void);
+void sp_free(void* p);
+
+/* ==== level 2: token pattern matcher ==== */
+
+/* strus::createPatternMatcher_std + PatternMatcherInterface::createInstance
+ * (src/libstrus_pattern.cpp:21-33, src/patternMatcher.cpp:718-726) */
+sp_matcher_t* sp_matcher_create(void);
+void sp_matcher_free(sp_matcher_t* m);
+const char* sp_matcher_last_error(const sp_matcher_t* m);
+
+/* PatternMatcherInstanceInterface (src/patternMatcher.cpp:361-671), same argument meaning */
+int sp_matcher_define_term_frequency(sp_matcher_t* m, uint32_t termid, double df);                 /* :361 */
+int sp_matcher_push_term(sp_matcher_t* m, uint32_t termid);                                         /* :366 */
+int sp_matcher_push_expression(sp_matcher_t* m, int joinop, size_t argc, uint32_t range, uint32_t cardinality); /* :377 */
+int sp_matcher_push_pattern(sp_matcher_t* m, const char* name);                                     /* :510 */
+int sp_matcher_attach_variable(sp_matcher_t* m, const char* name);                                  /* :522 */
+int sp_matcher_define_pattern(sp_matcher_t* m, const char* name, const char* formatstring, int visible); /* :545 */
+int sp_matcher_define_option(sp_matcher_t* m, const char* name, double value);                      /* :614 */
+int sp_matcher_compile(sp_matcher_t* m);                                                            /* :646 */
+/* symbol tables behind result handles / item variables (patternMap / variableMap, :82-83) */
+uint32_t sp_matcher_pattern_id(const sp_matcher_t* m, const char* name);
+const char* sp_matcher_pattern_name(const sp_matcher_t* m, uint32_t handle);
+uint32_t sp_matcher_variable_id(const sp_matcher_t* m, const char* name);
+const char* sp_matcher_variable_name(const sp_matcher_t* m, uint32_t variable);
+/* canonical dump of the compiled ProgramTable (test hook; format in csrc/l2_compile.hpp) */
+size_t sp_matcher_dump_table(const sp_matcher_t* m, uint32_t** out);
+
+/* PatternMatcherInstanceInterface::createContext (src/patternMatcher.cpp:586).  `device` is the
+ * HIP device ordinal.  Fails with SP_ERR_DEVICE when no GPU is usable: there is no CPU fallback. */
+sp_matcher_ctx_t* sp_matcher_ctx_create(const sp_matcher_t* m, int device);
+void sp_matcher_ctx_free(sp_matcher_ctx_t* c);
+const char* sp_matcher_ctx_last_error(const sp_matcher_ctx_t* c);
+
+/* PatternMatcherContextInterface::putInput (src/patternMatcher.cpp:131): appends lexems of the
+ * current document (host side, ascending ordpos); origseg may be NULL (= all 0). */
+int sp_matcher_ctx_put_input(sp_matcher_ctx_t* c, const sp_lexem_t* lexems, const uint32_t* origseg, size_t n);
+/* PatternMatcherContextInterface::fetchResults (:271): runs the document on the GPU. */
+int sp_matcher_ctx_fetch_results(sp_matcher_ctx_t* c, sp_result_t** results, size_t* nresults,
+                                 sp_result_item_t** items, size_t* nitems);
+/* PatternMatcherContextInterface::getStatistics (:303) of the last fetch */
+int sp_matcher_ctx_statistics(sp_matcher_ctx_t* c, sp_matcher_stats_t* out);
+/* PatternMatcherContextInterface::reset (:320) */
+int sp_matcher_ctx_reset(sp_matcher_ctx_t* c);
+
+/* ---- batch mode: one Context per document, many documents per launch
+ *      (the reference runs one Context per document per thread,
+ *       tests/randomTokenPatternMatch/src/testRandomTokenPatternMatch.cpp:130-146, :325-345) ---- */
+typedef struct sp_match_batch {
+	size_t ndocs;
+	size_t nresults;
+	size_t nitems;
+	sp_result_t* results;          /* grouped by document, firing order inside a document */
+	sp_result_item_t* items;
+	uint64_t* doc_result_offsets;  /* ndocs+1 */
+	uint64_t* doc_stats;           /* ndocs x 4: programs installed, alt-key programs installed, signals fired, sum of active triggers */
+	int32_t* doc_status;           /* ndocs x SP_DOC_* */
+} sp_match_batch_t;
+
+/* host buffers in, host buffers out (PCIe both ways) */
+int sp_matcher_ctx_match_docs(sp_matcher_ctx_t* c, const sp_lexem_t* lexems, const uint32_t* origseg,
+                              const uint64_t* doc_offsets, size_t ndocs, sp_match_batch_t* out);
+void sp_match_batch_free(sp_match_batch_t* b);
+
+/* device-resident variant: d_lexems / d_origseg (may be NULL) / d_doc_offsets are device pointers,
+ * the launch is asynchronous on `stream` (a hipStream_t, NULL = default stream); results stay in HBM. */
+typedef struct sp_match_device_batch {
+	size_t ndocs;
+	void* d_results;             /* sp_result_t[result_capacity], grouped by document after sp_..._finish */
+	void* d_items;               /* sp_result_item_t[] */
+	void* d_doc_result_offsets;  /* uint64_t[ndocs+1] */
+	void* d_doc_stats;           /* uint64_t[ndocs*4] */
+	void* d_doc_status;          /* int32_t[ndocs] */
+	void* d_counters;            /* uint64_t[8]: results, items, events, failed docs, ... */
+} sp_match_device_batch_t;
+int sp_matcher_ctx_match_docs_device(sp_matcher_ctx_t* c, const void* d_lexems, const void* d_origseg,
+                                     const void* d_doc_offsets, size_t ndocs, size_t nlexems,
+                                     void* stream, sp_match_device_batch_t* out);
+/* waits for the stream and returns counters[0..7] = {results, items, events, failed docs, 0..} */
+int sp_matcher_ctx_batch_counters(sp_matcher_ctx_t* c, uint64_t counters[8]);
+/* duration of the last rule-automaton kernel in milliseconds (HIP events on the launch stream) */
+double sp_matcher_ctx_last_kernel_ms(sp_matcher_ctx_t* c);
+/* working-set capacity per in-flight document; 0 keeps a default.  Takes effect at the next launch. */
+int sp_matcher_ctx_set_arena(sp_matcher_ctx_t* c, uint32_t max_rules, uint32_t max_triggers, uint32_t bucket_capacity,
+                             uint32_t max_items, uint32_t max_follow);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

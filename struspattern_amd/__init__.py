@@ -1,0 +1,231 @@
+"""struspattern_amd -- MI355X-native two-level pattern engine behind the strus pattern API.
+
+Python mirror of the reference's plugin interfaces for the hot path (same method names and
+argument meaning as src/patternMatcher.cpp / src/patternLexer.cpp of strusPattern), layered on
+the C-ABI of libstruspattern_amd.so (include/strus_pattern_amd.h).  The native library is the
+product; there is no Python/CPU fallback for matching.
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+from .capi import SpLexem, SpResult, SpResultItem
+
+__all__ = ["PatternMatcher", "PatternMatcherInstance", "PatternMatcherContext", "PatternError", "JOIN_OP"]
+
+JOIN_OP = {"sequence": 0, "sequence_imm": 1, "sequence_struct": 2, "within": 3, "within_struct": 4, "any": 5, "and": 6}
+
+DOC_STATUS = {
+    0: "ok", 1: "term events not fed in ascending order", 2: "working set of the document exceeds the arena",
+    3: "pattern with too many identical key events defined", 4: "internal: encountered past trigger with follow",
+    5: "term event out of range", 6: "illegal free of event data reference",
+}
+
+
+class PatternError(RuntimeError):
+    pass
+
+
+class MatchBatch:
+    """Results of a batch of documents (host copies)."""
+
+    def __init__(self, results, items, doc_offsets, stats, status):
+        self.results = results          # (n, 9) u32: handle, ordpos, ordend, origseg, origpos, origendseg, origend, item_begin, item_count
+        self.items = items              # (m, 7) u32: variable, ordpos, ordend, origseg, origpos, origendseg, origend
+        self.doc_offsets = doc_offsets  # (ndocs+1,) u64
+        self.stats = stats              # (ndocs, 4) u64
+        self.status = status            # (ndocs,) i32
+
+    def doc(self, i):
+        return self.results[self.doc_offsets[i]:self.doc_offsets[i + 1]]
+
+
+class PatternMatcherContext:
+    """PatternMatcherContextInterface (src/patternMatcher.cpp:107-341) + batch mode."""
+
+    def __init__(self, instance, device=0):
+        self._L = capi.lib()
+        self._inst = instance  # keeps the instance alive: a context borrows its tables
+        self._h = self._L.sp_matcher_ctx_create(instance._h, device)
+        if not self._h:
+            raise PatternError("failed to create pattern match context: " + self._L.sp_matcher_last_error(instance._h).decode())
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.sp_matcher_ctx_free(self._h)
+        except Exception:
+            pass
+
+    def _err(self):
+        return self._L.sp_matcher_ctx_last_error(self._h).decode()
+
+    def setArena(self, max_rules=0, max_triggers=0, bucket_capacity=0, max_items=0, max_follow=0):
+        self._L.sp_matcher_ctx_set_arena(self._h, max_rules, max_triggers, bucket_capacity, max_items, max_follow)
+
+    # -- single document mode
+    def putInput(self, lexem_id, ordpos, origpos, origsize, origseg=0):
+        lx = SpLexem(lexem_id, ordpos, origpos, origsize)
+        seg = ctypes.c_uint32(origseg)
+        rc = self._L.sp_matcher_ctx_put_input(self._h, ctypes.addressof(lx), ctypes.addressof(seg) if origseg else None, 1)
+        if rc != 0:
+            raise PatternError("failed to feed input to pattern matcher: " + self._err())
+
+    def fetchResults(self):
+        res = ctypes.POINTER(SpResult)()
+        items = ctypes.POINTER(SpResultItem)()
+        nres = ctypes.c_size_t()
+        nitems = ctypes.c_size_t()
+        rc = self._L.sp_matcher_ctx_fetch_results(self._h, ctypes.byref(res), ctypes.byref(nres), ctypes.byref(items), ctypes.byref(nitems))
+        if rc != 0:
+            raise PatternError("failed to fetch pattern match result: " + self._err())
+        try:
+            r = np.ctypeslib.as_array(ctypes.cast(res, ctypes.POINTER(ctypes.c_uint32)), shape=(nres.value * 9 + 1,))[:nres.value * 9].reshape(-1, 9).copy()
+            it = np.ctypeslib.as_array(ctypes.cast(items, ctypes.POINTER(ctypes.c_uint32)), shape=(nitems.value * 7 + 1,))[:nitems.value * 7].reshape(-1, 7).copy()
+        finally:
+            self._L.sp_free(res)
+            self._L.sp_free(items)
+        return r, it
+
+    def getStatistics(self):
+        st = capi.SpMatcherStats()
+        self._L.sp_matcher_ctx_statistics(self._h, ctypes.byref(st))
+        return {n: getattr(st, n) for n, _ in capi.SpMatcherStats._fields_}
+
+    def reset(self):
+        self._L.sp_matcher_ctx_reset(self._h)
+
+    # -- batch mode (host buffers)
+    def matchDocs(self, lexems, doc_offsets, origseg=None, check=True):
+        """lexems: (n,4) u32 [id, ordpos, origpos, origsize]; doc_offsets: (ndocs+1,) u64."""
+        lexems = np.ascontiguousarray(lexems, dtype=np.uint32).reshape(-1, 4)
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        ndocs = len(doc_offsets) - 1
+        segp = None
+        if origseg is not None:
+            origseg = np.ascontiguousarray(origseg, dtype=np.uint32)
+            segp = origseg.ctypes.data
+        b = capi.SpMatchBatch()
+        rc = self._L.sp_matcher_ctx_match_docs(self._h, lexems.ctypes.data, segp, doc_offsets.ctypes.data, ndocs, ctypes.byref(b))
+        try:
+            if rc != 0 and (rc != -5 or check):
+                raise PatternError("batch match failed (%d): %s" % (rc, self._err()))
+            u32p = ctypes.POINTER(ctypes.c_uint32)
+            res = np.ctypeslib.as_array(ctypes.cast(b.results, u32p), shape=(b.nresults * 9 + 1,))[:b.nresults * 9].reshape(-1, 9).copy()
+            items = np.ctypeslib.as_array(ctypes.cast(b.items, u32p), shape=(b.nitems * 7 + 1,))[:b.nitems * 7].reshape(-1, 7).copy()
+            offs = np.ctypeslib.as_array(b.doc_result_offsets, shape=(ndocs + 1,)).copy()
+            stats = np.ctypeslib.as_array(b.doc_stats, shape=(ndocs * 4 + 1,))[:ndocs * 4].reshape(-1, 4).copy()
+            status = np.ctypeslib.as_array(b.doc_status, shape=(ndocs + 1,))[:ndocs].copy()
+        finally:
+            self._L.sp_match_batch_free(ctypes.byref(b))
+        return MatchBatch(res, items, offs, stats, status)
+
+    # -- batch mode (device-resident buffers; pointers are raw device addresses, e.g. torch data_ptr())
+    def matchDocsDevice(self, d_lexems, d_doc_offsets, ndocs, nlexems, stream=0, d_origseg=0):
+        out = capi.SpMatchDeviceBatch()
+        rc = self._L.sp_matcher_ctx_match_docs_device(self._h, d_lexems, d_origseg or None, d_doc_offsets, ndocs, nlexems, stream or None, ctypes.byref(out))
+        if rc != 0:
+            raise PatternError("device batch match failed (%d): %s" % (rc, self._err()))
+        return out
+
+    def batchCounters(self):
+        arr = (ctypes.c_uint64 * 8)()
+        rc = self._L.sp_matcher_ctx_batch_counters(self._h, arr)
+        if rc != 0:
+            raise PatternError("reading batch counters failed: " + self._err())
+        return {"results": arr[0], "items": arr[1], "events": arr[2], "failed_docs": arr[3]}
+
+    def lastKernelMs(self):
+        return self._L.sp_matcher_ctx_last_kernel_ms(self._h)
+
+
+class PatternMatcherInstance:
+    """PatternMatcherInstanceInterface (src/patternMatcher.cpp:345-733)."""
+
+    def __init__(self):
+        self._L = capi.lib()
+        self._h = self._L.sp_matcher_create()
+        if not self._h:
+            raise PatternError("failed to create pattern matcher instance")
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.sp_matcher_free(self._h)
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise PatternError("%s: %s" % (what, self._L.sp_matcher_last_error(self._h).decode()))
+
+    def defineTermFrequency(self, termid, df):
+        self._chk(self._L.sp_matcher_define_term_frequency(self._h, termid, df), "failed to define term frequency")
+
+    def pushTerm(self, termid):
+        self._chk(self._L.sp_matcher_push_term(self._h, termid), "failed to push term on the pattern match expression stack")
+
+    def pushExpression(self, joinop, argc, range_, cardinality=0):
+        op = JOIN_OP[joinop] if isinstance(joinop, str) else int(joinop)
+        self._chk(self._L.sp_matcher_push_expression(self._h, op, argc, range_, cardinality), "failed to push expression on the pattern match expression stack")
+
+    def pushPattern(self, name):
+        self._chk(self._L.sp_matcher_push_pattern(self._h, name.encode()), "failed to push pattern reference on the pattern match expression stack")
+
+    def attachVariable(self, name):
+        self._chk(self._L.sp_matcher_attach_variable(self._h, name.encode()), "failed to attach variable to top element of the pattern match expression stack")
+
+    def definePattern(self, name, formatstring="", visible=True):
+        self._chk(self._L.sp_matcher_define_pattern(self._h, name.encode(), formatstring.encode(), int(visible)), "failed to close pattern definition on the pattern match expression stack")
+
+    def defineOption(self, name, value=0.0):
+        self._chk(self._L.sp_matcher_define_option(self._h, name.encode(), value), "failed to define pattern matching automaton option")
+
+    def compile(self):
+        self._chk(self._L.sp_matcher_compile(self._h), "failed to compile (optimize) pattern matching automaton")
+        return True
+
+    def createContext(self, device=0):
+        return PatternMatcherContext(self, device)
+
+    def patternId(self, name):
+        return self._L.sp_matcher_pattern_id(self._h, name.encode())
+
+    def patternName(self, handle):
+        s = self._L.sp_matcher_pattern_name(self._h, handle)
+        return s.decode() if s else None
+
+    def variableId(self, name):
+        return self._L.sp_matcher_variable_id(self._h, name.encode())
+
+    def variableName(self, vid):
+        s = self._L.sp_matcher_variable_name(self._h, vid)
+        return s.decode() if s else None
+
+    def dumpTable(self):
+        p = ctypes.POINTER(ctypes.c_uint32)()
+        n = self._L.sp_matcher_dump_table(self._h, ctypes.byref(p))
+        arr = np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        self._L.sp_free(p)
+        return arr
+
+    def name(self):
+        return "std"
+
+
+class PatternMatcher:
+    """PatternMatcherInterface (src/patternMatcher.hpp:31-35)."""
+
+    def getCompileOptionNames(self):
+        return ["stopwordOccurrenceFactor", "weightFactor", "maxRange", "exclusive"]  # src/patternMatcher.cpp:707-716
+
+    def createInstance(self):
+        return PatternMatcherInstance()
+
+    def name(self):
+        return "std"
+
+
+def device_count():
+    return capi.lib().sp_device_count()

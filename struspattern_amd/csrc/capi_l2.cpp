@@ -1,0 +1,566 @@
+// C-ABI of level 2 (include/strus_pattern_amd.h): rule compiler handle + GPU match context.
+// No CPU fallback: a context cannot be created without a usable HIP device.
+#include "../../include/strus_pattern_amd.h"
+#include "l2_compile.hpp"
+#include "l2_device.h"
+#include "hip_util.hpp"
+#include <hip/hip_runtime_api.h>
+#include <cstdlib>
+#include <cstdio>
+#include <unistd.h>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace spa {
+hipError_t launchL2Match( const L2Params& P, unsigned nblocks, hipStream_t stream);
+}
+
+using namespace spa;
+
+struct sp_matcher
+{
+	RuleCompiler compiler;
+	bool compiled;		// compile() is optional for the matcher (reference: tests/randomTokenPatternMatch :317-320)
+	mutable std::string lasterror;
+	sp_matcher() :compiled(false){}
+};
+
+namespace {
+
+template <class FN>
+int guardedCall( std::string& err, int errcode, FN fn)
+{
+	try { fn(); return SP_OK; }
+	catch (const std::bad_alloc&) { err = "memory allocation error in strus pattern"; return SP_ERR_NOMEM; }
+	catch (const HipError& e) { err = e.what(); return SP_ERR_DEVICE; }
+	catch (const std::exception& e) { err = e.what(); return errcode; }
+}
+
+uint32_t alignUp( uint32_t v, uint32_t a) { return (v + a-1) / a * a; }
+
+void layoutArena( ArenaLayout& L)
+{
+	uint32_t o = 0;
+	L.oRules = o;	o += alignUp( L.maxRules*12, 4);
+	L.oTrigs = o;	o += alignUp( L.maxTrigs*8, 4);
+	L.oBEvent = o;	o += alignUp( 16*L.bucketCap, 16);
+	L.oBIdx = o;	o += alignUp( 16*L.bucketCap, 16);
+	L.oBSize = o;	o += 16;
+	L.oWindow = o;	o += 64;
+	L.oHeap = o;	o += alignUp( L.maxHeap*2, 4);
+	L.oFollow = o;	o += alignUp( L.maxFollow*12, 4);
+	L.oDispose = o;	o += alignUp( L.maxDispose, 4);
+	L.oStop = o;	o += alignUp( (L.nStop?L.nStop:1)*12, 4);
+	L.oItems = o;	o += alignUp( L.maxItems*12, 4);
+	L.oRefs = o;	o += alignUp( L.maxRefs*2, 4);
+	L.oGStack = o;	o += alignUp( L.maxGStack, 4);
+	L.oStaged = o;	o += alignUp( L.maxStaged*8, 4);
+	L.totalWords = alignUp( o, 64);
+}
+
+} // namespace
+
+struct sp_matcher_ctx
+{
+	const sp_matcher* inst;
+	int device;
+	std::string lasterror;
+	// device tables
+	DeviceBuffer dPrograms, dTrigdefs, dKeytab, dKeylist;
+	uint32_t keymask, nofStopWords;
+	// working memory
+	ArenaLayout arena;
+	DeviceBuffer dArena; unsigned arenaWaves;
+	DeviceBuffer dCursor, dCounters;
+	// batch buffers (grown on demand)
+	DeviceBuffer dLexems, dOrigseg, dDocOffsets, dResults, dItems, dDocRange, dDocStats, dDocStatus;
+	uint64_t resultCapacity, itemCapacity, minResultCapacity, minItemCapacity;
+	size_t lastNdocs;
+	hipEvent_t evStart, evStop; bool evValid;
+	hipStream_t lastStream;
+	bool withItems;
+	unsigned numCUs;
+	// single-document mode
+	std::vector<sp_lexem_t> curLexems;
+	std::vector<uint32_t> curOrigseg; bool curHasSeg;
+	sp_matcher_stats_t lastStats;
+
+	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),arenaWaves(0),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
+		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
+	{
+		std::memset( &arena, 0, sizeof(arena));
+		std::memset( &lastStats, 0, sizeof(lastStats));
+		// defaults sized for 10k-rule tables over ~1000-token documents; sp_matcher_ctx_set_arena overrides
+		arena.maxRules = 8192; arena.maxTrigs = 8192; arena.bucketCap = 2048; arena.maxItems = 16384;
+		arena.maxRefs = 8192; arena.maxFollow = 1024; arena.maxDispose = 2048; arena.maxHeap = 8192;
+		arena.maxGStack = 256; arena.maxStaged = 8192;
+	}
+};
+
+extern "C" {
+
+const char* sp_version(void) { return "struspattern_amd 0.1 (gfx950)"; }
+
+int sp_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount( &n) != hipSuccess) return 0;
+	return n;
+}
+
+void sp_free( void* p) { std::free( p); }
+
+// ------------------------------------------------------------------ instance
+sp_matcher_t* sp_matcher_create(void)
+{
+	try { return new sp_matcher(); } catch (...) { return 0; }
+}
+void sp_matcher_free( sp_matcher_t* m) { delete m; }
+const char* sp_matcher_last_error( const sp_matcher_t* m) { return m->lasterror.c_str(); }
+
+#define MGUARD( CODE, BODY) return guardedCall( m->lasterror, CODE, [&]{ BODY; })
+
+int sp_matcher_define_term_frequency( sp_matcher_t* m, uint32_t termid, double df)
+{ MGUARD( SP_ERR_INVALID, m->compiler.defineTermFrequency( termid, df)); }
+int sp_matcher_push_term( sp_matcher_t* m, uint32_t termid)
+{ MGUARD( SP_ERR_INVALID, m->compiler.pushTerm( termid)); }
+int sp_matcher_push_expression( sp_matcher_t* m, int joinop, size_t argc, uint32_t range, uint32_t cardinality)
+{ MGUARD( SP_ERR_INVALID, m->compiler.pushExpression( joinop, argc, range, cardinality)); }
+int sp_matcher_push_pattern( sp_matcher_t* m, const char* name)
+{ MGUARD( SP_ERR_INVALID, m->compiler.pushPattern( name ? name : "")); }
+int sp_matcher_attach_variable( sp_matcher_t* m, const char* name)
+{ MGUARD( SP_ERR_INVALID, m->compiler.attachVariable( name ? name : "")); }
+int sp_matcher_define_pattern( sp_matcher_t* m, const char* name, const char* formatstring, int visible)
+{ MGUARD( SP_ERR_INVALID, m->compiler.definePattern( name ? name : "", formatstring ? formatstring : "", visible != 0)); }
+int sp_matcher_define_option( sp_matcher_t* m, const char* name, double value)
+{ MGUARD( SP_ERR_INVALID, m->compiler.defineOption( name ? name : "", value)); }
+int sp_matcher_compile( sp_matcher_t* m)
+{ MGUARD( SP_ERR_COMPILE, m->compiler.compile(); m->compiled = true); }
+
+uint32_t sp_matcher_pattern_id( const sp_matcher_t* m, const char* name) { return m->compiler.patterns().get( name); }
+const char* sp_matcher_pattern_name( const sp_matcher_t* m, uint32_t handle) { return m->compiler.patterns().key( handle); }
+uint32_t sp_matcher_variable_id( const sp_matcher_t* m, const char* name) { return m->compiler.variables().get( name); }
+const char* sp_matcher_variable_name( const sp_matcher_t* m, uint32_t variable) { return m->compiler.variables().key( variable); }
+
+size_t sp_matcher_dump_table( const sp_matcher_t* m, uint32_t** out)
+{
+	std::vector<uint32_t> buf = m->compiler.dump();
+	*out = (uint32_t*)std::malloc( buf.size()*sizeof(uint32_t) + 4);
+	if (!*out) return 0;
+	std::memcpy( *out, buf.data(), buf.size()*sizeof(uint32_t));
+	return buf.size();
+}
+
+// ------------------------------------------------------------------ context
+sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
+{
+	sp_matcher_ctx* c = 0;
+	try
+	{
+		c = new sp_matcher_ctx();
+		c->inst = m; c->device = device;
+		int ndev = 0;
+		hipError_t e = hipGetDeviceCount( &ndev);
+		if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+		{
+			m->lasterror = "no usable HIP device: the rule automaton runs on the GPU only (no CPU fallback)";
+			delete c; return 0;
+		}
+		HIP_CHECK( hipSetDevice( device));
+		hipDeviceProp_t prop;
+		HIP_CHECK( hipGetDeviceProperties( &prop, device));
+		c->numCUs = prop.multiProcessorCount > 0 ? (unsigned)prop.multiProcessorCount : 256u;
+
+		FlatTables ft;
+		m->compiler.flatten( ft);
+		c->dPrograms.upload( ft.programs.data(), ft.programs.size()*sizeof(DevProgram));
+		c->dTrigdefs.upload( ft.trigdefs.data(), ft.trigdefs.size()*sizeof(DevTrigDef));
+		c->dKeytab.upload( ft.keytab.data(), ft.keytab.size()*sizeof(DevKeyEntry));
+		c->dKeylist.upload( ft.keylist.data(), ft.keylist.size()*sizeof(DevKeyRef));
+		c->keymask = (uint32_t)ft.keytab.size()-1;
+		c->nofStopWords = ft.nofStopWords;
+		c->arena.nStop = ft.nofStopWords;
+		c->dCursor.alloc( 64);
+		c->dCounters.alloc( SPC_COUNT*sizeof(uint64_t));
+		HIP_CHECK( hipEventCreate( &c->evStart));
+		HIP_CHECK( hipEventCreate( &c->evStop));
+		return c;
+	}
+	catch (const std::exception& e)
+	{
+		m->lasterror = e.what();
+		delete c;
+		return 0;
+	}
+}
+
+void sp_matcher_ctx_free( sp_matcher_ctx_t* c)
+{
+	if (!c) return;
+	if (c->evStart) (void)hipEventDestroy( c->evStart);
+	if (c->evStop) (void)hipEventDestroy( c->evStop);
+	delete c;
+}
+const char* sp_matcher_ctx_last_error( const sp_matcher_ctx_t* c) { return c->lasterror.c_str(); }
+
+int sp_matcher_ctx_set_arena( sp_matcher_ctx_t* c, uint32_t max_rules, uint32_t max_triggers, uint32_t bucket_capacity,
+				uint32_t max_items, uint32_t max_follow)
+{
+	if (max_rules) { c->arena.maxRules = max_rules; c->arena.maxHeap = max_rules; c->arena.maxDispose = max_rules < 2048 ? 2048 : max_rules; }
+	if (max_triggers) c->arena.maxTrigs = max_triggers;
+	if (bucket_capacity) c->arena.bucketCap = bucket_capacity;
+	if (max_items) { c->arena.maxItems = max_items; c->arena.maxRefs = max_items; }
+	if (max_follow) { c->arena.maxFollow = max_follow; }
+	c->arenaWaves = 0;	// forces re-layout at the next launch
+	return SP_OK;
+}
+
+} // extern "C"
+
+namespace {
+
+// enqueue one batch on `stream`; all inputs are device pointers
+void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg, const void* d_doc_offsets,
+		  size_t ndocs, size_t nlexems, hipStream_t stream)
+{
+	HIP_CHECK( hipSetDevice( c->device));
+	// geometry: 4 waves per 256-thread block; as many blocks as keep every CU busy, never more waves than documents
+	unsigned wavesWanted = (unsigned)((ndocs < (size_t)c->numCUs*12) ? ndocs : (size_t)c->numCUs*12);
+	unsigned nblocks = (wavesWanted + 3) / 4;
+	if (nblocks == 0) nblocks = 1;
+	unsigned nwaves = nblocks*4;
+	layoutArena( c->arena);
+	{
+		// keep the arena below ~48 GiB: fewer resident waves when documents need a large working set
+		size_t perWave = (size_t)c->arena.totalWords * sizeof(uint32_t);
+		size_t maxWaves = ((size_t)48 << 30) / perWave;
+		if (maxWaves < 4) maxWaves = 4;
+		if (nwaves > maxWaves) { nblocks = (unsigned)(maxWaves/4); nwaves = nblocks*4; }
+	}
+	if (c->arenaWaves < nwaves)
+	{
+		size_t perWave = (size_t)c->arena.totalWords * sizeof(uint32_t);
+		size_t full = (size_t)c->numCUs*12;
+		if (full * perWave > ((size_t)48 << 30)) full = ((size_t)48 << 30) / perWave;
+		unsigned alloc = nwaves < full ? (unsigned)full : nwaves;	// allocate for the full machine once
+		c->dArena.alloc( (size_t)alloc * perWave);
+		c->arenaWaves = alloc;
+	}
+	// output capacity: results are bounded by what fits; sized from the input, grown by the caller on SP_DOC_ERR_ARENA
+	uint64_t wantResults = (uint64_t)nlexems*2 + 1024;
+	if (wantResults < c->minResultCapacity) wantResults = c->minResultCapacity;
+	if (c->resultCapacity < wantResults)
+	{
+		c->dResults.alloc( wantResults*sizeof(sp_result_t));
+		c->resultCapacity = wantResults;
+	}
+	uint64_t wantItems = (uint64_t)nlexems*6 + 1024;
+	if (wantItems < c->minItemCapacity) wantItems = c->minItemCapacity;
+	if (c->itemCapacity < wantItems)
+	{
+		c->dItems.alloc( wantItems*sizeof(sp_result_item_t));
+		c->itemCapacity = wantItems;
+	}
+	c->dDocRange.reserve( (ndocs+1)*2*sizeof(uint64_t));
+	c->dDocStats.reserve( (ndocs+1)*4*sizeof(uint64_t));
+	c->dDocStatus.reserve( (ndocs+1)*sizeof(int32_t));
+
+	HIP_CHECK( hipMemsetAsync( c->dCursor.ptr, 0, 64, stream));
+	HIP_CHECK( hipMemsetAsync( c->dCounters.ptr, 0, SPC_COUNT*sizeof(uint64_t), stream));
+
+	L2Params P;
+	std::memset( &P, 0, sizeof(P));
+	P.programs = (const DevProgram*)c->dPrograms.ptr;
+	P.trigdefs = (const DevTrigDef*)c->dTrigdefs.ptr;
+	P.keytab = (const DevKeyEntry*)c->dKeytab.ptr;
+	P.keylist = (const DevKeyRef*)c->dKeylist.ptr;
+	P.keymask = c->keymask; P.nofStopWords = c->nofStopWords;
+	P.lexems = (const uint32_t*)d_lexems; P.origseg = (const uint32_t*)d_origseg;
+	P.docOffsets = (const uint64_t*)d_doc_offsets;
+	P.ndocs = (uint32_t)ndocs; P.withItems = c->withItems ? 1u : 0u;
+	P.arenaBase = (uint32_t*)c->dArena.ptr; P.arena = c->arena;
+	P.docCursor = (uint32_t*)c->dCursor.ptr;
+	P.counters = (uint64_t*)c->dCounters.ptr;
+	P.results = (uint32_t*)c->dResults.ptr; P.resultCapacity = c->resultCapacity;
+	P.items = (uint32_t*)c->dItems.ptr; P.itemCapacity = c->itemCapacity;
+	P.docRange = (uint64_t*)c->dDocRange.ptr;
+	P.docStats = (uint64_t*)c->dDocStats.ptr;
+	P.docStatus = (int32_t*)c->dDocStatus.ptr;
+
+#if defined(SPA_TRACE) || defined(SPA_POLL)
+	static uint32_t* traceHost = 0;
+	if (!traceHost && (getenv("SPA_HOSTALLOC") || 
+#ifdef SPA_TRACE
+		1
+#else
+		0
+#endif
+		))
+	{
+		HIP_CHECK( hipHostMalloc( (void**)&traceHost, 4096, hipHostMallocMapped));
+		std::memset( traceHost, 0xEE, 4096);
+	}
+	void* traceDev = 0;
+	if (traceHost) HIP_CHECK( hipHostGetDevicePointer( &traceDev, traceHost, 0));
+	P.trace = (uint32_t*)traceDev;
+#endif
+	HIP_CHECK( hipEventRecord( c->evStart, stream));
+	HIP_CHECK( launchL2Match( P, nblocks, stream));
+	HIP_CHECK( hipEventRecord( c->evStop, stream));
+#if defined(SPA_TRACE) || defined(SPA_POLL)
+	static uint32_t traceDummy[16];
+	uint32_t* traceShow = traceHost ? traceHost : traceDummy;
+	for (int waited=0; hipStreamQuery( stream) == hipErrorNotReady; ++waited)
+	{
+		usleep( 100000);
+		if (waited == 100 || waited == 150)
+		{
+			fprintf( stderr, "[spa trace] kernel still running after %d ms:", waited*100);
+			for (int i=0; i<16; ++i) fprintf( stderr, " [%d]=%u", i, traceShow[i]);
+			fprintf( stderr, "\n");
+			if (waited == 150) { fflush( stderr); _exit( 3); }
+		}
+	}
+#endif
+	c->evValid = true; c->lastStream = stream; c->lastNdocs = ndocs;
+}
+
+} // namespace
+
+extern "C" {
+
+int sp_matcher_ctx_match_docs_device( sp_matcher_ctx_t* c, const void* d_lexems, const void* d_origseg,
+				      const void* d_doc_offsets, size_t ndocs, size_t nlexems,
+				      void* stream, sp_match_device_batch_t* out)
+{
+	return guardedCall( c->lasterror, SP_ERR_INVALID, [&]{
+		if (ndocs >= 0xFFFFFFFFull) throw std::runtime_error( "too many documents in one batch");
+		launchBatch( c, d_lexems, d_origseg, d_doc_offsets, ndocs, nlexems, (hipStream_t)stream);
+		if (out)
+		{
+			out->ndocs = ndocs;
+			out->d_results = c->dResults.ptr; out->d_items = c->dItems.ptr;
+			out->d_doc_result_offsets = c->dDocRange.ptr;
+			out->d_doc_stats = c->dDocStats.ptr; out->d_doc_status = c->dDocStatus.ptr;
+			out->d_counters = c->dCounters.ptr;
+		}
+	});
+}
+
+int sp_matcher_ctx_batch_counters( sp_matcher_ctx_t* c, uint64_t counters[8])
+{
+	return guardedCall( c->lasterror, SP_ERR_DEVICE, [&]{
+		HIP_CHECK( hipSetDevice( c->device));
+		HIP_CHECK( hipStreamSynchronize( c->lastStream));
+		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, SPC_COUNT*sizeof(uint64_t), hipMemcpyDeviceToHost));
+	});
+}
+
+double sp_matcher_ctx_last_kernel_ms( sp_matcher_ctx_t* c)
+{
+	if (!c->evValid) return -1.0;
+	float ms = 0.0f;
+	if (hipEventSynchronize( c->evStop) != hipSuccess) return -1.0;
+	if (hipEventElapsedTime( &ms, c->evStart, c->evStop) != hipSuccess) return -1.0;
+	return (double)ms;
+}
+
+int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, const uint32_t* origseg,
+			       const uint64_t* doc_offsets, size_t ndocs, sp_match_batch_t* out)
+{
+	std::memset( out, 0, sizeof(*out));
+	return guardedCall( c->lasterror, SP_ERR_INVALID, [&]{
+		HIP_CHECK( hipSetDevice( c->device));
+		size_t nlex = ndocs ? (size_t)doc_offsets[ ndocs] : 0;
+		c->dLexems.reserve( (nlex+1)*sizeof(sp_lexem_t));
+		c->dDocOffsets.reserve( (ndocs+1)*sizeof(uint64_t));
+		if (nlex) HIP_CHECK( hipMemcpy( c->dLexems.ptr, lexems, nlex*sizeof(sp_lexem_t), hipMemcpyHostToDevice));
+		HIP_CHECK( hipMemcpy( c->dDocOffsets.ptr, doc_offsets, (ndocs+1)*sizeof(uint64_t), hipMemcpyHostToDevice));
+		const void* dseg = 0;
+		if (origseg)
+		{
+			c->dOrigseg.reserve( (nlex+1)*sizeof(uint32_t));
+			if (nlex) HIP_CHECK( hipMemcpy( c->dOrigseg.ptr, origseg, nlex*sizeof(uint32_t), hipMemcpyHostToDevice));
+			dseg = c->dOrigseg.ptr;
+		}
+		uint64_t counters[ SPC_COUNT];
+		for (int attempt=0;; ++attempt)
+		{
+			launchBatch( c, c->dLexems.ptr, dseg, c->dDocOffsets.ptr, ndocs, nlex, 0);
+			HIP_CHECK( hipStreamSynchronize( 0));
+			HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
+			// the output counters keep counting past the capacity: if the buffers were too small,
+			// grow them to what this batch needs and run it again (the kernel is deterministic)
+			bool grow = false;
+			if (counters[ SPC_RESULTS] > c->resultCapacity) { c->minResultCapacity = counters[ SPC_RESULTS] + counters[ SPC_RESULTS]/8 + 1024; grow = true; }
+			if (counters[ SPC_ITEMS] > c->itemCapacity) { c->minItemCapacity = counters[ SPC_ITEMS] + counters[ SPC_ITEMS]/8 + 1024; grow = true; }
+			if (!grow && counters[ SPC_FAILED])
+			{
+				// documents whose working set exceeded the per-wave arena: double the arena and rerun
+				std::vector<int32_t> st( ndocs);
+				HIP_CHECK( hipMemcpy( st.data(), c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+				bool arena = false;
+				for (size_t di=0; di<ndocs && !arena; ++di) arena = (st[ di] == SPD_ERR_ARENA);
+				if (arena && c->arena.maxRules < (1u<<20))
+				{
+					c->arena.maxRules *= 2; c->arena.maxTrigs *= 2; c->arena.bucketCap *= 2; c->arena.maxItems *= 2;
+					c->arena.maxRefs *= 2; c->arena.maxFollow *= 2; c->arena.maxDispose *= 2; c->arena.maxHeap *= 2;
+					c->arena.maxStaged *= 2; c->arena.maxGStack *= 2;
+					c->arenaWaves = 0;
+					grow = true;
+				}
+			}
+			if (!grow || attempt >= 6) break;
+		}
+		std::vector<uint64_t> range( ndocs*2+2);
+		if (ndocs) HIP_CHECK( hipMemcpy( range.data(), c->dDocRange.ptr, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
+		out->ndocs = ndocs;
+		out->doc_stats = (uint64_t*)std::malloc( (ndocs*4+1)*sizeof(uint64_t));
+		out->doc_status = (int32_t*)std::malloc( (ndocs+1)*sizeof(int32_t));
+		out->doc_result_offsets = (uint64_t*)std::malloc( (ndocs+1)*sizeof(uint64_t));
+		if (!out->doc_stats || !out->doc_status || !out->doc_result_offsets) throw std::bad_alloc();
+		if (ndocs)
+		{
+			HIP_CHECK( hipMemcpy( out->doc_stats, c->dDocStats.ptr, ndocs*4*sizeof(uint64_t), hipMemcpyDeviceToHost));
+			HIP_CHECK( hipMemcpy( out->doc_status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+		}
+		uint64_t nres = counters[ SPC_RESULTS] < c->resultCapacity ? counters[ SPC_RESULTS] : c->resultCapacity;
+		uint64_t nitems = counters[ SPC_ITEMS] < c->itemCapacity ? counters[ SPC_ITEMS] : c->itemCapacity;
+		std::vector<sp_result_t> raw( nres+1);
+		std::vector<sp_result_item_t> rawitems( nitems+1);
+		if (nres) HIP_CHECK( hipMemcpy( raw.data(), c->dResults.ptr, nres*sizeof(sp_result_t), hipMemcpyDeviceToHost));
+		if (nitems) HIP_CHECK( hipMemcpy( rawitems.data(), c->dItems.ptr, nitems*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
+		// regroup by document (the device appends whole documents in completion order)
+		uint64_t total = 0, totalItems = 0;
+		for (size_t di=0; di<ndocs; ++di)
+		{
+			if (out->doc_status[ di] != 0) { range[ 2*di+1] = 0; continue; }
+			total += range[ 2*di+1];
+			for (uint64_t ri=0; ri<range[ 2*di+1]; ++ri) totalItems += raw[ range[ 2*di]+ri].item_count;
+		}
+		out->results = (sp_result_t*)std::malloc( (total+1)*sizeof(sp_result_t));
+		out->items = (sp_result_item_t*)std::malloc( (totalItems+1)*sizeof(sp_result_item_t));
+		if (!out->results || !out->items) throw std::bad_alloc();
+		uint64_t rp = 0, ip = 0;
+		// `exclusive` option: covered results are dropped on the way out (src/patternMatcher.cpp:192-246, :278-289)
+		const bool exclusive = c->inst->compiler.exclusive();
+		const uint32_t maxResultSize = c->inst->compiler.maxResultSize();
+		std::vector<char> covered;
+		for (size_t di=0; di<ndocs; ++di)
+		{
+			out->doc_result_offsets[ di] = rp;
+			const uint64_t b = range[ 2*di], n = range[ 2*di+1];
+			if (exclusive)
+			{
+				covered.assign( n, 0);
+				for (uint64_t ai=0; ai<n; ++ai)
+				{
+					const sp_result_t& r = raw[ b+ai];
+					for (uint64_t ni=ai; ni<n; ++ni)
+					{
+						const sp_result_t& f = raw[ b+ni];
+						if (f.origseg > r.origendseg || f.origpos >= r.origend + maxResultSize) break;
+						bool differ = (f.origendseg != r.origendseg || f.origend != r.origend || f.origseg != r.origseg || f.origpos != r.origpos);
+						if (f.origseg <= r.origseg && f.origpos <= r.origpos && f.origendseg >= r.origendseg && f.origend >= r.origend && differ) covered[ ai] = 1;
+						if (f.origseg >= r.origseg && f.origpos >= r.origpos && f.origendseg <= r.origendseg && f.origend <= r.origend && differ) covered[ ni] = 1;
+					}
+				}
+			}
+			for (uint64_t ri=0; ri<n; ++ri)
+			{
+				if (exclusive && covered[ ri]) continue;
+				sp_result_t r = raw[ b+ri];
+				uint32_t ib = r.item_begin, ic = r.item_count;
+				r.item_begin = (uint32_t)ip;
+				for (uint32_t k=0; k<ic; ++k) out->items[ ip++] = rawitems[ ib+k];
+				out->results[ rp++] = r;
+			}
+		}
+		out->doc_result_offsets[ ndocs] = rp;
+		out->nresults = rp; out->nitems = ip;
+		if (counters[ SPC_FAILED])
+		{
+			size_t bad = 0;
+			while (bad < ndocs && out->doc_status[ bad] == 0) ++bad;
+			char msg[ 128];
+			snprintf( msg, sizeof(msg), "at least one document failed: document %zu has status %d (see doc_status)", bad, bad < ndocs ? out->doc_status[ bad] : -1);
+			throw std::runtime_error( msg);
+		}
+	}) == SP_OK ? SP_OK : (c->lasterror.find( "document failed") != std::string::npos ? SP_ERR_MATCH : SP_ERR_DEVICE);
+}
+
+void sp_match_batch_free( sp_match_batch_t* b)
+{
+	std::free( b->results); std::free( b->items); std::free( b->doc_result_offsets);
+	std::free( b->doc_stats); std::free( b->doc_status);
+	std::memset( b, 0, sizeof(*b));
+}
+
+// ---- single-document mode: PatternMatcherContextInterface ----
+int sp_matcher_ctx_put_input( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, const uint32_t* origseg, size_t n)
+{
+	return guardedCall( c->lasterror, SP_ERR_INVALID, [&]{
+		// ascending-order contract checked up front like the reference does per call (src/patternMatcher.cpp:136-139)
+		uint32_t cur = c->curLexems.empty() ? 0 : c->curLexems.back().ordpos;
+		for (size_t i=0; i<n; ++i)
+		{
+			if (lexems[i].ordpos < cur) throw std::runtime_error( "term events not fed in ascending order");
+			cur = lexems[i].ordpos;
+		}
+		if (origseg && !c->curHasSeg) { c->curOrigseg.assign( c->curLexems.size(), 0); c->curHasSeg = true; }
+		c->curLexems.insert( c->curLexems.end(), lexems, lexems+n);
+		if (c->curHasSeg)
+		{
+			if (origseg) c->curOrigseg.insert( c->curOrigseg.end(), origseg, origseg+n);
+			else c->curOrigseg.insert( c->curOrigseg.end(), n, 0u);
+		}
+	});
+}
+
+int sp_matcher_ctx_fetch_results( sp_matcher_ctx_t* c, sp_result_t** results, size_t* nresults,
+				  sp_result_item_t** items, size_t* nitems)
+{
+	uint64_t offs[2] = {0, (uint64_t)c->curLexems.size()};
+	sp_match_batch_t b;
+	sp_lexem_t dummy = {0,0,0,0};
+	int rc = sp_matcher_ctx_match_docs( c, c->curLexems.empty() ? &dummy : c->curLexems.data(),
+					c->curHasSeg ? c->curOrigseg.data() : 0, offs, 1, &b);
+	if (rc != SP_OK && rc != SP_ERR_MATCH) { sp_match_batch_free( &b); return rc; }
+	if (rc == SP_ERR_MATCH)
+	{
+		static const char* msg[] = {"ok", "term events not fed in ascending order", "working set of the document exceeds the arena",
+			"pattern with too many identical key events defined", "internal: encountered past trigger with follow",
+			"term event out of range", "illegal free of event data reference"};
+		int st = b.doc_status ? b.doc_status[0] : 0;
+		c->lasterror = std::string("failed to feed input to pattern matcher: ") + ((st >= 0 && st <= 6) ? msg[ st] : "unknown");
+		sp_match_batch_free( &b);
+		return SP_ERR_MATCH;
+	}
+	c->lastStats.nofProgramsInstalled = (double)b.doc_stats[0];
+	c->lastStats.nofAltKeyProgramsInstalled = (double)b.doc_stats[1];
+	c->lastStats.nofSignalsFired = (double)b.doc_stats[2];
+	c->lastStats.nofTriggersAvgActive = c->curLexems.empty() ? 0.0 : (double)b.doc_stats[3] / (double)c->curLexems.size();
+	*results = b.results; *nresults = b.nresults; b.results = 0;
+	if (items) { *items = b.items; b.items = 0; }
+	if (nitems) *nitems = b.nitems;
+	sp_match_batch_free( &b);
+	return SP_OK;
+}
+
+int sp_matcher_ctx_statistics( sp_matcher_ctx_t* c, sp_matcher_stats_t* out)
+{
+	*out = c->lastStats;
+	return SP_OK;
+}
+
+int sp_matcher_ctx_reset( sp_matcher_ctx_t* c)
+{
+	c->curLexems.clear(); c->curOrigseg.clear(); c->curHasSeg = false;
+	std::memset( &c->lastStats, 0, sizeof(c->lastStats));
+	return SP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,835 @@
+// Level-2 rule automaton on gfx950: one wavefront per document.
+//
+// What it replaces (reference, CPU): StateMachine::doTransition / fireSignal / installProgram /
+// setCurrentPos / replayPastEvent and PatternMatcherContext::putInput / fetchResults
+// (src/ruleMatcherAutomaton.cpp:672-1334, src/patternMatcher.cpp:131-301).
+//
+// Execution model: a document is inherently sequential (every event mutates the rule state the
+// next event sees), so the unit of parallelism is the document: each 64-lane wavefront owns one
+// document at a time and pulls the next one from a global cursor when done.  Inside a document the
+// control flow is wave-uniform (all lanes follow the same path on the same values, so branches are
+// scalar and table/state reads are single-address broadcasts); the lanes are used as data-parallel
+// workers where the algorithm has width: scanning a trigger bucket for an event id (the 64-lane
+// analogue of the reference's SSE scan, src/ruleMatcherAutomaton.cpp:179-226), fetching lexems in
+// coalesced 1 KiB rows, clearing per-document tables, copying results out.
+// Integer only: no MFMA.  The compiled ProgramTable (l2_tables.h) is read-only in HBM/L2; the
+// mutable per-document state lives in a per-wave arena (layout: struct Arena below).
+//
+// Observable orders that are reproduced exactly (they decide which matches exist and in which
+// order they are reported): order of triggers inside the 16 hash buckets incl. swap-with-last
+// removal; LIFO order of the per-position dispose lists and of captured-item lists; libstdc++
+// push_heap/pop_heap order of the far-expiry queue; order of follow events.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "l2_tables.h"
+#include "l2_device.h"
+
+using namespace spa;
+
+namespace {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define LANE ((u32)(threadIdx.x & 63u))
+
+// Debug build only (make TRACE=1): progress words written to host-mapped memory by wave 0 so a
+// stuck kernel can be diagnosed from the host without waiting for it.
+#ifdef SPA_TRACE
+#define TRACE( SLOT, VALUE) do { if (P.trace && LANE == 0 && blockIdx.x == 0 && threadIdx.x < 64) { *(volatile u32*)&P.trace[ SLOT] = (u32)(VALUE); } } while (0)
+#else
+#define TRACE( SLOT, VALUE) do {} while (0)
+#endif
+#ifdef SPA_TRACE2
+#define TRACE2( SLOT, VALUE) TRACE( SLOT, VALUE)
+#else
+#define TRACE2( SLOT, VALUE) do {} while (0)
+#endif
+
+enum {F_ACTIVE=1u, F_DONE=2u};
+
+struct EvData { u32 sseg, eseg, spos, epos, sord, eord, sub, fmt; };		// src/ruleMatcherAutomaton.hpp:200-218
+
+struct Rule		// rule instance + its action slot (hpp:87-104, :171-186), 48 B
+{
+	u32 value, count, flags, start_ordpos;
+	u32 end_ordpos, start_origseg, start_origpos, program;
+	u32 trigHead, dataRef, next, expiry;
+};
+struct Trig		// installed trigger (hpp:45-74, :118-127), 32 B
+{
+	u32 event, rule, sigval, typevar;	// typevar = sigtype | variable<<4
+	u32 link, next, _a, _b;			// link = bucket<<28 | position ; next = next trigger of the same rule (1-based)
+};
+struct Item { u32 variable, next, _a, _b; EvData d; };	// captured variable (hpp:262-271), 48 B
+struct Follow { EvData d; u32 event, _a, _b, _c; };	// 48 B
+struct StopLog { EvData d; u32 timestamp, _a, _b, _c; };// 48 B
+struct StagedResult { u32 handle, sord, eord, sseg, spos, eseg, epos, dataRef; };	// 32 B
+
+struct WS		// per-wave state, lives in registers
+{
+	Rule* rules; Trig* trigs; u32* bEvent; u32* bIdx; u32* bSize; u32* window; u32* heap;
+	Follow* follow; u32* dispose; StopLog* stop; Item* items; u32* refs; u32* gstack; StagedResult* staged;
+	u32 curpos, timestamp, nInstalled, nAlt, nSignals, nTrig;
+	u64 open;
+	u32 ruleFree, ruleUsed, trigFree, trigUsed, itemFree, itemUsed, refFree, refUsed;
+	u32 heapSize, nFollow, nDispose, nStaged, err;
+};
+
+__device__ __forceinline__ u32 evhash( u32 a)		// src/ruleMatcherAutomaton.cpp:34-40
+{
+	a += ~(a>>5);
+	a +=  (a<<3);
+	a ^=  (a>>4);
+	return a;
+}
+
+__device__ __forceinline__ u32 bcast0( u32 v) { return __builtin_amdgcn_readfirstlane( v); }
+
+// Wave-uniform load: every lane reads the same address; the value is moved to a scalar register so
+// that everything computed from it (indices, loop bounds, branch conditions) stays scalar and the
+// control flow of the automaton is made of scalar branches, not exec-masked vector loops.
+__device__ __forceinline__ u32 ldu( const u32* p) { return __builtin_amdgcn_readfirstlane( *p); }
+__device__ __forceinline__ void ldEv( EvData& d, const EvData* p)
+{
+	d.sseg = ldu( &p->sseg); d.eseg = ldu( &p->eseg); d.spos = ldu( &p->spos); d.epos = ldu( &p->epos);
+	d.sord = ldu( &p->sord); d.eord = ldu( &p->eord); d.sub = ldu( &p->sub); d.fmt = ldu( &p->fmt);
+}
+
+// ---------------------------------------------------------------- allocators (order is not observable)
+__device__ __forceinline__ u32 allocRule( WS& w, const L2Params& P)
+{
+	u32 r;
+	if (w.ruleFree) { r = w.ruleFree-1; w.ruleFree = ldu( &w.rules[ r].next); }
+	else if (w.ruleUsed < P.arena.maxRules) { r = w.ruleUsed++; }
+	else { w.err = SPD_ERR_ARENA; r = 0; }
+	return r;
+}
+__device__ __forceinline__ void freeRule( WS& w, u32 r)
+{
+	w.rules[ r].next = w.ruleFree; w.ruleFree = r+1;
+}
+__device__ __forceinline__ u32 allocTrig( WS& w, const L2Params& P)
+{
+	u32 t;
+	if (w.trigFree) { t = w.trigFree-1; w.trigFree = ldu( &w.trigs[ t].next); }
+	else if (w.trigUsed < P.arena.maxTrigs) { t = w.trigUsed++; }
+	else { w.err = SPD_ERR_ARENA; t = 0; }
+	return t;
+}
+__device__ __forceinline__ u32 allocItem( WS& w, const L2Params& P)
+{
+	u32 t;
+	if (w.itemFree) { t = w.itemFree-1; w.itemFree = ldu( &w.items[ t].next); }
+	else if (w.itemUsed < P.arena.maxItems) { t = w.itemUsed++; }
+	else { w.err = SPD_ERR_ARENA; t = 0; }
+	return t;
+}
+// data references: refs[2i] = head of the item list (1-based), refs[2i+1] = reference count
+__device__ __forceinline__ u32 createRef( WS& w, const L2Params& P)	// cpp:750-753
+{
+	u32 t;
+	if (w.refFree) { t = w.refFree-1; w.refFree = ldu( &w.refs[ 2*t]); }
+	else if (w.refUsed < P.arena.maxRefs) { t = w.refUsed++; }
+	else { w.err = SPD_ERR_ARENA; return 0; }
+	w.refs[ 2*t] = 0; w.refs[ 2*t+1] = 1;
+	return t+1;
+}
+__device__ __forceinline__ void addRef( WS& w, u32 ref) { w.refs[ 2*(ref-1)+1] = ldu( &w.refs[ 2*(ref-1)+1]) + 1; }	// cpp:734-738
+
+__device__ void disposeRef( WS& w, u32 ref)				// cpp:710-732
+{
+	u32 cnt = ldu( &w.refs[ 2*(ref-1)+1]);
+	if (cnt > 1) { w.refs[ 2*(ref-1)+1] = cnt-1; }
+	else if (cnt == 1)
+	{
+		u32 it = ldu( &w.refs[ 2*(ref-1)]);
+		for (u32 guard=0; it; ++guard)
+		{
+			if (guard > w.itemUsed) { w.err = SPD_ERR_INTERNAL; break; }
+			u32 nx = ldu( &w.items[ it-1].next);
+			w.items[ it-1].next = w.itemFree; w.itemFree = it;
+			it = nx;
+		}
+		w.refs[ 2*(ref-1)+1] = 0;
+		w.refs[ 2*(ref-1)] = w.refFree; w.refFree = ref;
+	}
+	else { w.err = SPD_ERR_DATAREF; }
+}
+
+__device__ void appendItem( WS& w, const L2Params& P, u32 ref, u32 variable, const EvData& d)	// cpp:740-748
+{
+	if (d.sub) addRef( w, d.sub);
+	u32 it = allocItem( w, P);
+	if (w.err) return;
+	Item* I = &w.items[ it];
+	I->variable = variable; I->d = d;
+	I->next = ldu( &w.refs[ 2*(ref-1)]);
+	w.refs[ 2*(ref-1)] = it+1;
+}
+
+__device__ void joinItems( WS& w, const L2Params& P, u32 dest, u32 src)	// cpp:755-770
+{
+	u32 it = ldu( &w.refs[ 2*(src-1)]);
+	for (u32 guard=0; it && !w.err; ++guard)
+	{
+		if (guard > P.arena.maxItems) { w.err = SPD_ERR_INTERNAL; break; }
+		Item* S = &w.items[ it-1];
+		u32 variable = ldu( &S->variable); EvData d; ldEv( d, &S->d); it = ldu( &S->next);
+		appendItem( w, P, dest, variable, d);
+	}
+}
+
+// ---------------------------------------------------------------- event trigger table (cpp:114-257)
+__device__ __forceinline__ void addTrigger( WS& w, const L2Params& P, u32 t, u32 event)
+{
+	u32 h = evhash( event) & 15u;
+	u32 pos = ldu( &w.bSize[ h]);
+	if (pos >= P.arena.bucketCap) { w.err = SPD_ERR_ARENA; return; }
+	w.bEvent[ h*P.arena.bucketCap + pos] = event;
+	w.bIdx[ h*P.arena.bucketCap + pos] = t;
+	w.bSize[ h] = pos+1;
+	w.trigs[ t].link = (h << 28) | pos;
+	w.nTrig += 1;
+}
+__device__ __forceinline__ void removeTrigger( WS& w, const L2Params& P, u32 t)	// swap with last, cpp:133-152
+{
+	u32 link = ldu( &w.trigs[ t].link);
+	u32 h = link >> 28, pos = link & 0x0FFFFFFFu;
+	u32 last = ldu( &w.bSize[ h])-1;
+	if (pos != last)
+	{
+		u32 me = ldu( &w.bEvent[ h*P.arena.bucketCap + last]);
+		u32 mi = ldu( &w.bIdx[ h*P.arena.bucketCap + last]);
+		w.bEvent[ h*P.arena.bucketCap + pos] = me;
+		w.bIdx[ h*P.arena.bucketCap + pos] = mi;
+		w.trigs[ mi].link = link;
+	}
+	w.bSize[ h] = last;
+	w.nTrig -= 1;
+}
+
+__device__ void deactivateRule( WS& w, const L2Params& P, u32 r)	// cpp:679-702
+{
+	Rule* R = &w.rules[ r];
+	u32 flags = ldu( &R->flags);
+	if (flags & F_ACTIVE)
+	{
+		R->flags = flags & ~F_ACTIVE;
+		u32 t = ldu( &R->trigHead);
+		for (u32 guard=0; t; ++guard)
+		{
+			if (guard > w.trigUsed) { w.err = SPD_ERR_INTERNAL; break; }
+			u32 nx = ldu( &w.trigs[ t-1].next);
+			removeTrigger( w, P, t-1);
+			w.trigs[ t-1].next = w.trigFree; w.trigFree = t;
+			t = nx;
+		}
+		R->trigHead = 0;
+		u32 ref = ldu( &R->dataRef);
+		if (ref) { disposeRef( w, ref); R->dataRef = 0; }
+	}
+}
+
+// ---------------------------------------------------------------- expiry (cpp:1066-1135)
+// far-expiry queue: binary heap on `pos` (min-heap via the inverted comparison of hpp:425-428),
+// sifted exactly like libstdc++'s __push_heap/__adjust_heap so ties come out in the same order.
+__device__ void heapPush( WS& w, const L2Params& P, u32 pos, u32 idx)
+{
+	if (w.heapSize >= P.arena.maxHeap) { w.err = SPD_ERR_ARENA; return; }
+	u32 hole = w.heapSize++;
+	while (hole > 0)
+	{
+		u32 parent = (hole-1) >> 1;
+		u32 ppos = ldu( &w.heap[ 2*parent]);
+		if (!(ppos > pos)) break;			// comp(parent, value) == parent.pos > value.pos
+		w.heap[ 2*hole] = ppos; w.heap[ 2*hole+1] = ldu( &w.heap[ 2*parent+1]);
+		hole = parent;
+	}
+	w.heap[ 2*hole] = pos; w.heap[ 2*hole+1] = idx;
+}
+__device__ void heapPop( WS& w)
+{
+	u32 n = w.heapSize;
+	if (n > 1)
+	{
+		u32 len = n-1;
+		u32 vpos = ldu( &w.heap[ 2*len]), vidx = ldu( &w.heap[ 2*len+1]);
+		u32 hole = 0, child = 0;
+		while (child < (len-1)/2)
+		{
+			child = 2*(child+1);
+			if (ldu( &w.heap[ 2*child]) > ldu( &w.heap[ 2*(child-1)])) child--;	// comp(first[child], first[child-1])
+			w.heap[ 2*hole] = ldu( &w.heap[ 2*child]); w.heap[ 2*hole+1] = ldu( &w.heap[ 2*child+1]);
+			hole = child;
+		}
+		if ((len & 1) == 0 && child == (len-2)/2)
+		{
+			child = 2*(child+1);
+			w.heap[ 2*hole] = ldu( &w.heap[ 2*(child-1)]); w.heap[ 2*hole+1] = ldu( &w.heap[ 2*(child-1)+1]);
+			hole = child-1;
+		}
+		while (hole > 0)
+		{
+			u32 parent = (hole-1) >> 1;
+			u32 ppos = ldu( &w.heap[ 2*parent]);
+			if (!(ppos > vpos)) break;
+			w.heap[ 2*hole] = ppos; w.heap[ 2*hole+1] = ldu( &w.heap[ 2*parent+1]);
+			hole = parent;
+		}
+		w.heap[ 2*hole] = vpos; w.heap[ 2*hole+1] = vidx;
+	}
+	w.heapSize = n-1;
+}
+
+__device__ __forceinline__ void defineDisposeRule( WS& w, const L2Params& P, u32 pos, u32 r)	// cpp:1066-1082
+{
+	// pos >= curpos always holds here: installProgram has rejected expired programs
+	if (pos < w.curpos + 64u)
+	{
+		u32 widx = pos & 63u;
+		w.rules[ r].next = ldu( &w.window[ widx]);
+		w.window[ widx] = r+1;
+	}
+	else heapPush( w, P, pos, r);
+}
+
+__device__ __forceinline__ void disposeRule( WS& w, const L2Params& P, u32 r)	// cpp:704-708
+{
+	deactivateRule( w, P, r);
+	freeRule( w, r);
+}
+
+__device__ void setCurrentPos( WS& w, const L2Params& P, u32 pos)	// cpp:1084-1135
+{
+	if (w.curpos == pos) return;
+	u32 wcnt = 0;
+	for (; wcnt < 64u && w.curpos < pos; ++wcnt, ++w.curpos)
+	{
+		u32 widx = w.curpos & 63u;
+		if (widx == 0)
+		{
+			while (w.heapSize && ldu( &w.heap[0]) < w.curpos + 64u)
+			{
+				wcnt = 0;
+				u32 hp = ldu( &w.heap[0]), hr = ldu( &w.heap[1]);
+				w.rules[ hr].next = ldu( &w.window[ hp & 63u]);
+				w.window[ hp & 63u] = hr+1;
+				heapPop( w);
+			}
+		}
+		u32 lst = ldu( &w.window[ widx]);
+		if (lst)
+		{
+			for (u32 guard=0; lst; ++guard)
+			{
+				if (guard > w.ruleUsed) { w.err = SPD_ERR_INTERNAL; break; }
+				u32 r = lst-1;
+				lst = ldu( &w.rules[ r].next);
+				disposeRule( w, P, r);
+			}
+			w.window[ widx] = 0;
+		}
+	}
+	if (w.curpos < pos)
+	{
+		w.curpos = pos;
+		while (w.heapSize && ldu( &w.heap[0]) < w.curpos)
+		{
+			u32 hr = ldu( &w.heap[1]);
+			heapPop( w);
+			disposeRule( w, P, hr);
+		}
+	}
+}
+
+// ---------------------------------------------------------------- fireSignal (cpp:772-979)
+__device__ void fireSignal( WS& w, const L2Params& P, u32 r, u32 sigtype, u32 sigval, u32 variable, const EvData& d)
+{
+	Rule* R = &w.rules[ r];
+	u32 value = ldu( &R->value), count = ldu( &R->count), flags = ldu( &R->flags), end_ordpos = ldu( &R->end_ordpos);
+	bool match = false, take = false, fin = false;
+	w.nSignals += 1;
+
+	switch (sigtype)
+	{
+		case SIG_ANY:
+			take = true;
+			if (count > 0)
+			{
+				match = true; --count; fin = (count == 0);
+				if (end_ordpos < d.eord) end_ordpos = d.eord;
+			}
+			break;
+		case SIG_AND:
+			if (count > 0)
+			{
+				if (!value)
+				{
+					value = d.sord;
+					if (end_ordpos > d.eord) end_ordpos = d.eord;
+				}
+				if (value == d.sord) { match = true; --count; fin = (count == 0); take = true; }
+			}
+			break;
+		case SIG_SEQUENCE:
+		case SIG_SEQUENCE_IMM:
+		{
+			bool posok = (sigtype == SIG_SEQUENCE) ? (end_ordpos <= d.sord) : (end_ordpos == d.sord);
+			if (sigval == value && posok)
+			{
+				end_ordpos = d.eord; value = sigval-1;
+				if (count > 0) { --count; match = (count == 0); } else match = true;
+				fin = (value == 0); take = true;
+			}
+			break;
+		}
+		case SIG_WITHIN:
+			if ((sigval & value) != 0 && end_ordpos <= d.sord)
+			{
+				end_ordpos = d.eord; value &= ~sigval;
+				if (count > 0) { --count; match = (count == 0); } else match = true;
+				fin = (value == 0); take = true;
+			}
+			break;
+		default: // SIG_DEL
+			R->count = 0; R->value = 0;
+			if (w.nDispose < P.arena.maxDispose) w.dispose[ w.nDispose++] = r; else w.err = SPD_ERR_ARENA;
+			return;
+	}
+	R->value = value; R->count = count; R->end_ordpos = end_ordpos;
+	u32 start_ordpos = ldu( &R->start_ordpos), start_origseg = ldu( &R->start_origseg), start_origpos = ldu( &R->start_origpos);
+	u32 dataRef = ldu( &R->dataRef);
+	if (take)
+	{
+		if (P.withItems)
+		{
+			if (variable)
+			{
+				if (!dataRef) { dataRef = createRef( w, P); R->dataRef = dataRef; }
+				if (!w.err) appendItem( w, P, dataRef, variable, d);
+			}
+			else if (d.sub)
+			{
+				if (!dataRef) { dataRef = createRef( w, P); R->dataRef = dataRef; }
+				if (!w.err) joinItems( w, P, dataRef, d.sub);
+			}
+		}
+		if (start_ordpos == 0)
+		{
+			start_ordpos = d.sord; start_origseg = d.sseg; start_origpos = d.spos;
+		}
+		else if (start_ordpos > d.sord)
+		{
+			start_ordpos = d.sord;
+			if (start_origseg > d.sseg || (start_origseg == d.sseg && start_origpos > d.spos))
+			{
+				start_origseg = d.sseg; start_origpos = d.spos;
+			}
+		}
+		R->start_ordpos = start_ordpos; R->start_origseg = start_origseg; R->start_origpos = start_origpos;
+	}
+	if (match)
+	{
+		if (!(flags & F_DONE))
+		{
+			const DevProgram* G = &P.programs[ ldu( &R->program)];
+			u32 fevent = ldu( &G->event), handle = ldu( &G->resultHandle), fmt = ldu( &G->formatHandle);
+			if (fevent)
+			{
+				if (w.nFollow < P.arena.maxFollow)
+				{
+					Follow* F = &w.follow[ w.nFollow++];
+					F->d.sseg = start_origseg; F->d.spos = start_origpos; F->d.eseg = d.eseg; F->d.epos = d.epos;
+					F->d.sord = start_ordpos; F->d.eord = end_ordpos; F->d.sub = dataRef; F->d.fmt = fmt;
+					F->event = fevent;
+					if (dataRef) addRef( w, dataRef);
+				}
+				else w.err = SPD_ERR_ARENA;
+			}
+			if (handle)
+			{
+				if (w.nStaged < P.arena.maxStaged)
+				{
+					StagedResult* S = &w.staged[ w.nStaged++];
+					S->handle = handle; S->sord = start_ordpos; S->eord = end_ordpos;
+					S->sseg = start_origseg; S->spos = start_origpos; S->eseg = d.eseg; S->epos = d.epos;
+					S->dataRef = dataRef;
+					if (dataRef) addRef( w, dataRef);
+				}
+				else w.err = SPD_ERR_ARENA;
+			}
+			R->flags = flags | F_DONE;
+		}
+		if (fin)
+		{
+			if (w.nDispose < P.arena.maxDispose) w.dispose[ w.nDispose++] = r; else w.err = SPD_ERR_ARENA;
+		}
+	}
+}
+
+__device__ __forceinline__ const DevKeyEntry* lookupKey( const L2Params& P, u32 event)
+{
+	if (!event) return 0;
+	u32 slot = keyHash( event) & P.keymask;
+	for (u32 probes=0; probes<=P.keymask; ++probes)
+	{
+		const DevKeyEntry* e = &P.keytab[ slot];
+		u32 ev = ldu( &e->event);
+		if (ev == event) return e;
+		if (ev == 0) return 0;
+		slot = (slot+1) & P.keymask;
+	}
+	return 0;
+}
+
+// ---------------------------------------------------------------- replayPastEvent (cpp:1272-1334)
+__device__ void replayPastEvent( WS& w, const L2Params& P, u32 pastEvent, u32 pastStopIdx, u32 r, u32 range)
+{
+	if (!pastStopIdx) return;
+	const StopLog* L = &w.stop[ pastStopIdx-1];
+	u32 pastStamp = ldu( &L->timestamp);
+	if (!pastStamp) return;
+	EvData ld; ldEv( ld, &L->d);
+	if (ld.sord + range < w.curpos) return;
+
+	u32 nFollow0 = w.nFollow, nDispose0 = w.nDispose;
+	u32 t = ldu( &w.rules[ r].trigHead);
+	for (u32 guard=0; t && !w.err; ++guard)
+	{
+		if (guard > w.trigUsed) { w.err = SPD_ERR_INTERNAL; break; }
+		Trig* T = &w.trigs[ t-1];
+		u32 tev = ldu( &T->event), typevar = ldu( &T->typevar), sigval = ldu( &T->sigval);
+		t = ldu( &T->next);
+		if (tev == pastEvent) fireSignal( w, P, r, typevar & 15u, sigval, typevar >> 4, ld);
+	}
+	// a structure delimiter logged after the replayed event cancels the rule (cpp:1306-1321)
+	t = ldu( &w.rules[ r].trigHead);
+	for (u32 guard=0; t; ++guard)
+	{
+		if (guard > w.trigUsed) { w.err = SPD_ERR_INTERNAL; break; }
+		Trig* T = &w.trigs[ t-1];
+		u32 tev = ldu( &T->event), typevar = ldu( &T->typevar);
+		t = ldu( &T->next);
+		if ((typevar & 15u) == SIG_DEL)
+		{
+			const DevKeyEntry* e = lookupKey( P, tev);
+			u32 esi = e ? ldu( &e->stopIdx) : 0;
+			if (esi)
+			{
+				u32 ts = ldu( &w.stop[ esi-1].timestamp);
+				if (ts && ts > pastStamp) { deactivateRule( w, P, r); break; }
+			}
+		}
+	}
+	for (u32 di=nDispose0; di<w.nDispose; ++di) deactivateRule( w, P, ldu( &w.dispose[ di]));
+	w.nDispose = nDispose0;
+	if (w.nFollow != nFollow0) { w.nFollow = nFollow0; w.err = SPD_ERR_PASTFOLLOW; }
+}
+
+// ---------------------------------------------------------------- installProgram (cpp:1168-1270)
+__device__ void installProgram( WS& w, const L2Params& P, u32 keyevent, const DevKeyRef* K, const EvData& d)
+{
+	u32 program = ldu( &K->program);
+	const DevProgram* G = &P.programs[ program];
+	u32 range = ldu( &G->positionRange);
+	if (d.sord + range < w.curpos) return;
+
+	u32 r = allocRule( w, P);
+	if (w.err) return;
+	Rule* R = &w.rules[ r];
+	u32 count = ldu( &G->initcount) & 0xFFFFu;		// ActionSlot::count is 16 bit (hpp:98)
+	R->value = ldu( &G->initsigval); R->count = count; R->flags = F_ACTIVE; R->start_ordpos = 0;
+	R->end_ordpos = 0; R->start_origseg = 0; R->start_origpos = 0; R->program = program;
+	R->trigHead = 0; R->dataRef = 0; R->expiry = d.sord + range;
+	defineDisposeRule( w, P, d.sord + range, r);
+	if (w.err) return;
+
+	u32 tb = ldu( &G->trigBegin), tc = ldu( &G->trigCount);
+	u64 keymaskbits = 0;
+	u32 nofKey = 0;
+	bool hasKey = false;
+	u32 head = 0;
+	for (u32 j=0; j<tc; ++j)
+	{
+		const DevTrigDef* D = &P.trigdefs[ tb+j];
+		u32 tev = ldu( &D->event), tflags = ldu( &D->flags);
+		u32 sigtype = tflags & 15u;
+		bool doInstall;
+		if (tev == keyevent)
+		{
+			if (nofKey >= 32u || j >= 64u) { w.err = SPD_ERR_KEYTRIGGERS; return; }
+			keymaskbits |= (1ull << j); ++nofKey;
+			bool needs = (sigtype == SIG_ANY && count > 1);		// cpp:1159-1166
+			if ((tflags & 0x100u) && !hasKey) { hasKey = true; doInstall = needs; }
+			else if (sigtype == SIG_DEL) doInstall = needs;
+			else doInstall = true;
+		}
+		else doInstall = true;
+		if (doInstall)
+		{
+			u32 t = allocTrig( w, P);
+			if (w.err) return;
+			Trig* T = &w.trigs[ t];
+			T->event = tev; T->rule = r; T->sigval = ldu( &D->sigval); T->typevar = sigtype | (ldu( &D->variable) << 4);
+			T->next = head; head = t+1;
+			addTrigger( w, P, t, tev);
+			if (w.err) return;
+		}
+	}
+	R->trigHead = head;
+	w.nInstalled += 1;
+
+	u32 pastEvent = ldu( &K->pastEvent);
+	if (pastEvent)
+	{
+		w.nAlt += 1;
+		replayPastEvent( w, P, pastEvent, ldu( &K->pastStopIdx), r, range);
+	}
+	if (nofKey && (ldu( &R->flags) & F_ACTIVE))
+	{
+		while (keymaskbits && !w.err)
+		{
+			u32 j = (u32)__builtin_ctzll( keymaskbits);
+			keymaskbits &= keymaskbits-1;
+			const DevTrigDef* D = &P.trigdefs[ tb+j];
+			fireSignal( w, P, r, ldu( &D->flags) & 15u, ldu( &D->sigval), ldu( &D->variable), d);
+		}
+	}
+}
+
+// ---------------------------------------------------------------- doTransition (cpp:981-1064)
+__device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData& data)
+{
+	w.open += w.nTrig;
+	w.nFollow = 1;
+	w.follow[0].d = data; w.follow[0].event = event;
+
+	for (u32 fi=0; fi<w.nFollow && !w.err; ++fi)
+	{
+		EvData d; ldEv( d, &w.follow[ fi].d);
+		u32 ev = ldu( &w.follow[ fi].event);
+		w.nDispose = 0;
+		TRACE2( 6, fi); TRACE2( 7, ev);
+
+		// fire the triggers waiting for this event: 64 bucket entries per step, one ballot
+		if (ev)
+		{
+			u32 h = evhash( ev) & 15u;
+			u32 n = ldu( &w.bSize[ h]);
+			const u32* be = w.bEvent + h*P.arena.bucketCap;
+			const u32* bi = w.bIdx + h*P.arena.bucketCap;
+			for (u32 base=0; base<n && !w.err; base+=64)
+			{
+				u32 i = base + LANE;
+				u64 m = __ballot( i < n && be[ i] == ev);
+				while (m && !w.err)
+				{
+					u32 p = (u32)__builtin_ctzll( m);
+					m &= m-1;
+					const Trig* T = &w.trigs[ ldu( &bi[ base+p])];
+					u32 tr = ldu( &T->rule), typevar = ldu( &T->typevar), sigval = ldu( &T->sigval);
+					fireSignal( w, P, tr, typevar & 15u, sigval, typevar >> 4, d);
+				}
+			}
+		}
+		// install the programs keyed by this event
+		TRACE2( 9, 1);
+		const DevKeyEntry* e = lookupKey( P, ev);
+		TRACE2( 9, 2);
+		u32 stopIdx = 0;
+		if (e)
+		{
+			stopIdx = ldu( &e->stopIdx);
+			u32 lb = ldu( &e->listBegin), lc = ldu( &e->listCount);
+			TRACE2( 10, lc);
+			for (u32 k=0; k<lc && !w.err; ++k) { TRACE2( 11, k); installProgram( w, P, ev, &P.keylist[ lb+k], d); }
+		}
+		TRACE2( 9, 3);
+		// deactivate rules that finished or were deleted
+		for (u32 di=0; di<w.nDispose; ++di) deactivateRule( w, P, ldu( &w.dispose[ di]));
+
+		if (stopIdx)
+		{
+			StopLog* L = &w.stop[ stopIdx-1];
+			L->d = d; L->timestamp = ++w.timestamp;
+		}
+		else if (d.sub && P.withItems)
+		{
+			disposeRef( w, d.sub);
+		}
+	}
+}
+
+// ---------------------------------------------------------------- result items (patternMatcher.cpp:164-190)
+// depth-first walk of an item list; items with sub-lists (and no format) are followed by their
+// sub-items.  emit==0 counts only.
+__device__ u32 walkItems( WS& w, const L2Params& P, u32 ref, u32* out)
+{
+	u32 n = 0, sp = 0;
+	u32 cur = ldu( &w.refs[ 2*(ref-1)]);
+	for (u32 guard=0;; ++guard)
+	{
+		if (guard > (1u<<22)) { w.err = SPD_ERR_INTERNAL; break; }
+		if (!cur)
+		{
+			if (!sp) break;
+			cur = ldu( &w.gstack[ --sp]);
+			continue;
+		}
+		const Item* I = &w.items[ cur-1];
+		EvData d; ldEv( d, &I->d);
+		if (out)
+		{
+			u32* o = out + (u64)n*7;
+			o[0] = ldu( &I->variable); o[1] = d.sord; o[2] = d.eord; o[3] = d.sseg; o[4] = d.spos; o[5] = d.eseg; o[6] = d.epos;
+		}
+		++n;
+		cur = ldu( &I->next);
+		if (d.sub && !d.fmt)
+		{
+			if (sp >= P.arena.maxGStack) { w.err = SPD_ERR_ARENA; break; }
+			w.gstack[ sp++] = cur;
+			cur = ldu( &w.refs[ 2*(d.sub-1)]);
+		}
+	}
+	return n;
+}
+
+} // anonymous namespace
+
+// ================================================================== kernel
+extern "C" __global__ __launch_bounds__(256)
+void spa_l2_match_kernel( L2Params P)
+{
+	const u32 waveSlot = bcast0( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+	u32* A = P.arenaBase + (u64)waveSlot * P.arena.totalWords;
+
+	WS w;
+	w.rules = (Rule*)(A + P.arena.oRules);	w.trigs = (Trig*)(A + P.arena.oTrigs);
+	w.bEvent = A + P.arena.oBEvent;		w.bIdx = A + P.arena.oBIdx;
+	w.bSize = A + P.arena.oBSize;		w.window = A + P.arena.oWindow;
+	w.heap = A + P.arena.oHeap;		w.follow = (Follow*)(A + P.arena.oFollow);
+	w.dispose = A + P.arena.oDispose;	w.stop = (StopLog*)(A + P.arena.oStop);
+	w.items = (Item*)(A + P.arena.oItems);	w.refs = A + P.arena.oRefs;
+	w.gstack = A + P.arena.oGStack;		w.staged = (StagedResult*)(A + P.arena.oStaged);
+
+	// documents are dealt round-robin to the resident waves (document d -> wave d mod nwaves)
+	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
+	for (u32 doc=waveSlot; doc<P.ndocs; doc+=nWaveSlots)
+	{
+		TRACE( 1, doc);
+		// per-document reset (lane-parallel)
+		if (LANE < 16) w.bSize[ LANE] = 0;
+		w.window[ LANE] = 0;
+		for (u32 s=LANE; s<P.nofStopWords; s+=64) w.stop[ s].timestamp = 0;
+		w.curpos = 0; w.timestamp = 0; w.nInstalled = 0; w.nAlt = 0; w.nSignals = 0; w.nTrig = 0; w.open = 0;
+		w.ruleFree = 0; w.ruleUsed = 0; w.trigFree = 0; w.trigUsed = 0; w.itemFree = 0; w.itemUsed = 0;
+		w.refFree = 0; w.refUsed = 0; w.heapSize = 0; w.nFollow = 0; w.nDispose = 0; w.nStaged = 0; w.err = 0;
+
+		const u64 lbeg = ((u64)ldu( (const u32*)&P.docOffsets[ doc]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc]);
+		const u64 lend = ((u64)ldu( (const u32*)&P.docOffsets[ doc+1]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc+1]);
+		u32 curPosition = 0, nEvents = 0;
+		for (u64 lbase=lbeg; lbase<lend && !w.err; lbase+=64)
+		{
+			// coalesced fetch of up to 64 lexems (16 B each), then replayed one by one
+			uint4 lx = make_uint4( 0,0,0,0); u32 seg = 0;
+			if (lbase + LANE < lend)
+			{
+				lx = ((const uint4*)P.lexems)[ lbase + LANE];
+				if (P.origseg) seg = P.origseg[ lbase + LANE];
+			}
+			u32 cnt = (lend - lbase) < 64 ? (u32)(lend - lbase) : 64u;
+			for (u32 k=0; k<cnt && !w.err; ++k)
+			{
+				u32 id = __builtin_amdgcn_readlane( lx.x, k), ordpos = __builtin_amdgcn_readlane( lx.y, k);
+				u32 origpos = __builtin_amdgcn_readlane( lx.z, k), origsize = __builtin_amdgcn_readlane( lx.w, k);
+				u32 origseg = __builtin_amdgcn_readlane( seg, k);
+				// PatternMatcherContext::putInput (patternMatcher.cpp:131-162)
+				if (curPosition > ordpos) { w.err = SPD_ERR_ORDER; break; }
+				else if (curPosition < ordpos) { curPosition = ordpos; setCurrentPos( w, P, ordpos); }
+				else if (origsize >= 0x7FFFFFFFu || origseg >= 0x7FFFFFFFu || origpos >= 0x7FFFFFFFu) { w.err = SPD_ERR_RANGE; break; }
+				if (id >= (1u<<29)) { w.err = SPD_ERR_RANGE; break; }
+				EvData d;
+				d.sseg = origseg; d.eseg = origseg; d.spos = origpos; d.epos = origpos + origsize;
+				d.sord = ordpos; d.eord = ordpos+1; d.sub = 0; d.fmt = 0;
+				TRACE2( 2, nEvents); TRACE2( 3, id); TRACE2( 4, ordpos);
+				doTransition( w, P, id /*TermEvent: type bits 0*/, d);
+				TRACE2( 5, nEvents);
+				++nEvents;
+			}
+		}
+
+		// fetchResults: items first (one reservation per document), then the results themselves
+		TRACE2( 12, w.nStaged); TRACE2( 13, w.err);
+		u32 nres = w.err ? 0 : w.nStaged;
+		u64 itemBase = 0;
+		if (P.withItems && nres)
+		{
+			u32 total = 0;
+			for (u32 ri=0; ri<nres && !w.err; ++ri)
+			{
+				u32 ref = ldu( &w.staged[ ri].dataRef);
+				if (ref) total += walkItems( w, P, ref, 0);
+			}
+			if (w.err) nres = 0;
+			else if (total)
+			{
+				u64 b = 0;
+				if (LANE == 0) b = atomicAdd( (unsigned long long*)&P.counters[ SPC_ITEMS], (unsigned long long)total);
+				itemBase = ((u64)bcast0( (u32)(b >> 32)) << 32) | bcast0( (u32)b);
+				if (itemBase + total > P.itemCapacity) { w.err = SPD_ERR_OUTPUT; nres = 0; }
+			}
+		}
+		u64 resBase = 0;
+		if (nres)
+		{
+			u64 b = 0;
+			if (LANE == 0) b = atomicAdd( (unsigned long long*)&P.counters[ SPC_RESULTS], (unsigned long long)nres);
+			resBase = ((u64)bcast0( (u32)(b >> 32)) << 32) | bcast0( (u32)b);
+			if (resBase + nres > P.resultCapacity) { w.err = SPD_ERR_OUTPUT; nres = 0; }
+		}
+		if (nres)
+		{
+			u64 ip = itemBase;
+			if (P.withItems)
+			{
+				// item lists are pointer chains: walked serially, result records patched with (begin,count)
+				for (u32 ri=0; ri<nres; ++ri)
+				{
+					u32 ref = ldu( &w.staged[ ri].dataRef);
+					u32 n = ref ? walkItems( w, P, ref, P.items + ip*7) : 0;
+					u32* o = P.results + (resBase + ri)*9;
+					o[7] = (u32)ip; o[8] = n;
+					ip += n;
+				}
+			}
+			// the 7-tuples: one result per lane, 36-byte records
+			for (u32 ri=LANE; ri<nres; ri+=64)
+			{
+				const StagedResult* S = &w.staged[ ri];
+				u32* o = P.results + (resBase + ri)*9;
+				o[0] = S->handle; o[1] = S->sord; o[2] = S->eord; o[3] = S->sseg; o[4] = S->spos; o[5] = S->eseg; o[6] = S->epos;
+				if (!P.withItems) { o[7] = 0; o[8] = 0; }
+			}
+		}
+		if (LANE == 0)
+		{
+			P.docRange[ 2*(u64)doc] = resBase; P.docRange[ 2*(u64)doc+1] = nres;
+			u64* st = P.docStats + 4*(u64)doc;
+			st[0] = w.nInstalled; st[1] = w.nAlt; st[2] = w.nSignals; st[3] = w.open;
+			P.docStatus[ doc] = (int32_t)w.err;
+			atomicAdd( (unsigned long long*)&P.counters[ SPC_EVENTS], (unsigned long long)nEvents);
+			if (w.err) atomicAdd( (unsigned long long*)&P.counters[ SPC_FAILED], 1ull);
+		}
+	}
+}
+
+// host-side launcher (called from capi.cpp, same translation unit family compiled by hipcc)
+namespace spa {
+hipError_t launchL2Match( const L2Params& P, unsigned nblocks, hipStream_t stream)
+{
+	hipLaunchKernelGGL( spa_l2_match_kernel, dim3( nblocks), dim3( 256), 0, stream, P);
+	return hipGetLastError();
+}
+}

@@ -1,0 +1,146 @@
+"""GPU parity tests of the level-2 rule automaton: HIP kernel (through the C-ABI) vs the CPU oracle
+on the same inputs.  Bit-exact: per document the result 7-tuples in firing order, the captured
+items in list order, and the automaton statistics."""
+import numpy as np
+import pytest
+
+import oracle
+import struspattern_amd as spa
+from struspattern_amd import synth
+from tests import l2_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(gpu, ref, ndocs, with_items=True):
+    assert np.array_equal(gpu.status, np.zeros(ndocs, np.int32))
+    assert np.array_equal(gpu.doc_offsets, ref.doc_offsets)
+    assert np.array_equal(gpu.results[:, :7], ref.results[:, :7])
+    assert np.array_equal(gpu.stats, ref.stats)
+    if with_items:
+        assert np.array_equal(gpu.results[:, 8], ref.results[:, 8])
+        assert np.array_equal(gpu.items, ref.items)
+
+
+def _run_both(build, lex4, offs, origseg=None):
+    m = spa.PatternMatcherInstance()
+    o = oracle.L2Matcher()
+    build(m)
+    build(o)
+    ctx = m.createContext()
+    gpu = ctx.matchDocs(lex4, offs, origseg)
+    l5 = synth.lexems5(lex4)
+    if origseg is not None:
+        l5[:, 2] = origseg
+    ref = o.run(l5, offs)
+    return gpu, ref, m, o
+
+
+def test_simple_token_pattern_match_golden():
+    case = l2_cases.load("simple_token_pattern_match.json")
+    lex5 = l2_cases.simple_doc(case)
+    lex4 = lex5[:, [0, 1, 3, 4]]
+    gpu, ref, m, o = _run_both(lambda x: l2_cases.build_simple(x, case), lex4, [0, len(lex4)])
+    got = sorted({(m.patternName(int(r[0])), int(r[1])) for r in gpu.results})
+    exp = sorted((r["name"], p) for r in case["rules"] for p in r["expected_ordpos"])
+    assert got == exp
+    _compare(gpu, ref, 1)
+
+
+def test_nested_within_sequence_golden():
+    case = l2_cases.load("nested_within_sequence.json")
+    lex5 = l2_cases.nested_doc(case)
+    lex4 = lex5[:, [0, 1, 3, 4]]
+    gpu, ref, m, o = _run_both(lambda x: l2_cases.build_nested(x, case), lex4, [0, len(lex4)])
+    assert len(gpu.results) == len(case["results"])
+    for r, e in zip(gpu.results, case["results"]):
+        assert (int(r[1]), int(r[2]), int(r[4]), int(r[6])) == (e["ordpos"], e["ordend"], e["origpos"], e["origend"])
+        items = gpu.items[r[7]:r[7] + r[8]]
+        assert [[m.variableName(int(i[0])), int(i[1]), int(i[2])] for i in items] == e["items"]
+    assert gpu.stats[0, 0] == case["programs_installed"] and gpu.stats[0, 2] == case["signals_fired"]
+    _compare(gpu, ref, 1)
+
+
+@pytest.mark.parametrize("nrules,nfeat,ndocs,docsize,seed,op,optimize", [
+    (2000, 200, 300, 300, 21, None, True),
+    (2000, 200, 300, 300, 22, None, False),
+    (5000, 1000, 200, 1000, 23, "sequence", True),
+    (1000, 50, 100, 500, 24, "within", True),
+    (1000, 50, 100, 500, 25, "sequence_struct", True),
+    (1000, 50, 100, 500, 26, "within_struct", True),
+    (500, 30, 100, 300, 27, "any", True),
+])
+def test_random_token_pattern_match(nrules, nfeat, ndocs, docsize, seed, op, optimize):
+    rules = synth.random_rules(nrules, nfeat, seed, op)
+    lex, offs = synth.random_documents(ndocs, docsize, nfeat, seed + 1000)
+    gpu, ref, m, o = _run_both(lambda x: synth.apply_rules(x, rules, compile=optimize), lex, offs)
+    assert len(ref.results) > 0
+    _compare(gpu, ref, ndocs)
+
+
+def test_edge_cases_empty_and_ragged_documents():
+    rules = synth.random_rules(300, 20, 31)
+    lex, offs = synth.random_documents(50, 40, 20, 32)
+    # make ragged: empty documents at the start, in the middle and at the end, and a one-lexem document
+    offs2 = np.concatenate([[0, 0], offs[:20], [offs[19]], offs[20:22], [offs[21] + 1], offs[22:], [offs[-1]]]).astype(np.uint64)
+    offs2 = np.maximum.accumulate(offs2)
+    gpu, ref, m, o = _run_both(lambda x: synth.apply_rules(x, rules), lex, offs2)
+    _compare(gpu, ref, len(offs2) - 1)
+
+
+def test_origseg_and_position_gaps():
+    """ordinal positions with jumps > 64 exercise the far-expiry heap (ruleMatcherAutomaton.cpp:1093-1129)."""
+    rng = np.random.default_rng(41)
+    rules = []
+    for ni in range(400):
+        rg = int(rng.integers(1, 200))
+        rules.append(("r%d" % ni, ["sequence", "within", "sequence_struct", "within_struct"][ni % 4], rg,
+                      [int(rng.integers(1, 12)), int(rng.integers(1, 12))]))
+    ndocs, n = 60, 400
+    lex = np.zeros((ndocs * n, 4), np.uint32)
+    offs = np.arange(ndocs + 1, dtype=np.uint64) * n
+    seg = np.zeros(ndocs * n, np.uint32)
+    for d in range(ndocs):
+        steps = rng.choice([0, 1, 1, 1, 2, 5, 63, 64, 65, 130, 300], size=n)
+        steps[0] = 1
+        pos = np.cumsum(steps)
+        ids = rng.integers(1, 12, size=n)
+        ids[rng.random(n) < 0.08] = synth.DELIM
+        lex[d * n:(d + 1) * n, 0] = ids
+        lex[d * n:(d + 1) * n, 1] = pos
+        lex[d * n:(d + 1) * n, 2] = np.arange(n) * 3
+        lex[d * n:(d + 1) * n, 3] = 2
+        seg[d * n:(d + 1) * n] = np.arange(n) // 100
+    gpu, ref, m, o = _run_both(lambda x: synth.apply_rules(x, rules), lex, offs, seg)
+    assert len(ref.results) > 0
+    _compare(gpu, ref, ndocs)
+
+
+def test_not_ascending_positions_is_an_error():
+    m = spa.PatternMatcherInstance()
+    m.pushTerm(1)
+    m.definePattern("p")
+    ctx = m.createContext()
+    lex = np.array([[1, 5, 0, 1], [1, 4, 1, 1]], np.uint32)
+    b = ctx.matchDocs(lex, [0, 2], check=False)
+    assert b.status[0] == 1
+    with pytest.raises(spa.PatternError):
+        ctx.matchDocs(lex, [0, 2])
+
+
+def test_single_document_interface():
+    """putInput / fetchResults / getStatistics / reset (patternMatcher.cpp:131-331)."""
+    case = l2_cases.load("simple_token_pattern_match.json")
+    m = spa.PatternMatcherInstance()
+    l2_cases.build_simple(m, case)
+    ctx = m.createContext()
+    for lx in l2_cases.simple_doc(case):
+        ctx.putInput(int(lx[0]), int(lx[1]), int(lx[3]), int(lx[4]))
+    res, items = ctx.fetchResults()
+    assert sorted({(m.patternName(int(r[0])), int(r[1])) for r in res}) == sorted(
+        (r["name"], p) for r in case["rules"] for p in r["expected_ordpos"])
+    st = ctx.getStatistics()
+    assert st["nofProgramsInstalled"] == 18 and st["nofSignalsFired"] == 26
+    ctx.reset()
+    res, items = ctx.fetchResults()
+    assert len(res) == 0
