@@ -182,6 +182,12 @@ int sp_matcher_ctx_match_docs_device(sp_matcher_ctx_t* c, const void* d_lexems, 
 int sp_matcher_ctx_batch_counters(sp_matcher_ctx_t* c, uint64_t counters[8]);
 /* duration of the last rule-automaton kernel in milliseconds (HIP events on the launch stream) */
 double sp_matcher_ctx_last_kernel_ms(sp_matcher_ctx_t* c);
+/* copies the per-document status words of the last batch to the host (waits for the stream) */
+int sp_matcher_ctx_batch_status(sp_matcher_ctx_t* c, int32_t* status, size_t ndocs);
+/* doubles every per-document working-set capacity (what the host entry points do on SP_DOC_ERR_ARENA) */
+int sp_matcher_ctx_grow_arena(sp_matcher_ctx_t* c);
+/* minimum capacity (records) of the device result / item buffers of the batch entry points */
+int sp_matcher_ctx_reserve_output(sp_matcher_ctx_t* c, uint64_t results, uint64_t items);
 /* working-set capacity per in-flight document; 0 keeps a default.  Takes effect at the next launch. */
 int sp_matcher_ctx_set_arena(sp_matcher_ctx_t* c, uint32_t max_rules, uint32_t max_triggers, uint32_t bucket_capacity,
                              uint32_t max_items, uint32_t max_follow);

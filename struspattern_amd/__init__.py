@@ -136,6 +136,19 @@ class PatternMatcherContext:
             raise PatternError("reading batch counters failed: " + self._err())
         return {"results": arr[0], "items": arr[1], "events": arr[2], "failed_docs": arr[3]}
 
+    def batchStatus(self, ndocs):
+        st = np.zeros(ndocs, np.int32)
+        rc = self._L.sp_matcher_ctx_batch_status(self._h, st.ctypes.data, ndocs)
+        if rc != 0:
+            raise PatternError("reading batch status failed: " + self._err())
+        return st
+
+    def growArena(self):
+        return self._L.sp_matcher_ctx_grow_arena(self._h) == 0
+
+    def reserveOutput(self, results, items):
+        self._L.sp_matcher_ctx_reserve_output(self._h, results, items)
+
     def lastKernelMs(self):
         return self._L.sp_matcher_ctx_last_kernel_ms(self._h)
 

@@ -218,6 +218,33 @@ int sp_matcher_ctx_set_arena( sp_matcher_ctx_t* c, uint32_t max_rules, uint32_t 
 	return SP_OK;
 }
 
+int sp_matcher_ctx_batch_status( sp_matcher_ctx_t* c, int32_t* status, size_t ndocs)
+{
+	return guardedCall( c->lasterror, SP_ERR_DEVICE, [&]{
+		HIP_CHECK( hipSetDevice( c->device));
+		HIP_CHECK( hipStreamSynchronize( c->lastStream));
+		if (ndocs > c->lastNdocs) ndocs = c->lastNdocs;
+		if (ndocs) HIP_CHECK( hipMemcpy( status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+	});
+}
+
+int sp_matcher_ctx_grow_arena( sp_matcher_ctx_t* c)
+{
+	if (c->arena.maxRules >= (1u<<20)) { c->lasterror = "arena at its maximum size"; return SP_ERR_INVALID; }
+	c->arena.maxRules *= 2; c->arena.maxTrigs *= 2; c->arena.bucketCap *= 2; c->arena.maxItems *= 2;
+	c->arena.maxRefs *= 2; c->arena.maxFollow *= 2; c->arena.maxDispose *= 2; c->arena.maxHeap *= 2;
+	c->arena.maxStaged *= 2; c->arena.maxGStack *= 2;
+	c->arenaWaves = 0;
+	return SP_OK;
+}
+
+int sp_matcher_ctx_reserve_output( sp_matcher_ctx_t* c, uint64_t results, uint64_t items)
+{
+	if (results > c->minResultCapacity) c->minResultCapacity = results;
+	if (items > c->minItemCapacity) c->minItemCapacity = items;
+	return SP_OK;
+}
+
 } // extern "C"
 
 namespace {
@@ -404,14 +431,7 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 				HIP_CHECK( hipMemcpy( st.data(), c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
 				bool arena = false;
 				for (size_t di=0; di<ndocs && !arena; ++di) arena = (st[ di] == SPD_ERR_ARENA);
-				if (arena && c->arena.maxRules < (1u<<20))
-				{
-					c->arena.maxRules *= 2; c->arena.maxTrigs *= 2; c->arena.bucketCap *= 2; c->arena.maxItems *= 2;
-					c->arena.maxRefs *= 2; c->arena.maxFollow *= 2; c->arena.maxDispose *= 2; c->arena.maxHeap *= 2;
-					c->arena.maxStaged *= 2; c->arena.maxGStack *= 2;
-					c->arenaWaves = 0;
-					grow = true;
-				}
+				if (arena && sp_matcher_ctx_grow_arena( c) == SP_OK) grow = true;
 			}
 			if (!grow || attempt >= 6) break;
 		}
