@@ -156,3 +156,88 @@ class L2Matcher:
         if rc != 0:
             raise OracleError(self._L.orc_l2_last_error(self._h).decode())
         return L2Results(res, items, offs, stats, status)
+
+
+POSBIND = {"content": 0, "successor": 1, "predecessor": 2, "unique": 3}
+
+
+def _lib_l1():
+    L = lib()
+    if not getattr(L, "_l1_ready", False):
+        L.orc_l1_new.restype = ctypes.c_void_p
+        L.orc_l1_free.argtypes = [ctypes.c_void_p]
+        L.orc_l1_last_error.restype = ctypes.c_char_p
+        L.orc_l1_last_error.argtypes = [ctypes.c_void_p]
+        L.orc_l1_define_lexem.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]
+        L.orc_l1_define_symbol.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p]
+        L.orc_l1_define_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
+        L.orc_l1_compile.argtypes = [ctypes.c_void_p]
+        L.orc_l1_get_symbol.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p]
+        L.orc_l1_get_symbol.restype = ctypes.c_uint32
+        L.orc_l1_match_docs.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32)), ctypes.POINTER(ctypes.POINTER(ctypes.c_uint64))]
+        L._l1_ready = True
+    return L
+
+
+class L1Lexer:
+    """Mirror of PatternLexerInstanceInterface (patternLexer.cpp:961-1151) on the CPU oracle."""
+
+    def __init__(self):
+        self._L = _lib_l1()
+        self._h = self._L.orc_l1_new()
+
+    def __del__(self):
+        try:
+            self._L.orc_l1_free(self._h)
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise OracleError(self._L.orc_l1_last_error(self._h).decode(errors="replace"))
+
+    def defineLexem(self, id_, expression, resultIndex=0, level=0, posbind="content"):
+        expr = expression if isinstance(expression, bytes) else expression.encode()
+        pb = POSBIND[posbind] if isinstance(posbind, str) else int(posbind)
+        self._chk(self._L.orc_l1_define_lexem(self._h, id_, expr, resultIndex, level, pb))
+
+    def defineSymbol(self, symbolid, patternid, name):
+        nm = name if isinstance(name, bytes) else name.encode()
+        self._chk(self._L.orc_l1_define_symbol(self._h, symbolid, patternid, nm))
+
+    def getSymbol(self, patternid, name):
+        nm = name if isinstance(name, bytes) else name.encode()
+        return self._L.orc_l1_get_symbol(self._h, patternid, nm)
+
+    def defineOption(self, name, value=0.0):
+        self._chk(self._L.orc_l1_define_option(self._h, name.encode(), value))
+
+    def compile(self):
+        self._chk(self._L.orc_l1_compile(self._h))
+        return True
+
+    def matchDocs(self, text, doc_offsets, nthreads=1, raw=False):
+        """text: bytes of all documents concatenated; doc_offsets: (ndocs+1,) u64.
+        Returns (lexems (n,4) u32 [id, ordpos, origpos, origsize], lexem_doc_offsets (ndocs+1,) u64).
+        raw=True returns the report stream [patternidx, from, to, 0] that feeds the event handler."""
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        ndocs = len(doc_offsets) - 1
+        buf = bytes(text)
+        pl = ctypes.POINTER(ctypes.c_uint32)()
+        po = ctypes.POINTER(ctypes.c_uint64)()
+        rc = self._L.orc_l1_match_docs(self._h, buf, doc_offsets.ctypes.data, ndocs, nthreads, int(raw), ctypes.byref(pl), ctypes.byref(po))
+        try:
+            offs = np.ctypeslib.as_array(po, shape=(ndocs + 1,)).copy()
+            n = int(offs[-1])
+            lex = np.ctypeslib.as_array(pl, shape=(n * 4 + 1,))[:n * 4].reshape(-1, 4).copy()
+        finally:
+            self._L.orc_free(pl)
+            self._L.orc_free(po)
+        if rc != 0:
+            raise OracleError(self._L.orc_l1_last_error(self._h).decode(errors="replace"))
+        return lex, offs
+
+    def match(self, text):
+        lex, _ = self.matchDocs(text, [0, len(text)])
+        return lex

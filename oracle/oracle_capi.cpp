@@ -196,3 +196,90 @@ void orc_l2_free_out( OrcL2Out* out)
 void orc_free( void* p) { std::free( p); }
 
 } // extern "C"
+
+// ------------------------------------------------------------------ level 1
+#include "l1_oracle.hpp"
+namespace {
+struct L1Handle { oracle::LexerInstance inst; std::string lasterror; };
+template <class FN>
+int guarded1( L1Handle* h, FN fn)
+{
+	try { fn(); return 0; }
+	catch (const std::exception& e) { h->lasterror = e.what(); return -1; }
+}
+}
+extern "C" {
+void* orc_l1_new() { return new L1Handle(); }
+void orc_l1_free( void* h) { delete (L1Handle*)h; }
+const char* orc_l1_last_error( void* h) { return ((L1Handle*)h)->lasterror.c_str(); }
+int orc_l1_define_lexem( void* hp, uint32_t id, const char* expr, uint32_t resultIndex, uint32_t level, int posbind)
+{ L1Handle* h=(L1Handle*)hp; return guarded1( h, [&]{ h->inst.defineLexem( id, expr, resultIndex, level, (oracle::PosBind)posbind); }); }
+int orc_l1_define_symbol( void* hp, uint32_t symbolid, uint32_t patternid, const char* name)
+{ L1Handle* h=(L1Handle*)hp; return guarded1( h, [&]{ h->inst.defineSymbol( symbolid, patternid, name); }); }
+int orc_l1_define_option( void* hp, const char* name, double v)
+{ L1Handle* h=(L1Handle*)hp; return guarded1( h, [&]{ h->inst.defineOption( name, v); }); }
+int orc_l1_compile( void* hp)
+{ L1Handle* h=(L1Handle*)hp; return guarded1( h, [&]{ h->inst.compile(); }); }
+uint32_t orc_l1_get_symbol( void* hp, uint32_t patternid, const char* name) { return ((L1Handle*)hp)->inst.getSymbol( patternid, name); }
+
+// documents: concatenated bytes + ndocs+1 offsets.  out_lexems: malloc'd n x 4 u32 (id, ordpos, origpos, origsize);
+// out_doc_offsets: malloc'd ndocs+1 u64.  raw != 0: returns the raw report stream (idx, from, to, 0) instead.
+int orc_l1_match_docs( void* hp, const char* text, const uint64_t* doc_offsets, uint64_t ndocs, int nthreads, int raw,
+			uint32_t** out_lexems, uint64_t** out_doc_offsets)
+{
+	L1Handle* h = (L1Handle*)hp;
+	std::vector<std::vector<uint32_t> > perdoc( ndocs);
+	std::atomic<uint64_t> cursor(0);
+	std::atomic<int> haserr(0);
+	std::string firsterr;
+	auto worker = [&]()
+	{
+		for (;;)
+		{
+			uint64_t di = cursor.fetch_add( 1);
+			if (di >= ndocs) break;
+			try
+			{
+				const char* src = text + doc_offsets[ di];
+				size_t len = (size_t)(doc_offsets[ di+1] - doc_offsets[ di]);
+				std::vector<uint32_t>& o = perdoc[ di];
+				if (raw)
+				{
+					std::vector<oracle::RawMatch> r = h->inst.rawMatches( src, len);
+					for (size_t i=0; i<r.size(); ++i) { o.push_back( r[i].idx); o.push_back( r[i].from); o.push_back( r[i].to); o.push_back( 0); }
+				}
+				else
+				{
+					std::vector<oracle::LexemOut> r = h->inst.match( src, len);
+					for (size_t i=0; i<r.size(); ++i) { o.push_back( r[i].id); o.push_back( r[i].ordpos); o.push_back( r[i].origpos); o.push_back( r[i].origsize); }
+				}
+			}
+			catch (const std::exception& e)
+			{
+				if (!haserr.exchange( 1)) firsterr = e.what();
+			}
+		}
+	};
+	if (nthreads <= 1) worker();
+	else
+	{
+		std::vector<std::thread> th;
+		for (int ti=0; ti<nthreads; ++ti) th.push_back( std::thread( worker));
+		for (size_t ti=0; ti<th.size(); ++ti) th[ti].join();
+	}
+	uint64_t total = 0;
+	for (uint64_t di=0; di<ndocs; ++di) total += perdoc[ di].size()/4;
+	*out_lexems = (uint32_t*)std::malloc( (total*4+1)*sizeof(uint32_t));
+	*out_doc_offsets = (uint64_t*)std::malloc( (ndocs+1)*sizeof(uint64_t));
+	uint64_t p = 0;
+	for (uint64_t di=0; di<ndocs; ++di)
+	{
+		(*out_doc_offsets)[ di] = p;
+		if (!perdoc[ di].empty()) std::memcpy( *out_lexems + p*4, perdoc[ di].data(), perdoc[ di].size()*sizeof(uint32_t));
+		p += perdoc[ di].size()/4;
+	}
+	(*out_doc_offsets)[ ndocs] = p;
+	if (haserr.load()) { h->lasterror = firsterr; return -1; }
+	return 0;
+}
+} // extern "C"
