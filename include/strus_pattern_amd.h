@@ -192,6 +192,65 @@ int sp_matcher_ctx_reserve_output(sp_matcher_ctx_t* c, uint64_t results, uint64_
 int sp_matcher_ctx_set_arena(sp_matcher_ctx_t* c, uint32_t max_rules, uint32_t max_triggers, uint32_t bucket_capacity,
                              uint32_t max_items, uint32_t max_follow);
 
+/* ==== level 1: pattern lexer ==== */
+
+/* strus::createPatternLexer_std + PatternLexerInterface::createInstance
+ * (src/libstrus_pattern.cpp:35-47, src/patternLexer.cpp:1165-1172) */
+sp_lexer_t* sp_lexer_create(void);
+void sp_lexer_free(sp_lexer_t* l);
+const char* sp_lexer_last_error(const sp_lexer_t* l);
+
+/* PatternLexerInstanceInterface (src/patternLexer.cpp:971-1141), same argument meaning.
+ * Expressions are NUL terminated; posbind is an sp_position_bind. */
+int sp_lexer_define_lexem_name(sp_lexer_t* l, uint32_t id, const char* name);                       /* :971 */
+const char* sp_lexer_get_lexem_name(const sp_lexer_t* l, uint32_t id);                              /* :983 */
+int sp_lexer_define_lexem(sp_lexer_t* l, uint32_t id, const char* expression, uint32_t resultIndex,
+                          uint32_t level, int posbind);                                             /* :990 */
+int sp_lexer_define_symbol(sp_lexer_t* l, uint32_t symbolid, uint32_t patternid, const char* name); /* :1008 */
+uint32_t sp_lexer_get_symbol(const sp_lexer_t* l, uint32_t patternid, const char* name);            /* :1020 */
+int sp_lexer_define_option(sp_lexer_t* l, const char* name, double value);                          /* :1031 */
+int sp_lexer_compile(sp_lexer_t* l);                                                                /* :1068 */
+/* compiled automaton tables as a flat u64 array (test hook; layout in csrc/capi_l1.cpp) */
+size_t sp_lexer_dump_tables(const sp_lexer_t* l, uint64_t** out);
+
+/* PatternLexerInstanceInterface::createContext (:1120): an error before compile(); SP_ERR_DEVICE
+ * without a usable GPU (no CPU fallback) */
+sp_lexer_ctx_t* sp_lexer_ctx_create(const sp_lexer_t* l, int device);
+void sp_lexer_ctx_free(sp_lexer_ctx_t* c);
+const char* sp_lexer_ctx_last_error(const sp_lexer_ctx_t* c);
+/* PatternLexerContextInterface::match (:858): one document, host buffers */
+int sp_lexer_ctx_match(sp_lexer_ctx_t* c, const char* src, size_t srclen, sp_lexem_t** lexems, size_t* nlexems);
+/* PatternLexerContextInterface::reset (:700) */
+int sp_lexer_ctx_reset(sp_lexer_ctx_t* c);
+
+/* ---- batch mode: many documents per launch ---- */
+typedef struct sp_lex_batch {
+	size_t ndocs;
+	size_t nlexems;
+	sp_lexem_t* lexems;            /* grouped by document, reference output order inside a document */
+	uint64_t* doc_lexem_offsets;   /* ndocs+1 */
+	int32_t* doc_status;           /* ndocs x SP_DOC_* */
+} sp_lex_batch_t;
+/* text: all documents back to back; doc_offsets: ndocs+1 byte offsets */
+int sp_lexer_ctx_match_docs(sp_lexer_ctx_t* c, const char* text, const uint64_t* doc_offsets, size_t ndocs, sp_lex_batch_t* out);
+void sp_lex_batch_free(sp_lex_batch_t* b);
+
+typedef struct sp_lex_device_batch {
+	size_t ndocs;
+	void* d_lexems;        /* sp_lexem_t[], each document's lexems contiguous */
+	void* d_doc_ranges;    /* uint64_t[ndocs][2] = (first lexem, count) */
+	void* d_doc_status;    /* int32_t[ndocs] */
+	void* d_counters;      /* uint64_t[8]: lexems, bytes, raw reports, failed docs */
+} sp_lex_device_batch_t;
+/* device-resident text and offsets, asynchronous on `stream` (hipStream_t); lexems stay in HBM */
+int sp_lexer_ctx_match_docs_device(sp_lexer_ctx_t* c, const void* d_text, const void* d_doc_offsets,
+                                   size_t ndocs, size_t nbytes, void* stream, sp_lex_device_batch_t* out);
+int sp_lexer_ctx_batch_counters(sp_lexer_ctx_t* c, uint64_t counters[8]);
+int sp_lexer_ctx_batch_status(sp_lexer_ctx_t* c, int32_t* status, size_t ndocs);
+double sp_lexer_ctx_last_kernel_ms(sp_lexer_ctx_t* c);
+int sp_lexer_ctx_reserve_output(sp_lexer_ctx_t* c, uint64_t lexems);
+int sp_lexer_ctx_grow_arena(sp_lexer_ctx_t* c);
+
 #ifdef __cplusplus
 }
 #endif

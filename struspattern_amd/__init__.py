@@ -12,7 +12,8 @@ import numpy as np
 from . import capi
 from .capi import SpLexem, SpResult, SpResultItem
 
-__all__ = ["PatternMatcher", "PatternMatcherInstance", "PatternMatcherContext", "PatternError", "JOIN_OP"]
+__all__ = ["PatternMatcher", "PatternMatcherInstance", "PatternMatcherContext", "PatternLexer", "PatternLexerInstance",
+           "PatternLexerContext", "PatternError", "JOIN_OP", "POSITION_BIND"]
 
 JOIN_OP = {"sequence": 0, "sequence_imm": 1, "sequence_struct": 2, "within": 3, "within_struct": 4, "any": 5, "and": 6}
 
@@ -235,6 +236,176 @@ class PatternMatcher:
 
     def createInstance(self):
         return PatternMatcherInstance()
+
+    def name(self):
+        return "std"
+
+
+POSITION_BIND = {"content": 0, "successor": 1, "predecessor": 2, "unique": 3}
+
+
+class LexBatch:
+    def __init__(self, lexems, doc_offsets, status):
+        self.lexems = lexems            # (n,4) u32: id, ordpos, origpos, origsize
+        self.doc_offsets = doc_offsets  # (ndocs+1,) u64
+        self.status = status            # (ndocs,) i32
+
+    def doc(self, i):
+        return self.lexems[self.doc_offsets[i]:self.doc_offsets[i + 1]]
+
+
+class PatternLexerContext:
+    """PatternLexerContextInterface (src/patternLexer.cpp:681-959) + batch mode."""
+
+    def __init__(self, instance, device=0):
+        self._L = capi.lib()
+        self._inst = instance
+        self._h = self._L.sp_lexer_ctx_create(instance._h, device)
+        if not self._h:
+            raise PatternError("failed to create term match context: " + self._L.sp_lexer_last_error(instance._h).decode())
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.sp_lexer_ctx_free(self._h)
+        except Exception:
+            pass
+
+    def _err(self):
+        return self._L.sp_lexer_ctx_last_error(self._h).decode(errors="replace")
+
+    def match(self, src):
+        """std::vector<PatternLexem> match(const char* src, size_t len) (:858)."""
+        buf = bytes(src)
+        lex = ctypes.POINTER(SpLexem)()
+        n = ctypes.c_size_t()
+        rc = self._L.sp_lexer_ctx_match(self._h, buf, len(buf), ctypes.byref(lex), ctypes.byref(n))
+        if rc != 0:
+            raise PatternError("failed to run pattern matching terms with regular expressions: " + self._err())
+        try:
+            arr = np.ctypeslib.as_array(ctypes.cast(lex, ctypes.POINTER(ctypes.c_uint32)), shape=(n.value * 4 + 1,))[:n.value * 4].reshape(-1, 4).copy()
+        finally:
+            self._L.sp_free(lex)
+        return arr
+
+    def reset(self):
+        self._L.sp_lexer_ctx_reset(self._h)
+
+    def matchDocs(self, text, doc_offsets, check=True):
+        buf = bytes(text)
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        ndocs = len(doc_offsets) - 1
+        b = capi.SpLexBatch()
+        rc = self._L.sp_lexer_ctx_match_docs(self._h, buf, doc_offsets.ctypes.data, ndocs, ctypes.byref(b))
+        try:
+            if rc != 0 and (rc != -5 or check):
+                raise PatternError("batch lexer run failed (%d): %s" % (rc, self._err()))
+            lex = np.ctypeslib.as_array(ctypes.cast(b.lexems, ctypes.POINTER(ctypes.c_uint32)), shape=(b.nlexems * 4 + 1,))[:b.nlexems * 4].reshape(-1, 4).copy()
+            offs = np.ctypeslib.as_array(b.doc_lexem_offsets, shape=(ndocs + 1,)).copy()
+            status = np.ctypeslib.as_array(b.doc_status, shape=(ndocs + 1,))[:ndocs].copy()
+        finally:
+            self._L.sp_lex_batch_free(ctypes.byref(b))
+        return LexBatch(lex, offs, status)
+
+    def matchDocsDevice(self, d_text, d_doc_offsets, ndocs, nbytes, stream=0):
+        out = capi.SpLexDeviceBatch()
+        rc = self._L.sp_lexer_ctx_match_docs_device(self._h, d_text, d_doc_offsets, ndocs, nbytes, stream or None, ctypes.byref(out))
+        if rc != 0:
+            raise PatternError("device batch lexer run failed (%d): %s" % (rc, self._err()))
+        return out
+
+    def batchCounters(self):
+        arr = (ctypes.c_uint64 * 8)()
+        if self._L.sp_lexer_ctx_batch_counters(self._h, arr) != 0:
+            raise PatternError("reading batch counters failed: " + self._err())
+        return {"lexems": arr[0], "bytes": arr[1], "failed_docs": arr[3]}
+
+    def batchStatus(self, ndocs):
+        st = np.zeros(ndocs, np.int32)
+        if self._L.sp_lexer_ctx_batch_status(self._h, st.ctypes.data, ndocs) != 0:
+            raise PatternError("reading batch status failed: " + self._err())
+        return st
+
+    def lastKernelMs(self):
+        return self._L.sp_lexer_ctx_last_kernel_ms(self._h)
+
+    def reserveOutput(self, lexems):
+        self._L.sp_lexer_ctx_reserve_output(self._h, lexems)
+
+    def growArena(self):
+        return self._L.sp_lexer_ctx_grow_arena(self._h) == 0
+
+
+class PatternLexerInstance:
+    """PatternLexerInstanceInterface (src/patternLexer.cpp:961-1151)."""
+
+    def __init__(self):
+        self._L = capi.lib()
+        self._h = self._L.sp_lexer_create()
+        if not self._h:
+            raise PatternError("failed to create term match instance")
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.sp_lexer_free(self._h)
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise PatternError("%s: %s" % (what, self._L.sp_lexer_last_error(self._h).decode(errors="replace")))
+
+    @staticmethod
+    def _b(s):
+        return s if isinstance(s, bytes) else s.encode()
+
+    def defineLexemName(self, id_, name):
+        self._chk(self._L.sp_lexer_define_lexem_name(self._h, id_, self._b(name)), "failed to assign lexem name to lexem or symbol identifier")
+
+    def getLexemName(self, id_):
+        s = self._L.sp_lexer_get_lexem_name(self._h, id_)
+        return s.decode() if s else None
+
+    def defineLexem(self, id_, expression, resultIndex=0, level=0, posbind="content"):
+        pb = POSITION_BIND[posbind] if isinstance(posbind, str) else int(posbind)
+        self._chk(self._L.sp_lexer_define_lexem(self._h, id_, self._b(expression), resultIndex, level, pb), "failed to define term match regular expression pattern")
+
+    def defineSymbol(self, symbolid, patternid, name):
+        self._chk(self._L.sp_lexer_define_symbol(self._h, symbolid, patternid, self._b(name)), "failed to define regular expression pattern symbol")
+
+    def getSymbol(self, patternid, name):
+        return self._L.sp_lexer_get_symbol(self._h, patternid, self._b(name))
+
+    def defineOption(self, name, value=0.0):
+        self._chk(self._L.sp_lexer_define_option(self._h, name.encode(), value), "define option failed for pattern lexer")
+
+    def compile(self):
+        self._chk(self._L.sp_lexer_compile(self._h), "failed to compile regular expression patterns")
+        return True
+
+    def createContext(self, device=0):
+        return PatternLexerContext(self, device)
+
+    def dumpTables(self):
+        p = ctypes.POINTER(ctypes.c_uint64)()
+        n = self._L.sp_lexer_dump_tables(self._h, ctypes.byref(p))
+        arr = np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.uint64)
+        self._L.sp_free(p)
+        return arr
+
+    def name(self):
+        return "std"
+
+
+class PatternLexer:
+    """PatternLexerInterface (src/patternLexer.hpp:22-41)."""
+
+    def getCompileOptionNames(self):
+        return ["CASELESS", "DOTALL", "MULTILINE", "ALLOWEMPTY", "UCP"]  # src/patternLexer.cpp:1154-1163
+
+    def createInstance(self):
+        return PatternLexerInstance()
 
     def name(self):
         return "std"

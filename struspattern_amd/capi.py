@@ -38,6 +38,17 @@ class SpMatchBatch(ctypes.Structure):
     ]
 
 
+class SpLexBatch(ctypes.Structure):
+    _fields_ = [
+        ("ndocs", ctypes.c_size_t), ("nlexems", ctypes.c_size_t), ("lexems", P(SpLexem)),
+        ("doc_lexem_offsets", P(c_u64)), ("doc_status", P(ctypes.c_int32)),
+    ]
+
+
+class SpLexDeviceBatch(ctypes.Structure):
+    _fields_ = [("ndocs", ctypes.c_size_t), ("d_lexems", c_vp), ("d_doc_ranges", c_vp), ("d_doc_status", c_vp), ("d_counters", c_vp)]
+
+
 class SpMatchDeviceBatch(ctypes.Structure):
     _fields_ = [
         ("ndocs", ctypes.c_size_t), ("d_results", c_vp), ("d_items", c_vp), ("d_doc_result_offsets", c_vp),
@@ -82,6 +93,30 @@ SIGNATURES = {
     "sp_matcher_ctx_grow_arena": (ctypes.c_int, [c_vp]),
     "sp_matcher_ctx_reserve_output": (ctypes.c_int, [c_vp, c_u64, c_u64]),
     "sp_matcher_ctx_set_arena": (ctypes.c_int, [c_vp, c_u32, c_u32, c_u32, c_u32, c_u32]),
+    "sp_lexer_create": (c_vp, []),
+    "sp_lexer_free": (None, [c_vp]),
+    "sp_lexer_last_error": (c_cp, [c_vp]),
+    "sp_lexer_define_lexem_name": (ctypes.c_int, [c_vp, c_u32, c_cp]),
+    "sp_lexer_get_lexem_name": (c_cp, [c_vp, c_u32]),
+    "sp_lexer_define_lexem": (ctypes.c_int, [c_vp, c_u32, c_cp, c_u32, c_u32, ctypes.c_int]),
+    "sp_lexer_define_symbol": (ctypes.c_int, [c_vp, c_u32, c_u32, c_cp]),
+    "sp_lexer_get_symbol": (c_u32, [c_vp, c_u32, c_cp]),
+    "sp_lexer_define_option": (ctypes.c_int, [c_vp, c_cp, ctypes.c_double]),
+    "sp_lexer_compile": (ctypes.c_int, [c_vp]),
+    "sp_lexer_dump_tables": (ctypes.c_size_t, [c_vp, P(P(c_u64))]),
+    "sp_lexer_ctx_create": (c_vp, [c_vp, ctypes.c_int]),
+    "sp_lexer_ctx_free": (None, [c_vp]),
+    "sp_lexer_ctx_last_error": (c_cp, [c_vp]),
+    "sp_lexer_ctx_match": (ctypes.c_int, [c_vp, c_cp, ctypes.c_size_t, P(P(SpLexem)), P(ctypes.c_size_t)]),
+    "sp_lexer_ctx_reset": (ctypes.c_int, [c_vp]),
+    "sp_lexer_ctx_match_docs": (ctypes.c_int, [c_vp, c_cp, c_vp, ctypes.c_size_t, P(SpLexBatch)]),
+    "sp_lex_batch_free": (None, [P(SpLexBatch)]),
+    "sp_lexer_ctx_match_docs_device": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, ctypes.c_size_t, c_vp, P(SpLexDeviceBatch)]),
+    "sp_lexer_ctx_batch_counters": (ctypes.c_int, [c_vp, P(c_u64)]),
+    "sp_lexer_ctx_batch_status": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t]),
+    "sp_lexer_ctx_last_kernel_ms": (ctypes.c_double, [c_vp]),
+    "sp_lexer_ctx_reserve_output": (ctypes.c_int, [c_vp, c_u64]),
+    "sp_lexer_ctx_grow_arena": (ctypes.c_int, [c_vp]),
 }
 
 _LIB = None

@@ -1,0 +1,369 @@
+// C-ABI of level 1 (include/strus_pattern_amd.h): lexer compiler handle + GPU lexer context.
+// No CPU fallback: a context cannot be created without a usable HIP device.
+#include "../../include/strus_pattern_amd.h"
+#include "l1_compile.hpp"
+#include "l1_device.h"
+#include "hip_util.hpp"
+#include <hip/hip_runtime_api.h>
+#include <cstdlib>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace spa {
+hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, hipStream_t stream);
+}
+using namespace spa;
+
+struct sp_lexer
+{
+	LexCompiler compiler;
+	mutable std::string lasterror;
+};
+
+namespace {
+template <class FN>
+int guardedCall1( std::string& err, int errcode, FN fn)
+{
+	try { fn(); return SP_OK; }
+	catch (const std::bad_alloc&) { err = "memory allocation error in strus pattern"; return SP_ERR_NOMEM; }
+	catch (const HipError& e) { err = e.what(); return SP_ERR_DEVICE; }
+	catch (const std::exception& e) { err = e.what(); return errcode; }
+}
+}
+
+struct sp_lexer_ctx
+{
+	const sp_lexer* inst;
+	int device;
+	std::string lasterror;
+	DeviceBuffer dByteClass, dClassCtx, dCharMask, dStartMask, dAcceptMask, dShiftDst, dSelfLoop, dExSrc, dExDst, dExCount,
+		dWordPatBegin, dWordPats, dPatterns, dSymbols, dSymbolText;
+	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus;
+	uint32_t queueCap, eventCap;
+	unsigned arenaWaves; uint64_t arenaWords;
+	uint64_t lexemCapacity, minLexemCapacity;
+	unsigned numCUs;
+	hipEvent_t evStart, evStop; bool evValid;
+	hipStream_t lastStream; size_t lastNdocs;
+	sp_lexer_ctx() :inst(0),device(0),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
+		,numCUs(256),evStart(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0){}
+};
+
+extern "C" {
+
+sp_lexer_t* sp_lexer_create(void) { try { return new sp_lexer(); } catch (...) { return 0; } }
+void sp_lexer_free( sp_lexer_t* l) { delete l; }
+const char* sp_lexer_last_error( const sp_lexer_t* l) { return l->lasterror.c_str(); }
+
+#define LGUARD( CODE, BODY) return guardedCall1( l->lasterror, CODE, [&]{ BODY; })
+
+int sp_lexer_define_lexem_name( sp_lexer_t* l, uint32_t id, const char* name)
+{ LGUARD( SP_ERR_INVALID, l->compiler.defineLexemName( id, name ? name : "")); }
+const char* sp_lexer_get_lexem_name( const sp_lexer_t* l, uint32_t id) { return l->compiler.getLexemName( id); }
+int sp_lexer_define_lexem( sp_lexer_t* l, uint32_t id, const char* expression, uint32_t resultIndex, uint32_t level, int posbind)
+{ LGUARD( SP_ERR_INVALID, l->compiler.defineLexem( id, expression ? expression : "", resultIndex, level, posbind)); }
+int sp_lexer_define_symbol( sp_lexer_t* l, uint32_t symbolid, uint32_t patternid, const char* name)
+{ LGUARD( SP_ERR_INVALID, l->compiler.defineSymbol( symbolid, patternid, name ? name : "")); }
+uint32_t sp_lexer_get_symbol( const sp_lexer_t* l, uint32_t patternid, const char* name) { return l->compiler.getSymbol( patternid, name ? name : ""); }
+int sp_lexer_define_option( sp_lexer_t* l, const char* name, double value)
+{ LGUARD( SP_ERR_INVALID, l->compiler.defineOption( name ? name : "", value)); }
+int sp_lexer_compile( sp_lexer_t* l)
+{ LGUARD( SP_ERR_COMPILE, l->compiler.compile()); }
+
+// Flat dump for tests: header of 8 words {nofPasses, nofClasses, maxExceptions, nofPatterns, nofPositions, 0,0,0},
+// byteClass[256], classCtx[nofClasses], charMask, startMask, acceptMask, shiftDst, selfLoop,
+// exCount[nofPasses], exSrc, exDst, then per pattern {id, word, levelBind, prefixLen, suffixLen, mask}
+size_t sp_lexer_dump_tables( const sp_lexer_t* l, uint64_t** out)
+{
+	const LexTables& T = l->compiler.tables();
+	std::vector<uint64_t> b;
+	b.push_back( T.nofPasses); b.push_back( T.nofClasses); b.push_back( T.maxExceptions); b.push_back( T.patterns.size());
+	b.push_back( T.nofPositions); b.push_back( 0); b.push_back( 0); b.push_back( 0);
+	for (size_t i=0; i<256; ++i) b.push_back( T.byteClass.size() == 256 ? T.byteClass[i] : 0);
+	for (size_t i=0; i<T.classCtx.size(); ++i) b.push_back( T.classCtx[i]);
+	b.insert( b.end(), T.charMask.begin(), T.charMask.end());
+	b.insert( b.end(), T.startMask.begin(), T.startMask.end());
+	b.insert( b.end(), T.acceptMask.begin(), T.acceptMask.end());
+	b.insert( b.end(), T.shiftDst.begin(), T.shiftDst.end());
+	b.insert( b.end(), T.selfLoop.begin(), T.selfLoop.end());
+	for (size_t i=0; i<T.exCount.size(); ++i) b.push_back( T.exCount[i]);
+	b.insert( b.end(), T.exSrc.begin(), T.exSrc.end());
+	b.insert( b.end(), T.exDst.begin(), T.exDst.end());
+	for (size_t i=0; i<T.patterns.size(); ++i)
+	{
+		const DevLexPattern& p = T.patterns[i];
+		b.push_back( p.id); b.push_back( p.word); b.push_back( p.levelBind); b.push_back( p.prefixLen); b.push_back( p.suffixLen);
+		b.push_back( ((uint64_t)p.maskHi << 32) | p.maskLo);
+	}
+	*out = (uint64_t*)std::malloc( (b.size()+1)*sizeof(uint64_t));
+	if (!*out) return 0;
+	std::memcpy( *out, b.data(), b.size()*sizeof(uint64_t));
+	return b.size();
+}
+
+sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
+{
+	sp_lexer_ctx* c = 0;
+	try
+	{
+		if (!l->compiler.compiled())
+		{
+			l->lasterror = "called create context without calling 'compile'";	// src/patternLexer.cpp:1124-1127
+			return 0;
+		}
+		int ndev = 0;
+		hipError_t e = hipGetDeviceCount( &ndev);
+		if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+		{
+			l->lasterror = "no usable HIP device: the pattern lexer runs on the GPU only (no CPU fallback)";
+			return 0;
+		}
+		c = new sp_lexer_ctx();
+		c->inst = l; c->device = device;
+		HIP_CHECK( hipSetDevice( device));
+		hipDeviceProp_t prop;
+		HIP_CHECK( hipGetDeviceProperties( &prop, device));
+		c->numCUs = prop.multiProcessorCount > 0 ? (unsigned)prop.multiProcessorCount : 256u;
+		const LexTables& T = l->compiler.tables();
+		if (T.nofPasses > 32) throw std::runtime_error( "too many regular expression positions for this version (more than 32 passes of 4096 positions)");
+		c->dByteClass.upload( T.byteClass.data(), T.byteClass.size());
+		c->dClassCtx.upload( T.classCtx.data(), T.classCtx.size());
+		c->dCharMask.upload( T.charMask.data(), T.charMask.size()*8);
+		c->dStartMask.upload( T.startMask.data(), T.startMask.size()*8);
+		c->dAcceptMask.upload( T.acceptMask.data(), T.acceptMask.size()*8);
+		c->dShiftDst.upload( T.shiftDst.data(), T.shiftDst.size()*8);
+		c->dSelfLoop.upload( T.selfLoop.data(), T.selfLoop.size()*8);
+		c->dExSrc.upload( T.exSrc.data(), T.exSrc.size()*8);
+		c->dExDst.upload( T.exDst.data(), T.exDst.size()*8);
+		c->dExCount.upload( T.exCount.data(), T.exCount.size()*4);
+		c->dWordPatBegin.upload( T.wordPatBegin.data(), T.wordPatBegin.size()*4);
+		c->dWordPats.upload( T.wordPats.data(), T.wordPats.size()*4);
+		c->dPatterns.upload( T.patterns.data(), T.patterns.size()*sizeof(DevLexPattern));
+		c->dSymbols.upload( T.symbols.data(), T.symbols.size()*sizeof(DevSymbol));
+		c->dSymbolText.upload( T.symbolText.data(), T.symbolText.size());
+		c->dCounters.alloc( L1C_COUNT*sizeof(uint64_t));
+		uint32_t npat = (uint32_t)T.patterns.size();
+		c->queueCap = 4096 > 2*npat+256 ? 4096 : 2*npat+256;
+		HIP_CHECK( hipEventCreate( &c->evStart));
+		HIP_CHECK( hipEventCreate( &c->evStop));
+		return c;
+	}
+	catch (const std::exception& e)
+	{
+		l->lasterror = e.what();
+		delete c;
+		return 0;
+	}
+}
+
+void sp_lexer_ctx_free( sp_lexer_ctx_t* c)
+{
+	if (!c) return;
+	if (c->evStart) (void)hipEventDestroy( c->evStart);
+	if (c->evStop) (void)hipEventDestroy( c->evStop);
+	delete c;
+}
+const char* sp_lexer_ctx_last_error( const sp_lexer_ctx_t* c) { return c->lasterror.c_str(); }
+int sp_lexer_ctx_reset( sp_lexer_ctx_t*) { return SP_OK; }	// the context keeps no per-document state between calls
+
+int sp_lexer_ctx_reserve_output( sp_lexer_ctx_t* c, uint64_t lexems)
+{
+	if (lexems > c->minLexemCapacity) c->minLexemCapacity = lexems;
+	return SP_OK;
+}
+int sp_lexer_ctx_grow_arena( sp_lexer_ctx_t* c)
+{
+	if (c->eventCap >= (1u<<26)) { c->lasterror = "arena at its maximum size"; return SP_ERR_INVALID; }
+	c->eventCap *= 2; c->queueCap *= 2; c->arenaWaves = 0;
+	return SP_OK;
+}
+
+} // extern "C"
+
+namespace {
+void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, size_t ndocs, size_t nbytes, hipStream_t stream)
+{
+	HIP_CHECK( hipSetDevice( c->device));
+	const LexTables& T = c->inst->compiler.tables();
+	unsigned wavesWanted = (unsigned)((ndocs < (size_t)c->numCUs*16) ? ndocs : (size_t)c->numCUs*16);
+	unsigned nblocks = (wavesWanted + 3) / 4;
+	if (nblocks == 0) nblocks = 1;
+	unsigned nwaves = nblocks*4;
+	uint64_t perWaveWords = 4ull*c->queueCap + 4ull*c->eventCap;
+	{
+		size_t maxWaves = ((size_t)48 << 30) / (perWaveWords*4);
+		if (maxWaves < 4) maxWaves = 4;
+		if (nwaves > maxWaves) { nblocks = (unsigned)(maxWaves/4); nwaves = nblocks*4; }
+	}
+	if (c->arenaWaves < nwaves || c->arenaWords != perWaveWords)
+	{
+		size_t full = (size_t)c->numCUs*16;
+		if (full * perWaveWords*4 > ((size_t)48 << 30)) full = ((size_t)48 << 30) / (perWaveWords*4);
+		unsigned alloc = nwaves < full ? (unsigned)full : nwaves;
+		c->dArena.alloc( (size_t)alloc * perWaveWords * 4);
+		c->arenaWaves = alloc; c->arenaWords = perWaveWords;
+	}
+	uint64_t want = (uint64_t)nbytes/3 + 4096;
+	if (want < c->minLexemCapacity) want = c->minLexemCapacity;
+	if (c->lexemCapacity < want) { c->dLexems.alloc( want*sizeof(sp_lexem_t)); c->lexemCapacity = want; }
+	c->dDocRange.reserve( (ndocs+1)*2*sizeof(uint64_t));
+	c->dDocStatus.reserve( (ndocs+1)*sizeof(int32_t));
+	HIP_CHECK( hipMemsetAsync( c->dCounters.ptr, 0, L1C_COUNT*sizeof(uint64_t), stream));
+
+	L1Params P;
+	std::memset( &P, 0, sizeof(P));
+	P.byteClass = (const uint8_t*)c->dByteClass.ptr; P.classCtx = (const uint8_t*)c->dClassCtx.ptr;
+	P.charMask = (const uint64_t*)c->dCharMask.ptr; P.startMask = (const uint64_t*)c->dStartMask.ptr;
+	P.acceptMask = (const uint64_t*)c->dAcceptMask.ptr; P.shiftDst = (const uint64_t*)c->dShiftDst.ptr;
+	P.selfLoop = (const uint64_t*)c->dSelfLoop.ptr; P.exSrc = (const uint64_t*)c->dExSrc.ptr; P.exDst = (const uint64_t*)c->dExDst.ptr;
+	P.exCount = (const uint32_t*)c->dExCount.ptr; P.wordPatBegin = (const uint32_t*)c->dWordPatBegin.ptr;
+	P.wordPats = (const uint32_t*)c->dWordPats.ptr; P.patterns = (const DevLexPattern*)c->dPatterns.ptr;
+	P.symbols = (const DevSymbol*)c->dSymbols.ptr; P.symbolText = (const uint8_t*)c->dSymbolText.ptr;
+	P.symbolMask = (uint32_t)T.symbols.size()-1;
+	P.nofPasses = T.nofPasses; P.nofClasses = T.nofClasses; P.maxExceptions = T.maxExceptions ? T.maxExceptions : 1;
+	P.nofPatterns = (uint32_t)T.patterns.size();
+	P.text = (const uint8_t*)d_text; P.docOffsets = (const uint64_t*)d_doc_offsets; P.ndocs = (uint32_t)ndocs;
+	P.arenaBase = (uint32_t*)c->dArena.ptr; P.arenaWords = perWaveWords; P.queueCap = c->queueCap; P.eventCap = c->eventCap;
+	P.counters = (uint64_t*)c->dCounters.ptr; P.lexems = (uint32_t*)c->dLexems.ptr; P.lexemCapacity = c->lexemCapacity;
+	P.docRange = (uint64_t*)c->dDocRange.ptr; P.docStatus = (int32_t*)c->dDocStatus.ptr;
+	HIP_CHECK( hipEventRecord( c->evStart, stream));
+	HIP_CHECK( launchL1Lex( P, nblocks, stream));
+	HIP_CHECK( hipEventRecord( c->evStop, stream));
+	c->evValid = true; c->lastStream = stream; c->lastNdocs = ndocs;
+}
+}
+
+extern "C" {
+
+int sp_lexer_ctx_match_docs_device( sp_lexer_ctx_t* c, const void* d_text, const void* d_doc_offsets,
+				    size_t ndocs, size_t nbytes, void* stream, sp_lex_device_batch_t* out)
+{
+	return guardedCall1( c->lasterror, SP_ERR_INVALID, [&]{
+		if (ndocs >= 0xFFFFFFFFull) throw std::runtime_error( "too many documents in one batch");
+		launchLex( c, d_text, d_doc_offsets, ndocs, nbytes, (hipStream_t)stream);
+		if (out)
+		{
+			out->ndocs = ndocs; out->d_lexems = c->dLexems.ptr; out->d_doc_ranges = c->dDocRange.ptr;
+			out->d_doc_status = c->dDocStatus.ptr; out->d_counters = c->dCounters.ptr;
+		}
+	});
+}
+
+int sp_lexer_ctx_batch_counters( sp_lexer_ctx_t* c, uint64_t counters[8])
+{
+	return guardedCall1( c->lasterror, SP_ERR_DEVICE, [&]{
+		HIP_CHECK( hipSetDevice( c->device));
+		HIP_CHECK( hipStreamSynchronize( c->lastStream));
+		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, L1C_COUNT*sizeof(uint64_t), hipMemcpyDeviceToHost));
+	});
+}
+
+int sp_lexer_ctx_batch_status( sp_lexer_ctx_t* c, int32_t* status, size_t ndocs)
+{
+	return guardedCall1( c->lasterror, SP_ERR_DEVICE, [&]{
+		HIP_CHECK( hipSetDevice( c->device));
+		HIP_CHECK( hipStreamSynchronize( c->lastStream));
+		if (ndocs > c->lastNdocs) ndocs = c->lastNdocs;
+		if (ndocs) HIP_CHECK( hipMemcpy( status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+	});
+}
+
+double sp_lexer_ctx_last_kernel_ms( sp_lexer_ctx_t* c)
+{
+	if (!c->evValid) return -1.0;
+	float ms = 0.0f;
+	if (hipEventSynchronize( c->evStop) != hipSuccess) return -1.0;
+	if (hipEventElapsedTime( &ms, c->evStart, c->evStop) != hipSuccess) return -1.0;
+	return (double)ms;
+}
+
+int sp_lexer_ctx_match_docs( sp_lexer_ctx_t* c, const char* text, const uint64_t* doc_offsets, size_t ndocs, sp_lex_batch_t* out)
+{
+	std::memset( out, 0, sizeof(*out));
+	int rc = guardedCall1( c->lasterror, SP_ERR_INVALID, [&]{
+		HIP_CHECK( hipSetDevice( c->device));
+		size_t nbytes = ndocs ? (size_t)doc_offsets[ ndocs] : 0;
+		for (size_t di=0; di<ndocs; ++di)
+		{
+			if (doc_offsets[ di+1] - doc_offsets[ di] >= 0xFFFFFFFFull) throw std::runtime_error( "size of string to scan out of range");	// :866-869
+		}
+		c->dText.reserve( nbytes+16);
+		c->dDocOffsets.reserve( (ndocs+1)*sizeof(uint64_t));
+		if (nbytes) HIP_CHECK( hipMemcpy( c->dText.ptr, text, nbytes, hipMemcpyHostToDevice));
+		HIP_CHECK( hipMemcpy( c->dDocOffsets.ptr, doc_offsets, (ndocs+1)*sizeof(uint64_t), hipMemcpyHostToDevice));
+		uint64_t counters[ L1C_COUNT];
+		std::vector<int32_t> st( ndocs+1);
+		for (int attempt=0;; ++attempt)
+		{
+			launchLex( c, c->dText.ptr, c->dDocOffsets.ptr, ndocs, nbytes, 0);
+			HIP_CHECK( hipStreamSynchronize( 0));
+			HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
+			if (ndocs) HIP_CHECK( hipMemcpy( st.data(), c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+			bool grow = false;
+			if (counters[ L1C_LEXEMS] > c->lexemCapacity) { c->minLexemCapacity = counters[ L1C_LEXEMS] + counters[ L1C_LEXEMS]/8 + 1024; grow = true; }
+			if (!grow && counters[ L1C_FAILED])
+			{
+				bool arena = false;
+				for (size_t di=0; di<ndocs && !arena; ++di) arena = (st[ di] == SP_DOC_ERR_ARENA);
+				if (arena && sp_lexer_ctx_grow_arena( c) == SP_OK) grow = true;
+			}
+			if (!grow || attempt >= 8) break;
+		}
+		std::vector<uint64_t> range( ndocs*2+2);
+		if (ndocs) HIP_CHECK( hipMemcpy( range.data(), c->dDocRange.ptr, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
+		uint64_t nlex = counters[ L1C_LEXEMS] < c->lexemCapacity ? counters[ L1C_LEXEMS] : c->lexemCapacity;
+		std::vector<sp_lexem_t> raw( nlex+1);
+		if (nlex) HIP_CHECK( hipMemcpy( raw.data(), c->dLexems.ptr, nlex*sizeof(sp_lexem_t), hipMemcpyDeviceToHost));
+		out->ndocs = ndocs;
+		out->doc_lexem_offsets = (uint64_t*)std::malloc( (ndocs+1)*sizeof(uint64_t));
+		out->doc_status = (int32_t*)std::malloc( (ndocs+1)*sizeof(int32_t));
+		uint64_t total = 0;
+		for (size_t di=0; di<ndocs; ++di) { if (st[ di] != 0) range[ 2*di+1] = 0; total += range[ 2*di+1]; }
+		out->lexems = (sp_lexem_t*)std::malloc( (total+1)*sizeof(sp_lexem_t));
+		if (!out->doc_lexem_offsets || !out->doc_status || !out->lexems) throw std::bad_alloc();
+		uint64_t lp = 0;
+		for (size_t di=0; di<ndocs; ++di)
+		{
+			out->doc_lexem_offsets[ di] = lp;
+			out->doc_status[ di] = st[ di];
+			if (range[ 2*di+1]) std::memcpy( out->lexems + lp, raw.data() + range[ 2*di], range[ 2*di+1]*sizeof(sp_lexem_t));
+			lp += range[ 2*di+1];
+		}
+		out->doc_lexem_offsets[ ndocs] = lp;
+		out->nlexems = lp;
+		if (counters[ L1C_FAILED])
+		{
+			size_t bad = 0;
+			while (bad < ndocs && st[ bad] == 0) ++bad;
+			char msg[ 160];
+			snprintf( msg, sizeof(msg), "at least one document failed: document %zu has status %d%s", bad, bad < ndocs ? st[ bad] : -1,
+				(bad < ndocs && st[ bad] == SP_DOC_ERR_LEXEMSIZE) ? " (size of matched term out of range)" : "");
+			throw std::runtime_error( msg);
+		}
+	});
+	if (rc == SP_OK) return SP_OK;
+	return c->lasterror.find( "document failed") != std::string::npos ? SP_ERR_MATCH : rc;
+}
+
+void sp_lex_batch_free( sp_lex_batch_t* b)
+{
+	std::free( b->lexems); std::free( b->doc_lexem_offsets); std::free( b->doc_status);
+	std::memset( b, 0, sizeof(*b));
+}
+
+int sp_lexer_ctx_match( sp_lexer_ctx_t* c, const char* src, size_t srclen, sp_lexem_t** lexems, size_t* nlexems)
+{
+	uint64_t offs[2] = {0, (uint64_t)srclen};
+	sp_lex_batch_t b;
+	int rc = sp_lexer_ctx_match_docs( c, src, offs, 1, &b);
+	if (rc != SP_OK) { sp_lex_batch_free( &b); *lexems = 0; *nlexems = 0; return rc; }
+	*lexems = b.lexems; *nlexems = b.nlexems; b.lexems = 0;
+	sp_lex_batch_free( &b);
+	return SP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,852 @@
+// Level-1 lexer compiler, see l1_compile.hpp and l1_tables.h.
+//
+// Pipeline per expression:  text --(Syntax)--> tree of byte sets / operators / assertions
+//   --(Glushkov with conditional edges)--> positions, first/last/follow sets whose members carry the
+//   set of zero-width assertions crossed --(context splitting)--> unconditional follow edges,
+//   context-dependent start and accept sets --(layout)--> bit ranges in 64-bit words.
+// Reported semantics (what the reference obtains from Hyperscan with HS_FLAG_SOM_LEFTMOST|HS_FLAG_UTF8,
+// src/patternLexer.cpp:391-405): every end offset of a non-empty match once, with its leftmost start.
+#include "l1_compile.hpp"
+#include <algorithm>
+#include <cstring>
+#include <set>
+#include <stdexcept>
+
+using namespace spa;
+
+namespace {
+
+typedef std::vector<std::pair<uint32_t,uint32_t> > CpRanges;
+
+struct ByteSet
+{
+	uint64_t w[4];
+	ByteSet() { w[0]=w[1]=w[2]=w[3]=0; }
+	void add( unsigned c) { w[ c>>6] |= (1ull << (c&63)); }
+	void addRange( unsigned lo, unsigned hi) { for (unsigned c=lo; c<=hi; ++c) add( c); }
+	bool has( unsigned c) const { return (w[ c>>6] >> (c&63)) & 1ull; }
+	bool empty() const { return !(w[0]|w[1]|w[2]|w[3]); }
+};
+
+// assertion kinds, combined as a bit set = conjunction
+enum {A_WB=1, A_NWB=2, A_BOL=4, A_EOL=8, A_BOD=16, A_EOD=32};
+
+enum TreeOp {T_EMPTY, T_SET, T_CAT, T_ALT, T_STAR, T_PLUS, T_OPT, T_ASSERT, T_GROUP};
+struct Tree
+{
+	TreeOp op;
+	ByteSet set;
+	unsigned assertion;
+	unsigned group;
+	std::vector<Tree> kids;
+	Tree() :op(T_EMPTY),assertion(0),group(0){}
+	static Tree leaf( const ByteSet& s) { Tree t; t.op = T_SET; t.set = s; return t; }
+	static Tree node( TreeOp o) { Tree t; t.op = o; return t; }
+	static Tree cat( const std::vector<Tree>& k) { if (k.empty()) return Tree(); if (k.size() == 1) return k[0]; Tree t; t.op = T_CAT; t.kids = k; return t; }
+	static Tree alt( const std::vector<Tree>& k) { if (k.size() == 1) return k[0]; Tree t; t.op = T_ALT; t.kids = k; return t; }
+};
+
+bool isWordChar( unsigned c) { return (c>='0'&&c<='9')||(c>='A'&&c<='Z')||(c>='a'&&c<='z')||c=='_'; }
+
+// ---- UTF-8: code point ranges -> alternatives of byte-range sequences
+int encodeUtf8( uint32_t cp, unsigned char* b)
+{
+	if (cp < 0x80) { b[0] = (unsigned char)cp; return 1; }
+	if (cp < 0x800) { b[0] = (unsigned char)(0xC0 | (cp >> 6)); b[1] = (unsigned char)(0x80 | (cp & 0x3F)); return 2; }
+	if (cp < 0x10000) { b[0] = (unsigned char)(0xE0 | (cp >> 12)); b[1] = (unsigned char)(0x80 | ((cp >> 6) & 0x3F)); b[2] = (unsigned char)(0x80 | (cp & 0x3F)); return 3; }
+	b[0] = (unsigned char)(0xF0 | (cp >> 18)); b[1] = (unsigned char)(0x80 | ((cp >> 12) & 0x3F));
+	b[2] = (unsigned char)(0x80 | ((cp >> 6) & 0x3F)); b[3] = (unsigned char)(0x80 | (cp & 0x3F)); return 4;
+}
+void splitUtf8( uint32_t lo, uint32_t hi, std::vector<Tree>& alts)
+{
+	// cut at encoded-length boundaries, then at continuation-byte boundaries until every byte of the
+	// sequence ranges independently
+	static const uint32_t lenMax[3] = {0x7F, 0x7FF, 0xFFFF};
+	for (int i=0; i<3; ++i)
+	{
+		if (lo <= lenMax[i] && hi > lenMax[i]) { splitUtf8( lo, lenMax[i], alts); splitUtf8( lenMax[i]+1, hi, alts); return; }
+	}
+	if (hi >= 0x80)
+	{
+		for (int i=1; i<=3; ++i)
+		{
+			uint32_t m = (1u << (6*i)) - 1;
+			if ((lo & ~m) != (hi & ~m))
+			{
+				if (lo & m) { splitUtf8( lo, lo|m, alts); splitUtf8( (lo|m)+1, hi, alts); return; }
+				if ((hi & m) != m) { splitUtf8( lo, (hi & ~m)-1, alts); splitUtf8( hi & ~m, hi, alts); return; }
+			}
+		}
+	}
+	unsigned char a[4], b[4];
+	int n = encodeUtf8( lo, a); encodeUtf8( hi, b);
+	std::vector<Tree> seq;
+	for (int i=0; i<n; ++i) { ByteSet s; s.addRange( a[i], b[i]); seq.push_back( Tree::leaf( s)); }
+	alts.push_back( Tree::cat( seq));
+}
+
+// ---- syntax: expression text -> Tree
+class Syntax
+{
+public:
+	Syntax( const std::string& text, unsigned options)
+		:m_text(text),m_at(0),m_caseless((options & LEX_CASELESS)!=0),m_dotall((options & LEX_DOTALL)!=0)
+		,m_multiline((options & LEX_MULTILINE)!=0),m_utf8(true),m_groups(0){}
+
+	Tree run()
+	{
+		Tree t = alternation();
+		if (m_at != m_text.size()) error( "unmatched ')'");
+		return t;
+	}
+	unsigned groups() const {return m_groups;}
+
+private:
+	const std::string& m_text;
+	size_t m_at;
+	bool m_caseless, m_dotall, m_multiline, m_utf8;
+	unsigned m_groups;
+
+	void error( const std::string& what) const { throw std::runtime_error( "failed to compile pattern \"" + m_text + "\": " + what); }
+	bool done() const { return m_at >= m_text.size(); }
+	unsigned char cur() const { return (unsigned char)m_text[ m_at]; }
+	bool lookingAt( char c) const { return !done() && m_text[ m_at] == c; }
+
+	Tree alternation()
+	{
+		std::vector<Tree> branches;
+		branches.push_back( sequence());
+		while (lookingAt( '|')) { ++m_at; branches.push_back( sequence()); }
+		return Tree::alt( branches);
+	}
+	Tree sequence()
+	{
+		std::vector<Tree> items;
+		while (!done() && cur() != '|' && cur() != ')') items.push_back( quantified());
+		return Tree::cat( items);
+	}
+	static Tree repeat( const Tree& x, int lo, int hi)
+	{
+		// x{lo,hi}: lo copies then nested optionals; x{lo,}: lo-1 copies then x+ (x* if lo == 0)
+		std::vector<Tree> seq;
+		if (hi < 0)
+		{
+			for (int i=0; i+1<lo; ++i) seq.push_back( x);
+			Tree r = Tree::node( lo > 0 ? T_PLUS : T_STAR); r.kids.push_back( x);
+			seq.push_back( r);
+			return Tree::cat( seq);
+		}
+		for (int i=0; i<lo; ++i) seq.push_back( x);
+		Tree tail;
+		bool haveTail = false;
+		for (int i=lo; i<hi; ++i)
+		{
+			std::vector<Tree> inner; inner.push_back( x);
+			if (haveTail) inner.push_back( tail);
+			Tree o = Tree::node( T_OPT); o.kids.push_back( Tree::cat( inner));
+			tail = o; haveTail = true;
+		}
+		if (haveTail) seq.push_back( tail);
+		return Tree::cat( seq);
+	}
+	bool bounds( int& lo, int& hi)
+	{
+		size_t p = m_at+1;
+		auto number = [&]( int& v) -> bool {
+			if (p >= m_text.size() || m_text[p] < '0' || m_text[p] > '9') return false;
+			v = 0;
+			while (p < m_text.size() && m_text[p] >= '0' && m_text[p] <= '9') { v = v*10 + (m_text[p]-'0'); if (v > 1000) error( "repeat count too large"); ++p; }
+			return true;
+		};
+		if (!number( lo)) return false;
+		hi = lo;
+		if (p < m_text.size() && m_text[p] == ',')
+		{
+			++p;
+			if (p < m_text.size() && m_text[p] == '}') hi = -1;
+			else if (!number( hi)) return false;
+		}
+		if (p >= m_text.size() || m_text[p] != '}') return false;
+		if (hi >= 0 && hi < lo) error( "repeat bounds out of order");
+		m_at = p+1;
+		return true;
+	}
+	Tree quantified()
+	{
+		Tree x = atom();
+		while (!done())
+		{
+			int lo, hi;
+			if (cur() == '*') { lo = 0; hi = -1; ++m_at; }
+			else if (cur() == '+') { lo = 1; hi = -1; ++m_at; }
+			else if (cur() == '?') { lo = 0; hi = 1; ++m_at; }
+			else if (cur() == '{' && bounds( lo, hi)) {}
+			else break;
+			if (!done() && (cur() == '?' || cur() == '+')) ++m_at;	// lazy/possessive do not change the set of (from,to)
+			if (x.op == T_ASSERT) error( "nothing to repeat");
+			x = repeat( x, lo, hi);
+		}
+		return x;
+	}
+
+	// -- character sets
+	uint32_t topCp() const { return m_utf8 ? 0x10FFFFu : 0xFFu; }
+	static void norm( CpRanges& r)
+	{
+		std::sort( r.begin(), r.end());
+		CpRanges o;
+		for (size_t i=0; i<r.size(); ++i)
+		{
+			if (!o.empty() && r[i].first <= o.back().second + 1) o.back().second = std::max( o.back().second, r[i].second);
+			else o.push_back( r[i]);
+		}
+		r.swap( o);
+	}
+	CpRanges complement( CpRanges r) const
+	{
+		norm( r);
+		CpRanges o; uint32_t at = 0;
+		for (size_t i=0; i<r.size(); ++i) { if (r[i].first > at) o.push_back( std::make_pair( at, r[i].first-1)); at = r[i].second+1; }
+		if (at <= topCp()) o.push_back( std::make_pair( at, topCp()));
+		return o;
+	}
+	void fold( CpRanges& r) const
+	{
+		if (!m_caseless) return;
+		size_t n = r.size();
+		for (size_t i=0; i<n; ++i)
+		{
+			for (uint32_t c='a'; c<='z'; ++c) if (c >= r[i].first && c <= r[i].second) r.push_back( std::make_pair( c-32, c-32));
+			for (uint32_t c='A'; c<='Z'; ++c) if (c >= r[i].first && c <= r[i].second) r.push_back( std::make_pair( c+32, c+32));
+		}
+	}
+	Tree fromRanges( CpRanges r) const
+	{
+		norm( r);
+		if (r.empty()) { ByteSet none; return Tree::leaf( none); }
+		if (!m_utf8 || r.back().second < 0x80)
+		{
+			ByteSet s;
+			for (size_t i=0; i<r.size(); ++i) s.addRange( r[i].first, std::min<uint32_t>( r[i].second, 255));
+			return Tree::leaf( s);
+		}
+		std::vector<Tree> alts;
+		// merge all one-byte alternatives into a single leaf
+		ByteSet ascii; bool haveAscii = false;
+		for (size_t i=0; i<r.size(); ++i)
+		{
+			uint32_t lo = r[i].first, hi = r[i].second;
+			if (lo < 0x80) { ascii.addRange( lo, std::min<uint32_t>( hi, 0x7F)); haveAscii = true; lo = 0x80; }
+			if (lo <= hi) splitUtf8( lo, hi, alts);
+		}
+		if (haveAscii) alts.insert( alts.begin(), Tree::leaf( ascii));
+		return Tree::alt( alts);
+	}
+	static void shorthand( char e, CpRanges& r)
+	{
+		switch (e | 32)
+		{
+			case 'd': r.push_back( std::make_pair( '0','9')); break;
+			case 'w': r.push_back( std::make_pair( '0','9')); r.push_back( std::make_pair( 'A','Z')); r.push_back( std::make_pair( 'a','z')); r.push_back( std::make_pair( '_','_')); break;
+			case 's': r.push_back( std::make_pair( 9, 13)); r.push_back( std::make_pair( ' ',' ')); break;
+		}
+	}
+	uint32_t literalChar()
+	{
+		unsigned char c = cur();
+		if (!m_utf8 || c < 0x80) { ++m_at; return c; }
+		int n = c >= 0xF0 ? 4 : c >= 0xE0 ? 3 : c >= 0xC0 ? 2 : 0;
+		if (!n || m_at + n > m_text.size()) error( "invalid UTF-8 sequence");
+		uint32_t cp = c & (0xFFu >> (n+1));
+		for (int i=1; i<n; ++i) cp = (cp << 6) | ((unsigned char)m_text[ m_at+i] & 0x3F);
+		m_at += n;
+		return cp;
+	}
+	uint32_t escapedChar( unsigned char e)
+	{
+		switch (e)
+		{
+			case 'n': return 10; case 'r': return 13; case 't': return 9; case 'f': return 12; case 'v': return 11;
+			case 'a': return 7; case 'e': return 27; case '0': return 0;
+			case 'x':
+			{
+				uint32_t v = 0;
+				for (int i=0; i<2; ++i)
+				{
+					if (done()) error( "incomplete \\x escape");
+					unsigned char h = cur(); ++m_at;
+					if (h >= '0' && h <= '9') v = v*16 + (h-'0');
+					else if ((h|32) >= 'a' && (h|32) <= 'f') v = v*16 + ((h|32)-'a'+10);
+					else error( "incomplete \\x escape");
+				}
+				return v;
+			}
+		}
+		if ((e >= '0' && e <= '9') || (e >= 'A' && e <= 'Z') || (e >= 'a' && e <= 'z')) error( std::string("unsupported escape \\") + (char)e);
+		return e;
+	}
+	Tree assertNode( unsigned kind) const { Tree t = Tree::node( T_ASSERT); t.assertion = kind; return t; }
+
+	Tree bracket()
+	{
+		++m_at;
+		bool negated = false;
+		if (lookingAt( '^')) { negated = true; ++m_at; }
+		CpRanges r;
+		for (bool first=true;; first=false)
+		{
+			if (done()) error( "missing terminating ]");
+			unsigned char c = cur();
+			if (c == ']' && !first) { ++m_at; break; }
+			if (c == '[' && m_at+1 < m_text.size() && m_text[ m_at+1] == ':')
+			{
+				size_t e = m_text.find( ":]", m_at+2);
+				if (e == std::string::npos) error( "unterminated POSIX class");
+				std::string nm = m_text.substr( m_at+2, e-m_at-2);
+				if (nm == "alpha") { r.push_back( std::make_pair( 'A','Z')); r.push_back( std::make_pair( 'a','z')); }
+				else if (nm == "digit") r.push_back( std::make_pair( '0','9'));
+				else if (nm == "alnum") { r.push_back( std::make_pair( '0','9')); r.push_back( std::make_pair( 'A','Z')); r.push_back( std::make_pair( 'a','z')); }
+				else if (nm == "upper") r.push_back( std::make_pair( 'A','Z'));
+				else if (nm == "lower") r.push_back( std::make_pair( 'a','z'));
+				else if (nm == "space") { r.push_back( std::make_pair( 9,13)); r.push_back( std::make_pair( ' ',' ')); }
+				else if (nm == "punct") { r.push_back( std::make_pair( 33,47)); r.push_back( std::make_pair( 58,64)); r.push_back( std::make_pair( 91,96)); r.push_back( std::make_pair( 123,126)); }
+				else if (nm == "xdigit") { r.push_back( std::make_pair( '0','9')); r.push_back( std::make_pair( 'A','F')); r.push_back( std::make_pair( 'a','f')); }
+				else error( "unknown POSIX class name");
+				m_at = e+2;
+				continue;
+			}
+			uint32_t lo;
+			if (c == '\\')
+			{
+				++m_at;
+				if (done()) error( "\\ at end of pattern");
+				unsigned char e = cur(); ++m_at;
+				if (e=='d'||e=='w'||e=='s') { shorthand( (char)e, r); continue; }
+				if (e=='D'||e=='W'||e=='S') { CpRanges t; shorthand( (char)e, t); t = complement( t); r.insert( r.end(), t.begin(), t.end()); continue; }
+				lo = (e == 'b') ? 8 : escapedChar( e);
+			}
+			else lo = literalChar();
+			uint32_t hi = lo;
+			if (m_at+1 < m_text.size() && cur() == '-' && m_text[ m_at+1] != ']')
+			{
+				++m_at;
+				if (cur() == '\\') { ++m_at; if (done()) error( "\\ at end of pattern"); unsigned char e = cur(); ++m_at; hi = escapedChar( e); }
+				else hi = literalChar();
+				if (hi < lo) error( "range out of order in character class");
+			}
+			r.push_back( std::make_pair( lo, hi));
+		}
+		fold( r);
+		return fromRanges( negated ? complement( r) : r);
+	}
+
+	Tree atom()
+	{
+		unsigned char c = cur();
+		if (c == '(')
+		{
+			++m_at;
+			unsigned g = 0;
+			if (lookingAt( '?'))
+			{
+				if (m_at+1 < m_text.size() && m_text[ m_at+1] == ':') m_at += 2;
+				else error( "unsupported group syntax (?...)");
+			}
+			else g = ++m_groups;
+			Tree inner = alternation();
+			if (!lookingAt( ')')) error( "missing )");
+			++m_at;
+			Tree t = Tree::node( T_GROUP); t.group = g; t.kids.push_back( inner);
+			return t;
+		}
+		if (c == '[') return bracket();
+		if (c == '.')
+		{
+			++m_at;
+			CpRanges r;
+			if (m_dotall) r.push_back( std::make_pair( 0u, topCp()));
+			else { r.push_back( std::make_pair( 0u, 9u)); r.push_back( std::make_pair( 11u, topCp())); }
+			return fromRanges( r);
+		}
+		if (c == '^') { ++m_at; return assertNode( m_multiline ? A_BOL : A_BOD); }
+		if (c == '$') { ++m_at; return assertNode( m_multiline ? A_EOL : A_EOD); }
+		if (c == '*' || c == '+' || c == '?') error( "nothing to repeat");
+		if (c == ')') error( "unmatched ')'");
+		if (c == '\\')
+		{
+			++m_at;
+			if (done()) error( "\\ at end of pattern");
+			unsigned char e = cur(); ++m_at;
+			switch (e)
+			{
+				case 'b': return assertNode( A_WB);
+				case 'B': return assertNode( A_NWB);
+				case 'A': return assertNode( A_BOD);
+				case 'z': return assertNode( A_EOD);
+				case 'd': case 'w': case 's': { CpRanges r; shorthand( (char)e, r); return fromRanges( r); }
+				case 'D': case 'W': case 'S': { CpRanges r; shorthand( (char)e, r); return fromRanges( complement( r)); }
+				case 'p': case 'P': error( "unicode properties need UCP, which is not supported");
+			}
+			CpRanges r; uint32_t v = escapedChar( e); r.push_back( std::make_pair( v, v));
+			fold( r);
+			return fromRanges( r);
+		}
+		CpRanges r; uint32_t v = literalChar(); r.push_back( std::make_pair( v, v));
+		fold( r);
+		return fromRanges( r);
+	}
+};
+
+// ---- fixed length of a subtree in bytes, or -1
+int fixedLength( const Tree& t)
+{
+	switch (t.op)
+	{
+		case T_EMPTY: case T_ASSERT: return 0;
+		case T_SET: return 1;
+		case T_GROUP: return fixedLength( t.kids[0]);
+		case T_CAT: { int s = 0; for (size_t i=0; i<t.kids.size(); ++i) { int l = fixedLength( t.kids[i]); if (l < 0) return -1; s += l; } return s; }
+		case T_ALT: { int s = -2; for (size_t i=0; i<t.kids.size(); ++i) { int l = fixedLength( t.kids[i]); if (l < 0 || (s != -2 && s != l)) return -1; s = l; } return s; }
+		default: return -1;
+	}
+}
+// locate capture group g below concatenations/groups only and sum the fixed lengths around it
+bool groupContext( const Tree& t, unsigned g, int& before, int& after)
+{
+	if (t.op == T_GROUP) return t.group == g ? true : groupContext( t.kids[0], g, before, after);
+	if (t.op != T_CAT) return false;
+	for (size_t i=0; i<t.kids.size(); ++i)
+	{
+		int b = 0, a = 0;
+		if (!groupContext( t.kids[i], g, b, a)) continue;
+		for (size_t k=0; k<i; ++k) { int l = fixedLength( t.kids[k]); if (l < 0) return false; b += l; }
+		for (size_t k=i+1; k<t.kids.size(); ++k) { int l = fixedLength( t.kids[k]); if (l < 0) return false; a += l; }
+		before += b; after += a;
+		return true;
+	}
+	return false;
+}
+
+// ---- Glushkov construction with assertion-carrying set members
+typedef std::pair<uint32_t,unsigned> Member;		// (position, assertions crossed)
+struct Sets { std::vector<unsigned> nullable; std::vector<Member> first, last; };
+struct Edge { uint32_t from, to; unsigned cond; };
+
+struct Glushkov
+{
+	std::vector<ByteSet> positions;
+	std::vector<Edge> edges;
+
+	static void uniq( std::vector<Member>& v) { std::sort( v.begin(), v.end()); v.erase( std::unique( v.begin(), v.end()), v.end()); }
+	static void uniqN( std::vector<unsigned>& v)
+	{
+		std::sort( v.begin(), v.end()); v.erase( std::unique( v.begin(), v.end()), v.end());
+		if (!v.empty() && v[0] == 0) v.resize( 1);	// unconditional dominates
+	}
+	void link( const std::vector<Member>& from, const std::vector<Member>& to)
+	{
+		for (size_t i=0; i<from.size(); ++i) for (size_t k=0; k<to.size(); ++k)
+		{
+			Edge e = { from[i].first, to[k].first, from[i].second | to[k].second };
+			edges.push_back( e);
+		}
+	}
+	Sets build( const Tree& t)
+	{
+		Sets s;
+		switch (t.op)
+		{
+			case T_EMPTY: s.nullable.push_back( 0); break;
+			case T_ASSERT: s.nullable.push_back( t.assertion); break;
+			case T_SET:
+			{
+				if (t.set.empty()) break;		// matches nothing
+				uint32_t p = (uint32_t)positions.size(); positions.push_back( t.set);
+				s.first.push_back( Member( p, 0)); s.last.push_back( Member( p, 0));
+				break;
+			}
+			case T_GROUP: return build( t.kids[0]);
+			case T_ALT:
+				for (size_t i=0; i<t.kids.size(); ++i)
+				{
+					Sets k = build( t.kids[i]);
+					s.nullable.insert( s.nullable.end(), k.nullable.begin(), k.nullable.end());
+					s.first.insert( s.first.end(), k.first.begin(), k.first.end());
+					s.last.insert( s.last.end(), k.last.begin(), k.last.end());
+				}
+				break;
+			case T_CAT:
+			{
+				s.nullable.push_back( 0);
+				for (size_t i=0; i<t.kids.size(); ++i)
+				{
+					Sets k = build( t.kids[i]);
+					link( s.last, k.first);
+					// first: extend while everything so far is nullable
+					std::vector<Member> nf = s.first;
+					for (size_t n=0; n<s.nullable.size(); ++n) for (size_t f=0; f<k.first.size(); ++f)
+						nf.push_back( Member( k.first[f].first, k.first[f].second | s.nullable[n]));
+					// last: the child's last, plus ours carried over the child's nullability
+					std::vector<Member> nl = k.last;
+					for (size_t n=0; n<k.nullable.size(); ++n) for (size_t l=0; l<s.last.size(); ++l)
+						nl.push_back( Member( s.last[l].first, s.last[l].second | k.nullable[n]));
+					std::vector<unsigned> nn;
+					for (size_t a=0; a<s.nullable.size(); ++a) for (size_t b=0; b<k.nullable.size(); ++b) nn.push_back( s.nullable[a] | k.nullable[b]);
+					s.first.swap( nf); s.last.swap( nl); s.nullable.swap( nn);
+					uniq( s.first); uniq( s.last); uniqN( s.nullable);
+				}
+				break;
+			}
+			case T_STAR: case T_PLUS: case T_OPT:
+			{
+				s = build( t.kids[0]);
+				if (t.op != T_OPT) link( s.last, s.first);
+				if (t.op != T_PLUS) s.nullable.push_back( 0);
+				break;
+			}
+		}
+		uniq( s.first); uniq( s.last); uniqN( s.nullable);
+		return s;
+	}
+};
+
+int ctxOfByte( unsigned c) { return c == '\n' ? CTX_NEWLINE : isWordChar( c) ? CTX_WORD : CTX_OTHER; }
+bool ctxIsWord( int ctx) { return ctx == CTX_WORD; }
+// does the conjunction `cond` hold between a byte of context `prev` and one of context `next`?
+bool condHolds( unsigned cond, int prev, int next)
+{
+	if ((cond & A_WB) && ctxIsWord( prev) == ctxIsWord( next)) return false;
+	if ((cond & A_NWB) && ctxIsWord( prev) != ctxIsWord( next)) return false;
+	if ((cond & A_BOL) && !(prev == CTX_EDGE || prev == CTX_NEWLINE)) return false;
+	if ((cond & A_EOL) && !(next == CTX_EDGE || next == CTX_NEWLINE)) return false;
+	if ((cond & A_BOD) && prev != CTX_EDGE) return false;
+	if ((cond & A_EOD) && next != CTX_EDGE) return false;
+	return true;
+}
+
+// one compiled pattern in its own bit space (bit i = position i)
+struct Automaton
+{
+	std::vector<ByteSet> pos;		// byte set per position
+	std::vector<uint64_t> follow;		// follow[i] = successors of position i
+	uint64_t start[ CTX_COUNT];		// positions a match may begin with, by context of the byte before
+	uint64_t accept[ CTX_COUNT];		// positions a match may end with, by context of the byte after
+};
+
+Automaton makeAutomaton( const Tree& tree, const std::string& exprForError)
+{
+	Glushkov g;
+	Sets root = g.build( tree);
+	const size_t n0 = g.positions.size();
+	// which positions touch an assertion
+	std::vector<char> touched( n0, 0);
+	for (size_t i=0; i<g.edges.size(); ++i) if (g.edges[i].cond) { touched[ g.edges[i].from] = 1; touched[ g.edges[i].to] = 1; }
+	for (size_t i=0; i<root.first.size(); ++i) if (root.first[i].second) touched[ root.first[i].first] = 1;
+	for (size_t i=0; i<root.last.size(); ++i) if (root.last[i].second) touched[ root.last[i].first] = 1;
+	// split touched positions by context class so that their context is definite
+	Automaton a;
+	std::vector<std::vector<uint32_t> > parts( n0);	// old position -> new positions
+	std::vector<int> ctxOf;				// new position -> definite context or -1
+	for (size_t p=0; p<n0; ++p)
+	{
+		if (!touched[ p])
+		{
+			parts[ p].push_back( (uint32_t)a.pos.size()); a.pos.push_back( g.positions[ p]); ctxOf.push_back( -1);
+			continue;
+		}
+		ByteSet byCtx[3];
+		for (unsigned c=0; c<256; ++c) if (g.positions[ p].has( c)) byCtx[ ctxOfByte( c)].add( c);
+		for (int k=0; k<3; ++k) if (!byCtx[k].empty())
+		{
+			parts[ p].push_back( (uint32_t)a.pos.size()); a.pos.push_back( byCtx[k]); ctxOf.push_back( k);
+		}
+	}
+	if (a.pos.size() > 64)
+	{
+		throw std::runtime_error( "failed to compile pattern \"" + exprForError + "\": expression too complex (more than 64 byte positions)");
+	}
+	a.follow.assign( a.pos.size(), 0);
+	for (int c=0; c<CTX_COUNT; ++c) { a.start[c] = 0; a.accept[c] = 0; }
+	for (size_t i=0; i<g.edges.size(); ++i)
+	{
+		const Edge& e = g.edges[i];
+		for (size_t x=0; x<parts[ e.from].size(); ++x) for (size_t y=0; y<parts[ e.to].size(); ++y)
+		{
+			uint32_t pf = parts[ e.from][x], pt = parts[ e.to][y];
+			if (e.cond == 0 || condHolds( e.cond, ctxOf[ pf], ctxOf[ pt])) a.follow[ pf] |= (1ull << pt);
+		}
+	}
+	for (size_t i=0; i<root.first.size(); ++i)
+	{
+		const std::vector<uint32_t>& ps = parts[ root.first[i].first];
+		for (size_t x=0; x<ps.size(); ++x) for (int prev=0; prev<CTX_COUNT; ++prev)
+		{
+			if (root.first[i].second == 0 || condHolds( root.first[i].second, prev, ctxOf[ ps[x]])) a.start[ prev] |= (1ull << ps[x]);
+		}
+	}
+	for (size_t i=0; i<root.last.size(); ++i)
+	{
+		const std::vector<uint32_t>& ps = parts[ root.last[i].first];
+		for (size_t x=0; x<ps.size(); ++x) for (int next=0; next<CTX_COUNT; ++next)
+		{
+			if (root.last[i].second == 0 || condHolds( root.last[i].second, ctxOf[ ps[x]], next)) a.accept[ next] |= (1ull << ps[x]);
+		}
+	}
+	return a;
+}
+
+bool sameNoCase( const std::string& a, const char* b)
+{
+	size_t n = std::strlen( b);
+	if (a.size() != n) return false;
+	for (size_t i=0; i<n; ++i) { char x = a[i], y = b[i]; if (x>='a'&&x<='z') x -= 32; if (y>='a'&&y<='z') y -= 32; if (x != y) return false; }
+	return true;
+}
+
+// src/patternLexer.cpp:605-626: a trailing "~<digits>" is the edit distance
+unsigned cutEditDistance( std::string& expr)
+{
+	size_t e = expr.size();
+	while (e > 0 && (unsigned char)expr[e-1] <= 32) --e;
+	size_t d = e;
+	while (d > 0 && expr[d-1] >= '0' && expr[d-1] <= '9') --d;
+	if (d == e) return 0;
+	size_t t = d;
+	while (t > 0 && (unsigned char)expr[t-1] <= 32) --t;
+	if (t == 0 || expr[t-1] != '~') return 0;
+	unsigned dist = (unsigned)atoi( expr.c_str() + d);
+	--t;
+	while (t > 0 && (unsigned char)expr[t-1] <= 32) --t;
+	expr.resize( t);
+	return dist;
+}
+
+} // namespace
+
+// src/patternLexer.cpp:971-988
+void LexCompiler::defineLexemName( uint32_t id, const std::string& name)
+{
+	if (m_names.count( id)) throw std::runtime_error( "duplicate definition");
+	m_names[ id] = name;
+}
+const char* LexCompiler::getLexemName( uint32_t id) const
+{
+	std::map<uint32_t,std::string>::const_iterator it = m_names.find( id);
+	return it == m_names.end() ? 0 : it->second.c_str();
+}
+
+// src/patternLexer.cpp:990-1006, :245-262, limits :76-99
+void LexCompiler::defineLexem( uint32_t id, const std::string& expression, uint32_t resultIndex, uint32_t level, int posbind)
+{
+	if (m_compiled) throw std::runtime_error( "called define pattern after calling 'compile'");
+	if (id > (1u<<30)-1) throw std::runtime_error( "pattern id out of range, It must be a positive integer in the range 1..1073741823");
+	if (level > 255) throw std::runtime_error( "level out of range, It must be a positive integer in the range 1..255");
+	if (resultIndex > 255) throw std::runtime_error( "result index out of range, It must be a positive integer in the range 1..255");
+	if (posbind < 0 || posbind > 3) throw std::runtime_error( "unknown position bind value");
+	Def d; d.expression = expression; d.editdist = cutEditDistance( d.expression);
+	if (d.editdist > 255) throw std::runtime_error( "edit distance out of range, It must be a positive integer in the range 1..255");
+	d.id = id; d.resultIndex = resultIndex; d.level = level; d.posbind = posbind;
+	m_defs.push_back( d);
+}
+
+// src/patternLexer.cpp:1008-1019, :264-293
+void LexCompiler::defineSymbol( uint32_t symbolid, uint32_t patternid, const std::string& name)
+{
+	if (m_compiled) throw std::runtime_error( "called define pattern after calling 'compile'");
+	if (patternid > (1u<<30)-1 || symbolid > (1u<<30)-1) throw std::runtime_error( "symbol or pattern id out of range");
+	std::map<std::string,uint32_t>& tab = m_symbols[ patternid];
+	if (m_symbols.size() > 255) throw std::runtime_error( "too many pattern symbol tables defined");	// :440-445
+	if (tab.count( name)) throw std::runtime_error( "symbol defined twice: '" + name + "'");
+	tab[ name] = symbolid;
+}
+
+// src/patternLexer.cpp:1020-1029, :295-310
+uint32_t LexCompiler::getSymbol( uint32_t patternid, const std::string& name) const
+{
+	std::map<uint32_t, std::map<std::string,uint32_t> >::const_iterator t = m_symbols.find( patternid);
+	if (t == m_symbols.end()) return 0;
+	std::map<std::string,uint32_t>::const_iterator s = t->second.find( name);
+	return s == t->second.end() ? 0 : s->second;
+}
+
+// src/patternLexer.cpp:1031-1066
+void LexCompiler::defineOption( const std::string& name, double)
+{
+	if (sameNoCase( name, "CASELESS")) m_options |= LEX_CASELESS;
+	else if (sameNoCase( name, "DOTALL")) m_options |= LEX_DOTALL;
+	else if (sameNoCase( name, "MULTILINE")) m_options |= LEX_MULTILINE;
+	else if (sameNoCase( name, "ALLOWEMPTY")) m_options |= LEX_ALLOWEMPTY;
+	else if (sameNoCase( name, "UCP")) m_options |= LEX_UCP;
+	else if (sameNoCase( name, "BYTECHAR")) m_options |= LEX_BYTECHAR;
+	else throw std::runtime_error( "unknown option '" + name + "'");
+}
+
+// src/patternLexer.cpp:1068-1118 (+ PatternTable::complete :333-412)
+void LexCompiler::compile()
+{
+	if (m_options & LEX_UCP) throw std::runtime_error( "option UCP is not supported by this lexer");
+	if (m_options & LEX_BYTECHAR) throw std::runtime_error( "option BYTECHAR (one byte character map) is not supported by this lexer yet");
+	if (m_options & LEX_ALLOWEMPTY) throw std::runtime_error( "option ALLOWEMPTY is not supported by this lexer");
+	LexTables& T = m_tables;
+	T = LexTables();
+
+	// 1. per pattern automata
+	std::vector<Automaton> autos;
+	T.patterns.clear();
+	for (size_t di=0; di<m_defs.size(); ++di)
+	{
+		const Def& d = m_defs[ di];
+		if (d.editdist) throw std::runtime_error( "failed to compile pattern \"" + d.expression + "\": approximate matching (~N) is not supported by this lexer yet");
+		Syntax syn( d.expression, m_options);
+		Tree tree = syn.run();
+		DevLexPattern dp; std::memset( &dp, 0, sizeof(dp));
+		dp.id = d.id;
+		dp.levelBind = (d.level & 0xFF) | ((uint32_t)d.posbind << 8);
+		if (d.resultIndex)
+		{
+			int before = 0, after = 0;
+			if (d.resultIndex > syn.groups() || !groupContext( tree, d.resultIndex, before, after))
+			{
+				throw std::runtime_error( "failed to compile pattern \"" + d.expression + "\": selecting a sub expression needs fixed-length context around the group in this lexer");
+			}
+			dp.prefixLen = (uint32_t)before; dp.suffixLen = (uint32_t)after;
+			dp.levelBind |= (1u << 17);
+		}
+		if (m_symbols.count( d.id)) dp.levelBind |= (1u << 16);
+		T.patterns.push_back( dp);
+		autos.push_back( makeAutomaton( tree, d.expression));
+	}
+
+	// 2. layout: patterns in definition order, never straddling a 64-bit word (report order for equal
+	//    end offsets is ascending pattern index = ascending (pass, lane, bit))
+	std::vector<uint32_t> bitBase( autos.size(), 0);
+	uint32_t word = 0, used = 0;
+	T.wordPatBegin.clear(); T.wordPats.clear();
+	T.wordPatBegin.push_back( 0);
+	T.nofPositions = 0;
+	for (size_t pi=0; pi<autos.size(); ++pi)
+	{
+		uint32_t n = (uint32_t)autos[ pi].pos.size();
+		T.nofPositions += n;
+		if (used + n > 64) { ++word; used = 0; T.wordPatBegin.push_back( (uint32_t)T.wordPats.size()); }
+		bitBase[ pi] = used;
+		T.patterns[ pi].word = word;
+		uint64_t mask = n == 64 ? ~0ull : (((1ull << n) - 1) << used);
+		T.patterns[ pi].maskLo = (uint32_t)mask; T.patterns[ pi].maskHi = (uint32_t)(mask >> 32);
+		T.wordPats.push_back( (uint32_t)pi);
+		used += n;
+	}
+	uint32_t nwords = autos.empty() ? 0 : word+1;
+	T.nofPasses = (nwords + L1_WORDS_PER_PASS-1) / L1_WORDS_PER_PASS;
+	if (T.nofPasses == 0) T.nofPasses = 1;
+	const uint32_t totalWords = T.nofPasses * L1_WORDS_PER_PASS;
+	while (T.wordPatBegin.size() < totalWords+1) T.wordPatBegin.push_back( (uint32_t)T.wordPats.size());
+
+	// 3. byte classes: bytes that no position distinguishes (and that share a context) are one class
+	{
+		std::vector<uint64_t> sig( 256, 1469598103934665603ull);
+		uint32_t gp = 0;
+		for (size_t pi=0; pi<autos.size(); ++pi) for (size_t k=0; k<autos[ pi].pos.size(); ++k, ++gp)
+		{
+			for (unsigned c=0; c<256; ++c) if (autos[ pi].pos[k].has( c)) sig[ c] = (sig[ c] ^ (gp+1)) * 1099511628211ull + 0x9E3779B97F4A7C15ull;
+		}
+		std::map<std::pair<uint64_t,int>,uint32_t> classOf;
+		T.byteClass.assign( 256, 0); T.classCtx.clear();
+		for (unsigned c=0; c<256; ++c)
+		{
+			std::pair<uint64_t,int> key( sig[ c], ctxOfByte( c));
+			std::map<std::pair<uint64_t,int>,uint32_t>::const_iterator it = classOf.find( key);
+			uint32_t cls;
+			if (it == classOf.end())
+			{
+				cls = (uint32_t)classOf.size();
+				if (cls > 255) throw std::runtime_error( "too many distinct byte classes");
+				classOf[ key] = cls; T.classCtx.push_back( (uint8_t)key.second);
+			}
+			else cls = it->second;
+			T.byteClass[ c] = (uint8_t)cls;
+		}
+		T.nofClasses = (uint32_t)classOf.size();
+	}
+
+	// 4. masks
+	T.charMask.assign( (size_t)T.nofPasses * T.nofClasses * 64, 0);
+	T.startMask.assign( (size_t)T.nofPasses * CTX_COUNT * 64, 0);
+	T.acceptMask.assign( (size_t)T.nofPasses * CTX_COUNT * 64, 0);
+	T.shiftDst.assign( (size_t)T.nofPasses * 64, 0);
+	T.selfLoop.assign( (size_t)T.nofPasses * 64, 0);
+	std::vector<std::map<uint64_t,uint64_t> > exOfWord( totalWords);	// dst set -> src set
+	std::vector<unsigned char> repOfClass( T.nofClasses, 0);
+	for (unsigned c=256; c-->0;) repOfClass[ T.byteClass[ c]] = (unsigned char)c;
+	for (size_t pi=0; pi<autos.size(); ++pi)
+	{
+		const Automaton& a = autos[ pi];
+		const uint32_t w = T.patterns[ pi].word, base = bitBase[ pi];
+		const uint32_t pass = w / 64, lane = w % 64;
+		const uint32_t n = (uint32_t)a.pos.size();
+		for (uint32_t k=0; k<n; ++k)
+		{
+			for (uint32_t cls=0; cls<T.nofClasses; ++cls)
+			{
+				if (a.pos[k].has( repOfClass[ cls])) T.charMask[ ((size_t)pass*T.nofClasses + cls)*64 + lane] |= 1ull << (base+k);
+			}
+			uint64_t f = a.follow[ k];
+			if (f & (1ull << k)) { T.selfLoop[ pass*64 + lane] |= 1ull << (base+k); f &= ~(1ull << k); }
+			if (k+1 < n && (f & (1ull << (k+1)))) { T.shiftDst[ pass*64 + lane] |= 1ull << (base+k+1); f &= ~(1ull << (k+1)); }
+			if (f) exOfWord[ w][ f << base] |= 1ull << (base+k);
+		}
+		for (int c=0; c<CTX_COUNT; ++c)
+		{
+			T.startMask[ ((size_t)pass*CTX_COUNT + c)*64 + lane] |= a.start[ c] << base;
+			T.acceptMask[ ((size_t)pass*CTX_COUNT + c)*64 + lane] |= a.accept[ c] << base;
+		}
+	}
+	T.maxExceptions = 0;
+	T.exCount.assign( T.nofPasses, 0);
+	for (uint32_t w=0; w<totalWords; ++w)
+	{
+		uint32_t n = (uint32_t)exOfWord[ w].size();
+		if (n > T.exCount[ w/64]) T.exCount[ w/64] = n;
+		if (n > T.maxExceptions) T.maxExceptions = n;
+	}
+	T.exSrc.assign( (size_t)T.nofPasses * (T.maxExceptions ? T.maxExceptions : 1) * 64, 0);
+	T.exDst.assign( T.exSrc.size(), 0);
+	for (uint32_t w=0; w<totalWords; ++w)
+	{
+		uint32_t e = 0;
+		for (std::map<uint64_t,uint64_t>::const_iterator it=exOfWord[ w].begin(); it!=exOfWord[ w].end(); ++it, ++e)
+		{
+			size_t at = ((size_t)(w/64) * (T.maxExceptions ? T.maxExceptions : 1) + e)*64 + (w%64);
+			T.exDst[ at] = it->first; T.exSrc[ at] = it->second;
+		}
+	}
+
+	// 5. symbols: one hash table keyed by (lexem id, text)
+	{
+		size_t count = 0;
+		for (std::map<uint32_t, std::map<std::string,uint32_t> >::const_iterator t=m_symbols.begin(); t!=m_symbols.end(); ++t) count += t->second.size();
+		size_t size = 1;
+		while (size < count*2+1) size <<= 1;
+		DevSymbol none; std::memset( &none, 0, sizeof(none));
+		T.symbols.assign( size, none);
+		T.symbolText.clear();
+		for (std::map<uint32_t, std::map<std::string,uint32_t> >::const_iterator t=m_symbols.begin(); t!=m_symbols.end(); ++t)
+		{
+			for (std::map<std::string,uint32_t>::const_iterator s=t->second.begin(); s!=t->second.end(); ++s)
+			{
+				uint32_t h = 2166136261u;
+				for (int b=0; b<4; ++b) h = symbolHashStep( h, (t->first >> (8*b)) & 0xFF);
+				for (size_t k=0; k<s->first.size(); ++k) h = symbolHashStep( h, (unsigned char)s->first[k]);
+				if (!h) h = 1;
+				DevSymbol e; std::memset( &e, 0, sizeof(e));
+				e.hash = h; e.lexemId = t->first; e.textOffset = (uint32_t)T.symbolText.size(); e.len = (uint32_t)s->first.size(); e.symbolId = s->second;
+				T.symbolText.insert( T.symbolText.end(), s->first.begin(), s->first.end());
+				size_t slot = h & (size-1);
+				while (T.symbols[ slot].hash) slot = (slot+1) & (size-1);
+				T.symbols[ slot] = e;
+			}
+		}
+		if (T.symbolText.empty()) T.symbolText.push_back( 0);
+	}
+	m_compiled = true;
+}

@@ -1,0 +1,73 @@
+// Level-1 lexer compiler (host side of the product): regular expressions -> bit-parallel position
+// automaton tables for the HIP lexer kernel.  Replaces PatternTable + hs_compile_ext_multi of the
+// reference (src/patternLexer.cpp:231-649, :1068-1118); Hyperscan itself is not used.
+#ifndef SPA_L1_COMPILE_HPP
+#define SPA_L1_COMPILE_HPP
+#include <stdint.h>
+#include <cstddef>
+#include <map>
+#include <string>
+#include <vector>
+#include "l1_tables.h"
+
+namespace spa {
+
+enum {LEX_CASELESS=1, LEX_DOTALL=2, LEX_MULTILINE=4, LEX_ALLOWEMPTY=8, LEX_UCP=16, LEX_BYTECHAR=32};
+
+struct LexTables
+{
+	uint32_t nofPasses;
+	uint32_t nofClasses;
+	uint32_t maxExceptions;			// per word, over all passes
+	std::vector<uint8_t> byteClass;		// 256 -> class id
+	std::vector<uint8_t> classCtx;		// class id -> CTX_*
+	std::vector<uint64_t> charMask;		// [pass][class][64]
+	std::vector<uint64_t> startMask;	// [pass][CTX_COUNT][64]
+	std::vector<uint64_t> acceptMask;	// [pass][CTX_COUNT][64]
+	std::vector<uint64_t> shiftDst;		// [pass][64]
+	std::vector<uint64_t> selfLoop;		// [pass][64]
+	std::vector<uint32_t> exCount;		// [pass]: exception entries used by the widest word of the pass
+	std::vector<uint64_t> exSrc;		// [pass][maxExceptions][64]
+	std::vector<uint64_t> exDst;		// [pass][maxExceptions][64]
+	std::vector<uint32_t> wordPatBegin;	// [nofPasses*64+1] -> wordPats
+	std::vector<uint32_t> wordPats;		// pattern indices (0-based) per word, ascending
+	std::vector<DevLexPattern> patterns;
+	std::vector<DevSymbol> symbols;		// power-of-two size (>=1)
+	std::vector<uint8_t> symbolText;
+	uint32_t nofPositions;
+};
+
+class LexCompiler
+{
+public:
+	LexCompiler() :m_options(0),m_compiled(false){}
+
+	// PatternLexerInstanceInterface (src/patternLexer.cpp:971-1141); throw std::runtime_error
+	void defineLexemName( uint32_t id, const std::string& name);
+	const char* getLexemName( uint32_t id) const;
+	void defineLexem( uint32_t id, const std::string& expression, uint32_t resultIndex, uint32_t level, int posbind);
+	void defineSymbol( uint32_t symbolid, uint32_t patternid, const std::string& name);
+	uint32_t getSymbol( uint32_t patternid, const std::string& name) const;
+	void defineOption( const std::string& name, double value);
+	void compile();
+	bool compiled() const			{return m_compiled;}
+	const LexTables& tables() const		{return m_tables;}
+	size_t nofPatterns() const		{return m_defs.size();}
+
+private:
+	struct Def
+	{
+		std::string expression;
+		uint32_t id, resultIndex, level, editdist;
+		int posbind;
+	};
+	std::vector<Def> m_defs;
+	std::map<uint32_t, std::map<std::string,uint32_t> > m_symbols;
+	std::map<uint32_t,std::string> m_names;
+	unsigned m_options;
+	bool m_compiled;
+	LexTables m_tables;
+};
+
+} // namespace
+#endif

@@ -1,0 +1,49 @@
+// Launch parameters of the level-1 lexer kernel (shared by l1_kernel.hip and capi_l1.cpp).
+#ifndef SPA_L1_DEVICE_H
+#define SPA_L1_DEVICE_H
+#include <stdint.h>
+#include "l1_tables.h"
+
+namespace spa {
+
+enum {L1C_LEXEMS=0, L1C_BYTES=1, L1C_RAW=2, L1C_FAILED=3, L1C_COUNT=8};
+
+struct L1Params
+{
+	// compiled tables (read only)
+	const uint8_t* byteClass;	// 256
+	const uint8_t* classCtx;	// nofClasses
+	const uint64_t* charMask;	// [pass][class][64]
+	const uint64_t* startMask;	// [pass][4][64]
+	const uint64_t* acceptMask;	// [pass][4][64]
+	const uint64_t* shiftDst;	// [pass][64]
+	const uint64_t* selfLoop;	// [pass][64]
+	const uint64_t* exSrc;		// [pass][maxExceptions][64]
+	const uint64_t* exDst;
+	const uint32_t* exCount;	// [pass]
+	const uint32_t* wordPatBegin;
+	const uint32_t* wordPats;
+	const DevLexPattern* patterns;
+	const DevSymbol* symbols;
+	const uint8_t* symbolText;
+	uint32_t symbolMask;
+	uint32_t nofPasses, nofClasses, maxExceptions, nofPatterns;
+	// input
+	const uint8_t* text;		// all documents back to back
+	const uint64_t* docOffsets;	// ndocs+1 byte offsets
+	uint32_t ndocs;
+	// per-wave working memory
+	uint32_t* arenaBase;
+	uint64_t arenaWords;		// words per wave
+	uint32_t queueCap;		// raw-match queue records (4 words each)
+	uint32_t eventCap;		// event array records (4 words each)
+	// output
+	uint64_t* counters;		// L1C_*
+	uint32_t* lexems;		// sp_lexem_t[lexemCapacity]
+	uint64_t lexemCapacity;
+	uint64_t* docRange;		// ndocs x (first lexem, count)
+	int32_t* docStatus;		// ndocs
+};
+
+} // namespace
+#endif

@@ -1,0 +1,441 @@
+// Level-1 pattern lexer on gfx950: one wavefront per document, one 64-bit automaton word per lane.
+//
+// What it replaces (reference, CPU): hs_scan (Intel Hyperscan, src/patternLexer.cpp:875-879), the
+// per-match callback PatternLexerContext::match_event_handler (:717-826) and the ordinal-position
+// pass of PatternLexerContext::match (:893-945).
+//
+// Stages per document, fused in one kernel so that raw matches never leave the wave's arena:
+//  1. SCAN   bit-parallel position automaton (tables: l1_tables.h).  Lane l owns word l of every
+//            pass; the document byte is wave-uniform, the table row of its byte class is one
+//            coalesced 512-byte read; a report is detected with one __ballot per pass and byte.
+//            Reports are appended to a queue in (end offset, pattern index) order = the order in
+//            which the reference's handler is called.
+//  2. SOM    start of match: one lane per queued report runs the pattern's automaton BACKWARDS from
+//            the end offset (predecessor sets from the same shift/self/exception tables) and keeps
+//            the smallest offset at which a start position is live = leftmost start.
+//  3. HANDLER the reference's supersede / ignore / sorted-insert logic, executed in report order on
+//            the wave's event array (wave-uniform control flow, scalarised loads).
+//  4. ORDPOS ordinal positions and the output records, once per document.
+// Integer/byte work, HBM-streaming input: no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "l1_tables.h"
+#include "l1_device.h"
+
+using namespace spa;
+
+namespace {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define LANE ((u32)(threadIdx.x & 63u))
+
+enum {L1D_OK=0, L1D_ERR_ARENA=2, L1D_ERR_LEXEMSIZE=7, L1D_ERR_INTERNAL=8, L1D_ERR_OUTPUT=9};
+
+__device__ __forceinline__ u32 uni( u32 v) { return __builtin_amdgcn_readfirstlane( v); }
+__device__ __forceinline__ u32 ldu( const u32* p) { return __builtin_amdgcn_readfirstlane( *p); }
+
+struct Event { u32 id, origpos, origsize, levelBind; };	// levelBind = level | posbind<<8   (MatchEvent, patternLexer.cpp:665-679)
+
+struct LexWave
+{
+	u32* queue;		// raw reports: 4 words {to, pattern, accLo, accHi}; after SOM word 2 holds `from`
+	Event* events;
+	u32 nQueue, nEvents, err;
+	const unsigned char* doc;
+	u32 docLen;
+};
+
+__device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* doc, u32 len, long pos)
+{
+	if (pos < 0 || pos >= (long)len) return CTX_EDGE;
+	return P.classCtx[ P.byteClass[ doc[ pos]]];
+}
+
+// ---------------------------------------------------------------- stage 2: leftmost start per report
+// lane-parallel: lane i resolves report base+i
+__device__ void resolveStarts( LexWave& w, const L1Params& P, u32 base, u32 count)
+{
+	u32 i = base + LANE;
+	if (LANE < count)
+	{
+		u32* q = w.queue + 4*(u64)i;
+		u32 to = q[0], pi = q[1];
+		u64 R = ((u64)q[3] << 32) | q[2];
+		const DevLexPattern pat = P.patterns[ pi];
+		const u32 pass = pat.word >> 6, ln = pat.word & 63u;
+		const u64 mask = ((u64)pat.maskHi << 32) | pat.maskLo;
+		const u64 shiftDst = P.shiftDst[ pass*64 + ln], selfLoop = P.selfLoop[ pass*64 + ln];
+		const u32 nEx = P.exCount[ pass];
+		u32 from = to;
+		long j = (long)to;			// R = positions that consumed byte j-1
+		while (R && j > 0)
+		{
+			int prevctx = ctxAt( P, w.doc, w.docLen, j-2);
+			if (R & P.startMask[ ((u64)pass*CTX_COUNT + prevctx)*64 + ln]) from = (u32)(j-1);
+			if (j-1 == 0) break;
+			u64 Rp = ((R & shiftDst) >> 1) | (R & selfLoop);
+			for (u32 e=0; e<nEx; ++e)
+			{
+				u64 at = ((u64)pass*P.maxExceptions + e)*64 + ln;
+				if (R & P.exDst[ at]) Rp |= P.exSrc[ at];
+			}
+			u32 cls = P.byteClass[ w.doc[ j-2]];
+			R = Rp & mask & P.charMask[ ((u64)pass*P.nofClasses + cls)*64 + ln];
+			--j;
+		}
+		q[2] = from;
+	}
+}
+
+// ---------------------------------------------------------------- stage 3: the reference's handler
+__device__ __forceinline__ void ldEvent( Event& e, const Event* p)
+{
+	e.id = ldu( &p->id); e.origpos = ldu( &p->origpos); e.origsize = ldu( &p->origsize); e.levelBind = ldu( &p->levelBind);
+}
+__device__ __forceinline__ void stEvent( Event* p, const Event& e)
+{
+	p->id = e.id; p->origpos = e.origpos; p->origsize = e.origsize; p->levelBind = e.levelBind;
+}
+
+// symbol lookup (PatternTable::symbolId, patternLexer.cpp:312-317): exact text of the match
+__device__ u32 lookupSymbol( const LexWave& w, const L1Params& P, u32 lexemId, u32 from, u32 len)
+{
+	u32 h = 2166136261u;
+	for (u32 b=0; b<4; ++b) h = symbolHashStep( h, (lexemId >> (8*b)) & 0xFFu);
+	for (u32 k=0; k<len; ++k) h = symbolHashStep( h, uni( w.doc[ from+k]));
+	if (!h) h = 1;
+	u32 slot = h & P.symbolMask;
+	for (u32 probes=0; probes<=P.symbolMask; ++probes)
+	{
+		const DevSymbol* s = &P.symbols[ slot];
+		u32 sh = ldu( &s->hash);
+		if (!sh) return 0;
+		if (sh == h && ldu( &s->lexemId) == lexemId && ldu( &s->len) == len)
+		{
+			u32 off = ldu( &s->textOffset);
+			bool same = true;
+			for (u32 k=0; k<len && same; ++k) same = (uni( P.symbolText[ off+k]) == uni( w.doc[ from+k]));
+			if (same) return ldu( &s->symbolId);
+		}
+		slot = (slot+1) & P.symbolMask;
+	}
+	return 0;
+}
+
+__device__ void handleReport( LexWave& w, const L1Params& P, u32 pi, u32 from, u32 to)
+{
+	if (to - from >= 65535u) { w.err = L1D_ERR_LEXEMSIZE; return; }			// :727-730
+	const DevLexPattern* pat = &P.patterns[ pi];
+	u32 lb = ldu( &pat->levelBind), id = ldu( &pat->id);
+	if (lb & (1u<<17))										// sub expression selection
+	{
+		u32 pre = ldu( &pat->prefixLen), suf = ldu( &pat->suffixLen);
+		if (pre + suf > to - from) return;
+		from += pre; to -= suf;
+	}
+	u32 patternid = id;
+	if (lb & (1u<<16))
+	{
+		u32 sym = lookupSymbol( w, P, id, from, to-from);
+		if (sym) patternid = sym;
+	}
+	Event ev; ev.id = id; ev.origpos = from; ev.origsize = to-from; ev.levelBind = lb & 0xFFFFu;
+	const u32 level = lb & 0xFFu;
+	const bool twin = (patternid != id);
+	u32 n = w.nEvents;
+	if (n + 2 > P.eventCap) { w.err = L1D_ERR_ARENA; return; }
+	if (n == 0)
+	{
+		stEvent( &w.events[0], ev); n = 1;
+		if (twin) { Event t = ev; t.id = patternid; stEvent( &w.events[1], t); n = 2; }
+		w.nEvents = n;
+		return;
+	}
+	// delete pass (:757-777): from the back while origpos >= the new origpos
+	const u32 lastPos = from + (to-from);
+	u32 nofDeletes = 0;
+	for (u32 k=n; k>0; --k)
+	{
+		Event m; ldEvent( m, &w.events[ k-1]);
+		if (!(m.origpos >= ev.origpos)) break;
+		u32 mlevel = m.levelBind & 0xFFu;
+		if ((ev.id == m.id && m.origpos == ev.origpos && mlevel == level)
+		||  (mlevel < level && m.origpos + m.origsize <= lastPos))
+		{
+			// close the gap: lanes move the tail down by one (ascending order, distinct elements)
+			for (u32 t=k-1+LANE; t+1<n; t+=64)
+			{
+				Event x = w.events[ t+1];
+				__builtin_amdgcn_wave_barrier();
+				w.events[ t] = x;
+			}
+			--n; ++nofDeletes;
+		}
+	}
+	if (!nofDeletes)
+	{
+		// ignore pass (:778-792)
+		for (u32 k=n; k>0; --k)
+		{
+			Event m; ldEvent( m, &w.events[ k-1]);
+			if (!(m.origpos + m.origsize >= lastPos)) break;
+			if ((m.levelBind & 0xFFu) > level && m.origpos <= ev.origpos) { w.nEvents = n; return; }
+		}
+	}
+	// insert (:793-822), literal element moves of the reference (see oracle/l1_oracle.cpp for the
+	// two-slot quirk of the symbol twin variant)
+	const u32 newSlots = twin ? 2u : 1u;
+	Event zero; zero.id = 0; zero.origpos = 0; zero.origsize = 0; zero.levelBind = 0;
+	for (u32 s=0; s<newSlots; ++s) stEvent( &w.events[ n+s], zero);
+	long prev = (long)n + (long)newSlots - 1, mi = (long)n - 1;
+	for (; mi >= 0; prev = mi--)
+	{
+		Event m; ldEvent( m, &w.events[ mi]);
+		if (!(m.origpos > ev.origpos)) break;
+		stEvent( &w.events[ prev], m);
+	}
+	++mi;
+	stEvent( &w.events[ mi], ev);
+	if (twin) { Event t = ev; t.id = patternid; stEvent( &w.events[ mi+1], t); }
+	w.nEvents = n + newSlots;
+}
+
+// drain the report queue: SOM in batches of 64 lanes, handler in report order
+__device__ void drainQueue( LexWave& w, const L1Params& P)
+{
+	for (u32 base=0; base<w.nQueue && !w.err; base+=64)
+	{
+		u32 count = w.nQueue - base < 64 ? w.nQueue - base : 64;
+		resolveStarts( w, P, base, count);
+		for (u32 k=0; k<count && !w.err; ++k)
+		{
+			const u32* q = w.queue + 4*(u64)(base+k);
+			handleReport( w, P, ldu( &q[1]), ldu( &q[2]), ldu( &q[0]));
+		}
+	}
+	w.nQueue = 0;
+}
+
+// ---------------------------------------------------------------- stage 1: forward scan
+template <int PASSES>
+__device__ void scanDocument( LexWave& w, const L1Params& P)
+{
+	u64 state[ PASSES];
+#pragma unroll
+	for (int p=0; p<PASSES; ++p) state[ p] = 0;
+	const u32 len = w.docLen;
+	const u32 drainAt = P.queueCap > P.nofPatterns + 64 ? P.queueCap - P.nofPatterns - 64 : 0;
+	int prevctx = CTX_EDGE;
+	for (u32 tile=0; tile<=len && !w.err; tile+=64)
+	{
+		// 64 document bytes per load, one per lane; replayed byte by byte through a scalar register
+		u32 mine = (tile + LANE < len) ? w.doc[ tile + LANE] : 0u;
+		u32 inTile = (len - tile) < 64 ? (len - tile) : 64;	// document bytes in this tile
+		u32 steps = (tile + 64 > len) ? inTile + 1 : 64;	// +1: the virtual end-of-document step
+		for (u32 k=0; k<steps && !w.err; ++k)
+		{
+			const u32 i = tile + k;
+			const bool atEnd = (i >= len);
+			const u32 b = atEnd ? 0u : (u32)__builtin_amdgcn_readlane( mine, k);
+			const u32 cls = atEnd ? 0u : uni( P.byteClass[ b]);
+			const int ctx = atEnd ? (int)CTX_EDGE : (int)uni( P.classCtx[ cls]);
+#pragma unroll
+			for (int p=0; p<PASSES; ++p)
+			{
+				if ((u32)p >= P.nofPasses) break;
+				const u64 st = state[ p];
+				// reports for matches ending before byte i
+				const u64 acc = st & P.acceptMask[ ((u64)p*CTX_COUNT + ctx)*64 + LANE];
+				const u64 hit = __ballot( acc != 0);
+				if (hit)
+				{
+					// per lane: which of the patterns packed into my word fired
+					const u32 word = p*64 + LANE;
+					u32 mycount = 0;
+					u32 pb = 0, pe = 0;
+					if (acc)
+					{
+						pb = P.wordPatBegin[ word]; pe = P.wordPatBegin[ word+1];
+						for (u32 x=pb; x<pe; ++x)
+						{
+							const DevLexPattern* pat = &P.patterns[ P.wordPats[ x]];
+							u64 m = ((u64)pat->maskHi << 32) | pat->maskLo;
+							if (acc & m) ++mycount;
+						}
+					}
+					// exclusive prefix sum of the counts over the lanes (report order = lane order)
+					u32 incl = mycount;
+					for (int d=1; d<64; d<<=1)
+					{
+						u32 up = __shfl_up( incl, d);
+						if ((int)LANE >= d) incl += up;
+					}
+					u32 total = uni( __shfl( incl, 63));
+					u32 at = w.nQueue + incl - mycount;
+					if (w.nQueue + total > P.queueCap) { w.err = L1D_ERR_ARENA; break; }
+					if (acc)
+					{
+						for (u32 x=pb; x<pe; ++x)
+						{
+							u32 pi = P.wordPats[ x];
+							const DevLexPattern* pat = &P.patterns[ pi];
+							u64 m = ((u64)pat->maskHi << 32) | pat->maskLo;
+							if (acc & m)
+							{
+								u32* q = w.queue + 4*(u64)at;
+								q[0] = i; q[1] = pi; q[2] = (u32)(acc & m); q[3] = (u32)((acc & m) >> 32);
+								++at;
+							}
+						}
+					}
+					w.nQueue += total;
+				}
+				if (!atEnd)
+				{
+					u64 nxt = ((st << 1) & P.shiftDst[ p*64 + LANE]) | (st & P.selfLoop[ p*64 + LANE])
+						| P.startMask[ ((u64)p*CTX_COUNT + prevctx)*64 + LANE];
+					const u32 nEx = P.exCount[ p];
+					for (u32 e=0; e<nEx; ++e)
+					{
+						u64 at = ((u64)p*P.maxExceptions + e)*64 + LANE;
+						if (st & P.exSrc[ at]) nxt |= P.exDst[ at];
+					}
+					state[ p] = nxt & P.charMask[ ((u64)p*P.nofClasses + cls)*64 + LANE];
+				}
+			}
+			prevctx = ctx;
+			if (w.nQueue >= drainAt && w.nQueue)
+			{
+				__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+				drainQueue( w, P);
+			}
+		}
+	}
+	if (!w.err && w.nQueue)
+	{
+		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+		drainQueue( w, P);
+	}
+}
+
+// ---------------------------------------------------------------- stage 4: ordinal positions + output (:893-945)
+__device__ void emitLexems( LexWave& w, const L1Params& P, u32 doc)
+{
+	enum {BIND_CONTENT=0, BIND_SUCCESSOR=1, BIND_PREDECESSOR=2, BIND_UNIQUE=3};
+	// pass A counts, pass B writes; both walk the event array with the reference's state machine
+	u64 outBase = 0;
+	u32 total = 0;
+	for (int phase=0; phase<2 && !w.err; ++phase)
+	{
+		u32 n = w.nEvents, mi = 0, ordpos = 0, origpos = 0, lastbind = BIND_CONTENT, out = 0;
+		bool started = false;
+		// phase 1 of the reference: up to the first content/unique event
+		for (; mi<n; ++mi)
+		{
+			Event m; ldEvent( m, &w.events[ mi]);
+			u32 bind = (m.levelBind >> 8) & 0xFFu;
+			lastbind = bind;
+			if (bind == BIND_UNIQUE || bind == BIND_CONTENT)
+			{
+				ordpos = 1; origpos = m.origpos; started = true;
+				if (phase) { u32* o = P.lexems + 4*(outBase + out); o[0] = m.id; o[1] = 1; o[2] = m.origpos; o[3] = m.origsize; }
+				++out; ++mi;
+				break;
+			}
+			else if (bind == BIND_SUCCESSOR)
+			{
+				if (phase) { u32* o = P.lexems + 4*(outBase + out); o[0] = m.id; o[1] = 1; o[2] = m.origpos; o[3] = m.origsize; }
+				++out;
+			}
+		}
+		if (!started) out = 0;
+		for (; mi<n && started; ++mi)
+		{
+			Event m; ldEvent( m, &w.events[ mi]);
+			u32 bind = (m.levelBind >> 8) & 0xFFu;
+			u32 pos = 0; bool emit = true;
+			if (bind == BIND_UNIQUE && lastbind == BIND_UNIQUE) emit = false;
+			else if (bind == BIND_UNIQUE || bind == BIND_CONTENT)
+			{
+				if (m.origpos > origpos) { origpos = m.origpos; ++ordpos; }
+				pos = ordpos;
+			}
+			else if (bind == BIND_SUCCESSOR) pos = ordpos+1;
+			else pos = ordpos;
+			if (emit)
+			{
+				if (phase) { u32* o = P.lexems + 4*(outBase + out); o[0] = m.id; o[1] = pos; o[2] = m.origpos; o[3] = m.origsize; }
+				++out;
+			}
+			lastbind = bind;
+		}
+		if (!phase)
+		{
+			total = out;
+			u64 b = 0;
+			if (LANE == 0) b = atomicAdd( (unsigned long long*)&P.counters[ L1C_LEXEMS], (unsigned long long)total);
+			outBase = ((u64)uni( (u32)(b >> 32)) << 32) | uni( (u32)b);
+			if (outBase + total > P.lexemCapacity) { w.err = L1D_ERR_OUTPUT; total = 0; }
+			if (!total) break;
+		}
+	}
+	if (LANE == 0)
+	{
+		P.docRange[ 2*(u64)doc] = outBase; P.docRange[ 2*(u64)doc+1] = w.err ? 0 : total;
+	}
+}
+
+template <int PASSES>
+__device__ void lexDocuments( const L1Params& P)
+{
+	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
+	u32* A = P.arenaBase + (u64)waveSlot * P.arenaWords;
+	LexWave w;
+	w.queue = A;
+	w.events = (Event*)(A + 4*(u64)P.queueCap);
+	for (u32 doc=waveSlot; doc<P.ndocs; doc+=nWaveSlots)
+	{
+		const u64 beg = ((u64)ldu( (const u32*)&P.docOffsets[ doc]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc]);
+		const u64 end = ((u64)ldu( (const u32*)&P.docOffsets[ doc+1]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc+1]);
+		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
+		w.nQueue = 0; w.nEvents = 0; w.err = 0;
+		scanDocument<PASSES>( w, P);
+		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+		if (!w.err) emitLexems( w, P, doc);
+		else if (LANE == 0) { P.docRange[ 2*(u64)doc] = 0; P.docRange[ 2*(u64)doc+1] = 0; }
+		if (LANE == 0)
+		{
+			P.docStatus[ doc] = (int32_t)w.err;
+			atomicAdd( (unsigned long long*)&P.counters[ L1C_BYTES], (unsigned long long)w.docLen);
+			if (w.err) atomicAdd( (unsigned long long*)&P.counters[ L1C_FAILED], 1ull);
+		}
+	}
+}
+
+} // anonymous namespace
+
+#define SPA_L1_KERNEL( N) \
+extern "C" __global__ __launch_bounds__(256) void spa_l1_lex_kernel_p##N( L1Params P) { lexDocuments<N>( P); }
+SPA_L1_KERNEL( 1)
+SPA_L1_KERNEL( 2)
+SPA_L1_KERNEL( 4)
+SPA_L1_KERNEL( 8)
+SPA_L1_KERNEL( 16)
+SPA_L1_KERNEL( 32)
+
+namespace spa {
+hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, hipStream_t stream)
+{
+	if (P.nofPasses <= 1) hipLaunchKernelGGL( spa_l1_lex_kernel_p1, dim3( nblocks), dim3( 256), 0, stream, P);
+	else if (P.nofPasses <= 2) hipLaunchKernelGGL( spa_l1_lex_kernel_p2, dim3( nblocks), dim3( 256), 0, stream, P);
+	else if (P.nofPasses <= 4) hipLaunchKernelGGL( spa_l1_lex_kernel_p4, dim3( nblocks), dim3( 256), 0, stream, P);
+	else if (P.nofPasses <= 8) hipLaunchKernelGGL( spa_l1_lex_kernel_p8, dim3( nblocks), dim3( 256), 0, stream, P);
+	else if (P.nofPasses <= 16) hipLaunchKernelGGL( spa_l1_lex_kernel_p16, dim3( nblocks), dim3( 256), 0, stream, P);
+	else if (P.nofPasses <= 32) hipLaunchKernelGGL( spa_l1_lex_kernel_p32, dim3( nblocks), dim3( 256), 0, stream, P);
+	else return hipErrorInvalidValue;
+	return hipGetLastError();
+}
+}

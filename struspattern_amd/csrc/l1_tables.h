@@ -1,0 +1,53 @@
+// Level-1 device tables shared by the host regex compiler (l1_compile.cpp) and the HIP lexer kernel
+// (l1_kernel.hip).
+//
+// Model: every regex is compiled to a Glushkov position automaton (one state bit per byte-consuming
+// position).  A pattern occupies a contiguous bit range inside ONE 64-bit word; words are grouped
+// into passes of 64 words = one word per lane of a wavefront.  All zero-width assertions
+// (\b \B ^ $) are compiled away by splitting positions by the context class of their byte
+// (word / other / newline), so that inside a pattern every follow edge is unconditional; only the
+// start of a match depends on the byte before it and the end on the byte after it:
+//     state' = ( (state<<1 & shiftDst) | (state & selfLoop) | exceptions(state) | start[ctx(prev)] ) & charMask[class(byte)]
+//     report = state & accept[ctx(next)]
+#ifndef SPA_L1_TABLES_H
+#define SPA_L1_TABLES_H
+#include <stdint.h>
+
+namespace spa {
+
+// context class of a byte as seen by the assertions
+enum {CTX_WORD=0, CTX_OTHER=1, CTX_NEWLINE=2, CTX_EDGE=3, CTX_COUNT=4};	// EDGE = begin/end of document
+
+enum {L1_WORDS_PER_PASS=64};
+
+struct DevLexPattern		// 32 B, one per defineLexem call, index = definition index (0-based)
+{
+	uint32_t id;		// lexem id reported
+	uint32_t word;		// global word index (pass*64 + lane) holding the pattern's positions
+	uint32_t levelBind;	// level | posbind<<8 | hasSymbols<<16 | hasSubexpr<<17
+	uint32_t prefixLen;	// sub-expression selection: bytes cut at the front ...
+	uint32_t suffixLen;	// ... and at the back of the raw match (fixed-length context)
+	uint32_t maskLo, maskHi;// bits of the word that belong to this pattern
+	uint32_t _pad;
+};
+
+struct DevSymbol		// 32 B, open addressing (linear probing), hash==0 = empty
+{
+	uint32_t hash;
+	uint32_t lexemId;
+	uint32_t textOffset;
+	uint32_t len;
+	uint32_t symbolId;
+	uint32_t _pad[3];
+};
+
+// FNV-1a step used for the symbol hash (lexem id first, then the text bytes); 0 is reserved for
+// "empty" so a zero hash is mapped to 1
+static inline
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+uint32_t symbolHashStep( uint32_t h, uint32_t byte) { return (h ^ byte) * 16777619u; }
+
+} // namespace
+#endif

@@ -93,3 +93,112 @@ def lexems5(lex4):
     out[:, 3] = lex4[:, 2]
     out[:, 4] = lex4[:, 3]
     return out
+
+
+# ---------------------------------------------------------------- level 1 synthetic workload
+_LETTERS = "etaoinshrdlcumwfgypbvkjxqz"
+
+
+def vocabulary(nwords, seed):
+    """Synthetic vocabulary: distinct lower-case words of length 2..12 (letter frequencies roughly English)."""
+    rng = np.random.default_rng(seed)
+    p = np.array([12.7, 9.1, 8.2, 7.5, 7.0, 6.7, 6.3, 6.1, 6.0, 4.3, 4.0, 2.8, 2.8, 2.4, 2.4, 2.2, 2.0, 2.0, 1.9, 1.5, 1.0, 0.8, 0.15, 0.15, 0.1, 0.07])
+    p = p / p.sum()
+    words, seen = [], set()
+    while len(words) < nwords:
+        ln = int(rng.integers(2, 13))
+        w = "".join(_LETTERS[i] for i in rng.choice(26, size=ln, p=p))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    return words
+
+
+def text_documents(ndocs, docbytes, vocab, seed, utf8=False):
+    """Documents of about `docbytes` bytes: Zipf(s=1) words, separators ' ' / '. ' / '\\n', 2 % digit tokens,
+    some capitalised words; with utf8=True 10 % of the words carry a 2-byte and 2 % a 3-byte code point.
+    Returns (bytes of all documents, doc_offsets u64)."""
+    rng = np.random.default_rng(seed)
+    cum = zipf_cum(len(vocab), 1.0)
+    parts = []
+    offs = [0]
+    total = 0
+    for d in range(ndocs):
+        nw = docbytes // 5 + 8
+        idx = zipf_sample(cum, rng, nw) - 1
+        r = rng.random(nw)
+        sep = rng.random(nw)
+        toks = []
+        size = 0
+        for k in range(nw):
+            if r[k] < 0.02:
+                w = str(int(rng.integers(0, 100000)))
+                if rng.random() < 0.3:
+                    w = w[:2] + "'" + "%03d" % int(rng.integers(0, 1000))
+            else:
+                w = vocab[idx[k]]
+                if r[k] < 0.10:
+                    w = w.capitalize()
+                elif utf8 and r[k] < 0.20:
+                    w = w[:1] + "ö" + w[1:]
+                elif utf8 and r[k] < 0.22:
+                    w = w + "€"
+            s = " " if sep[k] < 0.85 else (". " if sep[k] < 0.95 else "\n")
+            piece = (w + s).encode()
+            if size + len(piece) > docbytes:
+                break
+            toks.append(piece)
+            size += len(piece)
+        doc = b"".join(toks)
+        parts.append(doc)
+        total += len(doc)
+        offs.append(total)
+    return b"".join(parts), np.array(offs, dtype=np.uint64)
+
+
+def lexer_patterns(npatterns, vocab, seed):
+    """Regex set modelled on the reference's test/doc patterns (tests/charRegexMatch :109-112, the
+    rule language example of the web page): list of (lexem id, expression, resultIndex, level, posbind)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    nlit = npatterns // 4 if npatterns <= 1024 else (npatterns * 8) // 10
+    for i in range(npatterns):
+        lid = i + 1
+        level = 1 + int(rng.integers(0, 4))
+        posbind = "content" if rng.random() < 0.85 else "predecessor"
+        if i < nlit:
+            w = vocab[i % len(vocab)]
+            expr = "\\b" + w + "\\b"
+            if rng.random() < 0.1:
+                expr = "\\b" + w.capitalize() + "\\b"
+        else:
+            fam = int(rng.integers(0, 8))
+            suf = "".join(_LETTERS[int(x)] for x in rng.integers(0, 12, size=int(rng.integers(2, 4))))
+            if fam == 0:
+                expr = "[0-9]+\\b"
+            elif fam == 1:
+                expr = "[a-z]+%s\\b" % suf
+            elif fam == 2:
+                expr = "\\b[A-Z][a-z]+\\b"
+            elif fam == 3:
+                expr = "\\b[0-9]{1,3}'[0-9]{3}\\b"
+            elif fam == 4:
+                expr = "\\b%s[a-z]*\\b" % suf
+            elif fam == 5:
+                w2 = vocab[int(rng.integers(0, min(200, len(vocab))))]
+                expr = "\\b%s\\s\\w+\\b" % w2
+            elif fam == 6:
+                a, b, c = (vocab[int(x)] for x in rng.integers(0, min(2000, len(vocab)), size=3))
+                expr = "\\b(%s|%s|%s)\\b" % (a, b, c)
+            else:
+                expr = "\\b[a-z]{%d}\\b" % int(rng.integers(2, 10))
+        out.append((lid, expr, 0, level, posbind))
+    return out
+
+
+def apply_lexer_patterns(lx, patterns, options=("DOTALL",)):
+    for o in options:
+        lx.defineOption(o)
+    for lid, expr, residx, level, posbind in patterns:
+        lx.defineLexem(lid, expr, residx, level, posbind)
+    lx.compile()

@@ -1,0 +1,98 @@
+"""Test utility: a tiny pure-Python interpreter of the product's compiled lexer tables
+(sp_lexer_dump_tables).  It executes exactly the recurrences the HIP kernel executes -- forward
+scan with per-word bit masks, backward start-of-match resolution -- with Python integers, so the
+host regex compiler can be checked against the oracle on the CPU, without a GPU.  Test code only:
+nothing in the product imports this."""
+import numpy as np
+
+M64 = (1 << 64) - 1
+CTX_EDGE = 3
+
+
+class Tables:
+    def __init__(self, dump):
+        d = [int(x) for x in dump]
+        self.nofPasses, self.nofClasses, self.maxEx, self.nofPatterns, self.nofPositions = d[0:5]
+        p = 8
+        self.byteClass = d[p:p + 256]; p += 256
+        self.classCtx = d[p:p + self.nofClasses]; p += self.nofClasses
+        P, C = self.nofPasses, self.nofClasses
+        E = max(self.maxEx, 1)
+
+        def take(n):
+            nonlocal p
+            v = d[p:p + n]
+            p += n
+            return v
+        self.charMask = take(P * C * 64)
+        self.startMask = take(P * 4 * 64)
+        self.acceptMask = take(P * 4 * 64)
+        self.shiftDst = take(P * 64)
+        self.selfLoop = take(P * 64)
+        self.exCount = take(P)
+        self.exSrc = take(P * E * 64)
+        self.exDst = take(P * E * 64)
+        self.E = E
+        self.patterns = []
+        for i in range(self.nofPatterns):
+            pid, word, lb, pre, suf, mask = take(6)
+            self.patterns.append(dict(id=pid, word=word, levelBind=lb, prefixLen=pre, suffixLen=suf, mask=mask))
+        assert p == len(d)
+
+    def ctx(self, text, pos):
+        if pos < 0 or pos >= len(text):
+            return CTX_EDGE
+        return self.classCtx[self.byteClass[text[pos]]]
+
+    def raw_reports(self, text):
+        """[(patternidx 1-based, from, to)] in (to, idx) order."""
+        P, C, E = self.nofPasses, self.nofClasses, self.E
+        nwords = P * 64
+        state = [0] * nwords
+        out = []
+        prevctx = CTX_EDGE
+        for i in range(len(text) + 1):
+            ctx = self.ctx(text, i)
+            cls = self.byteClass[text[i]] if i < len(text) else 0
+            new = list(state)
+            for w in range(nwords):
+                st = state[w]
+                p, ln = divmod(w, 64)
+                acc = st & self.acceptMask[(p * 4 + ctx) * 64 + ln]
+                if acc:
+                    for pi, pat in enumerate(self.patterns):
+                        if pat["word"] == w and (acc & pat["mask"]):
+                            out.append((pi + 1, self.som(text, pi, i, acc & pat["mask"]), i))
+                if i < len(text):
+                    nxt = ((st << 1) & M64 & self.shiftDst[w]) | (st & self.selfLoop[w]) | self.startMask[(p * 4 + prevctx) * 64 + ln]
+                    for e in range(self.exCount[p]):
+                        at = (p * E + e) * 64 + ln
+                        if st & self.exSrc[at]:
+                            nxt |= self.exDst[at]
+                    new[w] = nxt & self.charMask[(p * C + cls) * 64 + ln]
+            state = new
+            prevctx = ctx
+        out.sort(key=lambda r: (r[2], r[0]))
+        return out
+
+    def som(self, text, pi, to, R):
+        pat = self.patterns[pi]
+        w = pat["word"]
+        p, ln = divmod(w, 64)
+        frm = to
+        j = to
+        while R and j > 0:
+            prevctx = self.ctx(text, j - 2)
+            if R & self.startMask[(p * 4 + prevctx) * 64 + ln]:
+                frm = j - 1
+            if j - 1 == 0:
+                break
+            Rp = ((R & self.shiftDst[w]) >> 1) | (R & self.selfLoop[w])
+            for e in range(self.exCount[p]):
+                at = (p * self.E + e) * 64 + ln
+                if R & self.exDst[at]:
+                    Rp |= self.exSrc[at]
+            cls = self.byteClass[text[j - 2]]
+            R = Rp & pat["mask"] & self.charMask[(p * self.nofClasses + cls) * 64 + ln]
+            j -= 1
+        return frm

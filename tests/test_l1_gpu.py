@@ -1,0 +1,116 @@
+"""GPU parity tests of the level-1 lexer: HIP kernel (through the C-ABI) vs the CPU oracle on the
+same inputs; lexem lists must be identical (id, ordpos, origpos, origsize) and in the same order.
+Parity with real Hyperscan is pinned only by the 36-lexem charRegexMatch vector (first test)."""
+import random
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+import struspattern_amd as spa
+from struspattern_amd import synth
+from tests import l1_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(build):
+    lx = spa.PatternLexerInstance()
+    o = oracle.L1Lexer()
+    build(lx)
+    build(o)
+    return lx, o
+
+
+def test_char_regex_match_golden_case1():
+    case = l1_cases.load_char_regex_cases()[0]
+    lx = spa.PatternLexerInstance()
+    l1_cases.build_case(lx, case)
+    got = lx.createContext().match(case["src"].encode()).tolist()
+    assert got == case["result"]
+
+
+def test_supersede_levels_symbols():
+    def build(x):
+        x.defineLexem(1, "\\b\\w+\\b", 0, 1, "content")
+        x.defineLexem(2, "[.]", 0, 2, "content")
+        x.defineLexem(3, "\\b[a-z]+[.][a-z]+\\b", 0, 3, "content")
+        x.defineLexem(4, "[0-9]+", 0, 1, "successor")
+        x.defineLexem(5, "\\b[a-z]{3}\\b", 0, 1, "unique")
+        x.defineSymbol(70, 1, "now")
+        x.defineSymbol(71, 1, "go")
+        x.compile()
+    lx, o = _both(build)
+    text = b"go to example.com now. call 555 1234 now or see foo.bar.baz for the cat"
+    assert lx.createContext().match(text).tolist() == o.match(text).tolist()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_regex_sets(seed):
+    rng = random.Random(5000 + seed)
+    ctxs = []
+    for _ in range(12):
+        pats = []
+        while len(pats) < rng.randint(1, 8):
+            p = l1_cases.random_regex(rng)
+            try:
+                re.compile(p)
+                one = spa.PatternLexerInstance()
+                one.defineLexem(1, p, 0, 1, "content")
+                one.compile()
+            except (re.error, spa.PatternError):
+                continue
+            pats.append((p, rng.randint(1, 3), rng.choice(["content", "content", "predecessor", "successor", "unique"])))
+
+        def build(x):
+            x.defineOption("DOTALL")
+            for i, (p, level, pb) in enumerate(pats):
+                x.defineLexem(1 + i % 5, p, 0, level, pb)
+            x.compile()
+        lx, o = _both(build)
+        docs = [l1_cases.random_text(rng, rng.randint(0, 200)).encode() for _ in range(20)]
+        offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
+        text = b"".join(docs)
+        gpu = lx.createContext().matchDocs(text, offs)
+        ref, roffs = o.matchDocs(text, offs)
+        assert np.array_equal(gpu.doc_offsets, roffs), pats
+        assert np.array_equal(gpu.lexems, ref), pats
+
+
+@pytest.mark.parametrize("npat,ndocs,docbytes,utf8,seed", [(64, 16, 2000, False, 1), (256, 24, 4096, False, 2), (256, 8, 3000, True, 3), (700, 6, 2000, False, 4)])
+def test_synthetic_lexer_workload(npat, ndocs, docbytes, utf8, seed):
+    vocab = synth.vocabulary(3000, 77)
+    pats = synth.lexer_patterns(npat, vocab, seed)
+    text, offs = synth.text_documents(ndocs, docbytes, vocab, 100 + seed, utf8=utf8)
+    lx, o = _both(lambda x: synth.apply_lexer_patterns(x, pats))
+    gpu = lx.createContext().matchDocs(text, offs)
+    ref, roffs = o.matchDocs(text, offs, nthreads=8)
+    assert len(ref) > 100
+    assert np.array_equal(gpu.status, np.zeros(ndocs, np.int32))
+    assert np.array_equal(gpu.doc_offsets, roffs)
+    assert np.array_equal(gpu.lexems, ref)
+
+
+def test_edge_cases_empty_documents_and_errors():
+    def build(x):
+        x.defineLexem(1, "[a-z]+\\b", 0, 1, "content")
+        x.compile()
+    lx, o = _both(build)
+    docs = [b"", b"a", b"", b"hello world", b" ", b""]
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
+    gpu = lx.createContext().matchDocs(b"".join(docs), offs)
+    ref, roffs = o.matchDocs(b"".join(docs), offs)
+    assert np.array_equal(gpu.doc_offsets, roffs) and np.array_equal(gpu.lexems, ref)
+    # a lexem of 65535 bytes or more is an error (patternLexer.cpp:727-730)
+    big = b"a" * 70000
+    ctx = lx.createContext()
+    b = ctx.matchDocs(big + b" ok", [0, len(big) + 3], check=False)
+    assert b.status[0] == 7
+    with pytest.raises(spa.PatternError):
+        ctx.match(big)
+    # context before compile is an error (patternLexer.cpp:1124-1127)
+    lx2 = spa.PatternLexerInstance()
+    lx2.defineLexem(1, "a", 0, 1, "content")
+    with pytest.raises(spa.PatternError):
+        lx2.createContext()
