@@ -178,6 +178,12 @@ typedef struct sp_match_device_batch {
 int sp_matcher_ctx_match_docs_device(sp_matcher_ctx_t* c, const void* d_lexems, const void* d_origseg,
                                      const void* d_doc_offsets, size_t ndocs, size_t nlexems,
                                      void* stream, sp_match_device_batch_t* out);
+/* fused pipeline entry: the lexems and per-document (first, count) ranges produced by
+ * sp_lexer_ctx_match_docs_device are consumed in place, nothing leaves HBM in between */
+int sp_matcher_ctx_match_lexed_device(sp_matcher_ctx_t* c, const void* d_lexems, const void* d_doc_ranges,
+                                      size_t ndocs, size_t nlexems_hint, void* stream, sp_match_device_batch_t* out);
+/* copies the results of the last device batch to the host, grouped by document */
+int sp_matcher_ctx_batch_fetch(sp_matcher_ctx_t* c, sp_match_batch_t* out);
 /* waits for the stream and returns counters[0..7] = {results, items, events, failed docs, 0..} */
 int sp_matcher_ctx_batch_counters(sp_matcher_ctx_t* c, uint64_t counters[8]);
 /* duration of the last rule-automaton kernel in milliseconds (HIP events on the launch stream) */

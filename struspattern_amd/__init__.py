@@ -130,6 +130,32 @@ class PatternMatcherContext:
             raise PatternError("device batch match failed (%d): %s" % (rc, self._err()))
         return out
 
+    def matchLexedDevice(self, d_lexems, d_doc_ranges, ndocs, nlexems_hint, stream=0):
+        """consume the device output of PatternLexerContext.matchDocsDevice in place (fused pipeline)."""
+        out = capi.SpMatchDeviceBatch()
+        rc = self._L.sp_matcher_ctx_match_lexed_device(self._h, d_lexems, d_doc_ranges, ndocs, nlexems_hint, stream or None, ctypes.byref(out))
+        if rc != 0:
+            raise PatternError("device batch match failed (%d): %s" % (rc, self._err()))
+        return out
+
+    def batchFetch(self):
+        """host copy of the last device batch, grouped by document."""
+        b = capi.SpMatchBatch()
+        rc = self._L.sp_matcher_ctx_batch_fetch(self._h, ctypes.byref(b))
+        try:
+            if rc != 0:
+                raise PatternError("fetching the batch failed (%d): %s" % (rc, self._err()))
+            ndocs = b.ndocs
+            u32p = ctypes.POINTER(ctypes.c_uint32)
+            res = np.ctypeslib.as_array(ctypes.cast(b.results, u32p), shape=(b.nresults * 9 + 1,))[:b.nresults * 9].reshape(-1, 9).copy()
+            items = np.ctypeslib.as_array(ctypes.cast(b.items, u32p), shape=(b.nitems * 7 + 1,))[:b.nitems * 7].reshape(-1, 7).copy()
+            offs = np.ctypeslib.as_array(b.doc_result_offsets, shape=(ndocs + 1,)).copy()
+            stats = np.ctypeslib.as_array(b.doc_stats, shape=(ndocs * 4 + 1,))[:ndocs * 4].reshape(-1, 4).copy()
+            status = np.ctypeslib.as_array(b.doc_status, shape=(ndocs + 1,))[:ndocs].copy()
+        finally:
+            self._L.sp_match_batch_free(ctypes.byref(b))
+        return MatchBatch(res, items, offs, stats, status)
+
     def batchCounters(self):
         arr = (ctypes.c_uint64 * 8)()
         rc = self._L.sp_matcher_ctx_batch_counters(self._h, arr)

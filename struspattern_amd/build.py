@@ -9,6 +9,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "_build", "libstruspattern_amd.so")
 
 
+HOST_LIB = os.path.join(HERE, "_build", "libstrus_pattern.so")
+HOST_MODULE = os.path.join(HERE, "_build", "modstrus_analyzer_pattern.so")
+HOST_TEST = os.path.join(HERE, "_build", "testStrusInterface")
+
+
 def _sources():
     out = []
     for d in (os.path.join(HERE, "csrc"), os.path.join(os.path.dirname(HERE), "include")):
@@ -16,6 +21,16 @@ def _sources():
             if f.endswith((".cpp", ".hpp", ".h", ".hip")) or f == "Makefile":
                 out.append(os.path.join(d, f))
     return out
+
+
+def build_host(quiet=True):
+    """C++ host side of the drop-in (strus plugin interfaces over the C-ABI) + module entry point."""
+    build(quiet=quiet)
+    cmd = ["make", "-C", os.path.join(HERE, "host")]
+    if quiet:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return HOST_LIB, HOST_MODULE, HOST_TEST
 
 
 def needs_build():

@@ -87,6 +87,8 @@ SIGNATURES = {
     "sp_matcher_ctx_match_docs": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, P(SpMatchBatch)]),
     "sp_match_batch_free": (None, [P(SpMatchBatch)]),
     "sp_matcher_ctx_match_docs_device": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, ctypes.c_size_t, c_vp, P(SpMatchDeviceBatch)]),
+    "sp_matcher_ctx_match_lexed_device": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, ctypes.c_size_t, c_vp, P(SpMatchDeviceBatch)]),
+    "sp_matcher_ctx_batch_fetch": (ctypes.c_int, [c_vp, P(SpMatchBatch)]),
     "sp_matcher_ctx_batch_counters": (ctypes.c_int, [c_vp, P(c_u64)]),
     "sp_matcher_ctx_last_kernel_ms": (ctypes.c_double, [c_vp]),
     "sp_matcher_ctx_batch_status": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t]),

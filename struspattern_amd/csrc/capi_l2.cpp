@@ -218,6 +218,62 @@ int sp_matcher_ctx_set_arena( sp_matcher_ctx_t* c, uint32_t max_rules, uint32_t 
 	return SP_OK;
 }
 
+// copies the device results of the last batch to the host, grouped by document (test/verification hook)
+int sp_matcher_ctx_batch_fetch( sp_matcher_ctx_t* c, sp_match_batch_t* out)
+{
+	std::memset( out, 0, sizeof(*out));
+	return guardedCall( c->lasterror, SP_ERR_DEVICE, [&]{
+		HIP_CHECK( hipSetDevice( c->device));
+		HIP_CHECK( hipStreamSynchronize( c->lastStream));
+		size_t ndocs = c->lastNdocs;
+		uint64_t counters[ SPC_COUNT];
+		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
+		std::vector<uint64_t> range( ndocs*2+2);
+		out->ndocs = ndocs;
+		out->doc_stats = (uint64_t*)std::malloc( (ndocs*4+1)*sizeof(uint64_t));
+		out->doc_status = (int32_t*)std::malloc( (ndocs+1)*sizeof(int32_t));
+		out->doc_result_offsets = (uint64_t*)std::malloc( (ndocs+1)*sizeof(uint64_t));
+		if (!out->doc_stats || !out->doc_status || !out->doc_result_offsets) throw std::bad_alloc();
+		if (ndocs)
+		{
+			HIP_CHECK( hipMemcpy( range.data(), c->dDocRange.ptr, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
+			HIP_CHECK( hipMemcpy( out->doc_stats, c->dDocStats.ptr, ndocs*4*sizeof(uint64_t), hipMemcpyDeviceToHost));
+			HIP_CHECK( hipMemcpy( out->doc_status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+		}
+		uint64_t nres = counters[ SPC_RESULTS] < c->resultCapacity ? counters[ SPC_RESULTS] : c->resultCapacity;
+		uint64_t nitems = counters[ SPC_ITEMS] < c->itemCapacity ? counters[ SPC_ITEMS] : c->itemCapacity;
+		std::vector<sp_result_t> raw( nres+1);
+		std::vector<sp_result_item_t> rawitems( nitems+1);
+		if (nres) HIP_CHECK( hipMemcpy( raw.data(), c->dResults.ptr, nres*sizeof(sp_result_t), hipMemcpyDeviceToHost));
+		if (nitems) HIP_CHECK( hipMemcpy( rawitems.data(), c->dItems.ptr, nitems*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
+		uint64_t total = 0, totalItems = 0;
+		for (size_t di=0; di<ndocs; ++di)
+		{
+			if (out->doc_status[ di] != 0) range[ 2*di+1] = 0;
+			total += range[ 2*di+1];
+			for (uint64_t ri=0; ri<range[ 2*di+1]; ++ri) totalItems += raw[ range[ 2*di]+ri].item_count;
+		}
+		out->results = (sp_result_t*)std::malloc( (total+1)*sizeof(sp_result_t));
+		out->items = (sp_result_item_t*)std::malloc( (totalItems+1)*sizeof(sp_result_item_t));
+		if (!out->results || !out->items) throw std::bad_alloc();
+		uint64_t rp = 0, ip = 0;
+		for (size_t di=0; di<ndocs; ++di)
+		{
+			out->doc_result_offsets[ di] = rp;
+			for (uint64_t ri=0; ri<range[ 2*di+1]; ++ri)
+			{
+				sp_result_t r = raw[ range[ 2*di]+ri];
+				uint32_t ib = r.item_begin, ic = r.item_count;
+				r.item_begin = (uint32_t)ip;
+				for (uint32_t k=0; k<ic; ++k) out->items[ ip++] = rawitems[ ib+k];
+				out->results[ rp++] = r;
+			}
+		}
+		out->doc_result_offsets[ ndocs] = rp;
+		out->nresults = rp; out->nitems = ip;
+	});
+}
+
 int sp_matcher_ctx_batch_status( sp_matcher_ctx_t* c, int32_t* status, size_t ndocs)
 {
 	return guardedCall( c->lasterror, SP_ERR_DEVICE, [&]{
@@ -251,7 +307,7 @@ namespace {
 
 // enqueue one batch on `stream`; all inputs are device pointers
 void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg, const void* d_doc_offsets,
-		  size_t ndocs, size_t nlexems, hipStream_t stream)
+		  size_t ndocs, size_t nlexems, hipStream_t stream, const void* d_doc_ranges=0)
 {
 	HIP_CHECK( hipSetDevice( c->device));
 	// geometry: 4 waves per 256-thread block; as many blocks as keep every CU busy, never more waves than documents
@@ -307,6 +363,7 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	P.keymask = c->keymask; P.nofStopWords = c->nofStopWords;
 	P.lexems = (const uint32_t*)d_lexems; P.origseg = (const uint32_t*)d_origseg;
 	P.docOffsets = (const uint64_t*)d_doc_offsets;
+	P.docRangesIn = (const uint64_t*)d_doc_ranges;
 	P.ndocs = (uint32_t)ndocs; P.withItems = c->withItems ? 1u : 0u;
 	P.arenaBase = (uint32_t*)c->dArena.ptr; P.arena = c->arena;
 	P.docCursor = (uint32_t*)c->dCursor.ptr;
@@ -366,6 +423,23 @@ int sp_matcher_ctx_match_docs_device( sp_matcher_ctx_t* c, const void* d_lexems,
 	return guardedCall( c->lasterror, SP_ERR_INVALID, [&]{
 		if (ndocs >= 0xFFFFFFFFull) throw std::runtime_error( "too many documents in one batch");
 		launchBatch( c, d_lexems, d_origseg, d_doc_offsets, ndocs, nlexems, (hipStream_t)stream);
+		if (out)
+		{
+			out->ndocs = ndocs;
+			out->d_results = c->dResults.ptr; out->d_items = c->dItems.ptr;
+			out->d_doc_result_offsets = c->dDocRange.ptr;
+			out->d_doc_stats = c->dDocStats.ptr; out->d_doc_status = c->dDocStatus.ptr;
+			out->d_counters = c->dCounters.ptr;
+		}
+	});
+}
+
+int sp_matcher_ctx_match_lexed_device( sp_matcher_ctx_t* c, const void* d_lexems, const void* d_doc_ranges,
+				       size_t ndocs, size_t nlexems_hint, void* stream, sp_match_device_batch_t* out)
+{
+	return guardedCall( c->lasterror, SP_ERR_INVALID, [&]{
+		if (ndocs >= 0xFFFFFFFFull) throw std::runtime_error( "too many documents in one batch");
+		launchBatch( c, d_lexems, 0, 0, ndocs, nlexems_hint, (hipStream_t)stream, d_doc_ranges);
 		if (out)
 		{
 			out->ndocs = ndocs;

@@ -33,7 +33,8 @@ struct L2Params
 	// input
 	const uint32_t* lexems;		// sp_lexem_t[]: id, ordpos, origpos, origsize
 	const uint32_t* origseg;	// optional
-	const uint64_t* docOffsets;	// ndocs+1 lexem indices
+	const uint64_t* docOffsets;	// ndocs+1 lexem indices, or NULL when docRangesIn is given
+	const uint64_t* docRangesIn;	// ndocs x (first lexem, count): the lexer kernel's output layout
 	uint32_t ndocs;
 	uint32_t withItems;
 	// working memory

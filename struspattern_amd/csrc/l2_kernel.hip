@@ -727,8 +727,18 @@ void spa_l2_match_kernel( L2Params P)
 		w.ruleFree = 0; w.ruleUsed = 0; w.trigFree = 0; w.trigUsed = 0; w.itemFree = 0; w.itemUsed = 0;
 		w.refFree = 0; w.refUsed = 0; w.heapSize = 0; w.nFollow = 0; w.nDispose = 0; w.nStaged = 0; w.err = 0;
 
-		const u64 lbeg = ((u64)ldu( (const u32*)&P.docOffsets[ doc]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc]);
-		const u64 lend = ((u64)ldu( (const u32*)&P.docOffsets[ doc+1]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc+1]);
+		u64 lbeg, lend;
+		if (P.docRangesIn)
+		{
+			const u32* rp = (const u32*)&P.docRangesIn[ 2*(u64)doc];
+			lbeg = ((u64)ldu( rp+1) << 32) | ldu( rp);
+			lend = lbeg + (((u64)ldu( rp+3) << 32) | ldu( rp+2));
+		}
+		else
+		{
+			lbeg = ((u64)ldu( (const u32*)&P.docOffsets[ doc]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc]);
+			lend = ((u64)ldu( (const u32*)&P.docOffsets[ doc+1]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc+1]);
+		}
 		u32 curPosition = 0, nEvents = 0;
 		for (u64 lbase=lbeg; lbase<lend && !w.err; lbase+=64)
 		{

@@ -1,0 +1,168 @@
+// Ports of the reference's two known-answer tests to the C++ plugin interface of this build:
+// tests/simpleTokenPatternMatch/src/testSimpleTokenPatternMatch.cpp (6 sequence rules, 5 expected matches)
+// tests/charRegexMatch/src/testCharRegexMatch.cpp case 1 (36 expected lexems).
+// The expected values are read from the fixture files in tests/golden/ (argv[1], argv[2], flat
+// text form written by tests/test_host_shim.py) so that no reference test source lives here.
+// Also loads modstrus_analyzer_pattern.so through dlopen/dlsym("entryPoint") like the strus
+// module loader does.
+#include "strus/lib/pattern.hpp"
+#include "strus/errorBufferInterface.hpp"
+#include "strus/patternLexerInterface.hpp"
+#include "strus/patternMatcherInterface.hpp"
+#include "strus/analyzerModule.hpp"
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+class ErrorBuffer :public strus::ErrorBufferInterface
+{
+public:
+	ErrorBuffer() :m_has(false) { m_msg[0] = 0; }
+	virtual void report( int, const char* format, ...)
+	{
+		if (m_has) return;
+		va_list ap; va_start( ap, format); vsnprintf( m_msg, sizeof(m_msg), format, ap); va_end( ap);
+		m_has = true;
+	}
+	virtual bool hasError() const { return m_has; }
+	virtual const char* fetchError() { m_has = false; return m_msg; }
+private:
+	bool m_has; char m_msg[ 2048];
+};
+
+static std::vector<std::string> readLines( const char* path)
+{
+	std::ifstream in( path);
+	if (!in) throw std::runtime_error( std::string("cannot open ") + path);
+	std::vector<std::string> rt; std::string ln;
+	while (std::getline( in, ln)) rt.push_back( ln);
+	return rt;
+}
+
+// fixture line formats (tab separated):
+//   simple:  RULE name term1 var1 term2 var2 range   |  DOC id ordpos origpos  |  EXPECT name ordpos
+//   regex:   OPTION name | LEXEM id expr resultIndex level haspos | SYMBOL symid patid name | SRC text | EXPECT id ordpos origpos origsize
+static std::vector<std::string> split( const std::string& s)
+{
+	std::vector<std::string> rt; std::string cur;
+	for (size_t i=0; i<=s.size(); ++i) { if (i == s.size() || s[i] == '\t') { rt.push_back( cur); cur.clear(); } else cur.push_back( s[i]); }
+	return rt;
+}
+
+static void testSimpleTokenPatternMatch( strus::PatternMatcherInterface* pt, ErrorBuffer& err, const char* fixture)
+{
+	std::unique_ptr<strus::PatternMatcherInstanceInterface> inst( pt->createInstance());
+	if (!inst.get()) throw std::runtime_error( "failed to create pattern matcher instance");
+	std::vector<std::string> lines = readLines( fixture);
+	std::set<std::pair<std::string,unsigned> > expected;
+	std::vector<std::vector<std::string> > doc;
+	for (size_t i=0; i<lines.size(); ++i)
+	{
+		std::vector<std::string> f = split( lines[i]);
+		if (f[0] == "RULE")
+		{
+			inst->pushTerm( atoi( f[2].c_str())); inst->attachVariable( f[3]);
+			inst->pushTerm( atoi( f[4].c_str())); inst->attachVariable( f[5]);
+			inst->pushExpression( strus::PatternMatcherInstanceInterface::OpSequence, 2, atoi( f[6].c_str()), 0);
+			inst->definePattern( f[1], "", true);
+		}
+		else if (f[0] == "DOC") doc.push_back( f);
+		else if (f[0] == "EXPECT") expected.insert( std::make_pair( f[1], (unsigned)atoi( f[2].c_str())));
+	}
+	inst->compile();
+	if (err.hasError()) throw std::runtime_error( std::string("error creating automaton: ") + err.fetchError());
+	std::unique_ptr<strus::PatternMatcherContextInterface> ctx( inst->createContext());
+	if (!ctx.get()) throw std::runtime_error( std::string("failed to create context: ") + err.fetchError());
+	for (size_t i=0; i<doc.size(); ++i)
+	{
+		ctx->putInput( strus::analyzer::PatternLexem( atoi( doc[i][1].c_str()), atoi( doc[i][2].c_str()), strus::analyzer::Position( 0, atoi( doc[i][3].c_str())), 1));
+		if (err.hasError()) throw std::runtime_error( std::string("error matching rules: ") + err.fetchError());
+	}
+	std::vector<strus::analyzer::PatternMatcherResult> results = ctx->fetchResults();
+	if (err.hasError()) throw std::runtime_error( std::string("error fetching results: ") + err.fetchError());
+	std::set<std::pair<std::string,unsigned> > got;
+	for (size_t i=0; i<results.size(); ++i) got.insert( std::make_pair( std::string( results[i].name()), results[i].ordpos()));
+	if (got != expected) throw std::runtime_error( "simpleTokenPatternMatch: match set differs from the expected one");
+	double installed = -1;
+	strus::analyzer::PatternMatcherStatistics st = ctx->getStatistics();
+	for (size_t i=0; i<st.items().size(); ++i) if (!strcmp( st.items()[i].name(), "nofProgramsInstalled")) installed = st.items()[i].value();
+	std::cerr << "simpleTokenPatternMatch OK (" << results.size() << " results, " << installed << " programs installed)" << std::endl;
+}
+
+static void testCharRegexMatch( strus::PatternLexerInterface* pl, ErrorBuffer& err, const char* fixture)
+{
+	std::unique_ptr<strus::PatternLexerInstanceInterface> inst( pl->createInstance());
+	if (!inst.get()) throw std::runtime_error( "failed to create lexer instance");
+	std::vector<std::string> lines = readLines( fixture);
+	std::string src;
+	std::vector<std::vector<int> > expected;
+	for (size_t i=0; i<lines.size(); ++i)
+	{
+		std::vector<std::string> f = split( lines[i]);
+		if (f[0] == "OPTION") inst->defineOption( f[1], 0);
+		else if (f[0] == "LEXEM") inst->defineLexem( atoi( f[1].c_str()), f[2], atoi( f[3].c_str()), atoi( f[4].c_str()), atoi( f[5].c_str()) ? strus::analyzer::BindContent : strus::analyzer::BindPredecessor);
+		else if (f[0] == "SYMBOL") inst->defineSymbol( atoi( f[1].c_str()), atoi( f[2].c_str()), f[3]);
+		else if (f[0] == "SRC") src = f[1];
+		else if (f[0] == "EXPECT") { std::vector<int> e; for (int k=1; k<=4; ++k) e.push_back( atoi( f[k].c_str())); expected.push_back( e); }
+	}
+	if (!inst->compile()) throw std::runtime_error( std::string("error building term match automaton: ") + err.fetchError());
+	std::unique_ptr<strus::PatternLexerContextInterface> ctx( inst->createContext());
+	if (!ctx.get()) throw std::runtime_error( std::string("failed to create context: ") + err.fetchError());
+	std::vector<strus::analyzer::PatternLexem> result = ctx->match( src.c_str(), src.size());
+	if (result.empty() && err.hasError()) throw std::runtime_error( std::string("error matching: ") + err.fetchError());
+	if (result.size() != expected.size()) throw std::runtime_error( "charRegexMatch: number of lexems differs");
+	for (size_t i=0; i<result.size(); ++i)
+	{
+		if ((int)result[i].id() != expected[i][0] || (int)result[i].ordpos() != expected[i][1]
+		||  result[i].origpos().ofs() != expected[i][2] || (int)result[i].origsize() != expected[i][3])
+			throw std::runtime_error( "charRegexMatch: test failed");
+	}
+	// error convention: a broken expression is reported through the error buffer, compile() returns false
+	std::unique_ptr<strus::PatternLexerInstanceInterface> bad( pl->createInstance());
+	bad->defineLexem( 1, "(unbalanced", 0, 1, strus::analyzer::BindContent);
+	if (bad->compile() || !err.hasError()) throw std::runtime_error( "charRegexMatch: compile error not reported");
+	std::cerr << "charRegexMatch OK (" << result.size() << " lexems); compile error text: " << err.fetchError() << std::endl;
+}
+
+int main( int argc, const char** argv)
+{
+	try
+	{
+		if (argc < 4) { std::cerr << "usage: testStrusInterface <simple fixture> <regex fixture> <module .so>" << std::endl; return 2; }
+		ErrorBuffer err;
+		// 1. through the exported factory functions (libstrus_pattern)
+		std::unique_ptr<strus::PatternMatcherInterface> pt( strus::createPatternMatcher_std( &err));
+		std::unique_ptr<strus::PatternLexerInterface> pl( strus::createPatternLexer_std( &err));
+		if (!pt.get() || !pl.get()) throw std::runtime_error( "failed to create the interfaces");
+		testSimpleTokenPatternMatch( pt.get(), err, argv[1]);
+		testCharRegexMatch( pl.get(), err, argv[2]);
+		// 2. through the module entry point, like the strus module loader
+		void* mod = dlopen( argv[3], RTLD_NOW | RTLD_LOCAL);
+		if (!mod) throw std::runtime_error( std::string("dlopen failed: ") + dlerror());
+		strus::AnalyzerModule* ep = (strus::AnalyzerModule*)dlsym( mod, "entryPoint");
+		if (!ep) throw std::runtime_error( "module has no symbol entryPoint");
+		if (strcmp( ep->patternLexer->name, "std") || strcmp( ep->patternMatcher->name, "std")) throw std::runtime_error( "module constructors are not named std");
+		std::unique_ptr<strus::PatternMatcherInterface> pt2( ep->patternMatcher->create( &err));
+		std::unique_ptr<strus::PatternLexerInterface> pl2( ep->patternLexer->create( &err));
+		testSimpleTokenPatternMatch( pt2.get(), err, argv[1]);
+		testCharRegexMatch( pl2.get(), err, argv[2]);
+		std::cerr << "module entryPoint OK: " << ep->version3rdparty << std::endl;
+		std::cout << "OK" << std::endl;
+		return 0;
+	}
+	catch (const std::exception& e)
+	{
+		std::cerr << "ERROR " << e.what() << std::endl;
+		return 1;
+	}
+}

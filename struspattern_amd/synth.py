@@ -158,40 +158,47 @@ def text_documents(ndocs, docbytes, vocab, seed, utf8=False):
 
 def lexer_patterns(npatterns, vocab, seed):
     """Regex set modelled on the reference's test/doc patterns (tests/charRegexMatch :109-112, the
-    rule language example of the web page): list of (lexem id, expression, resultIndex, level, posbind)."""
+    rule language example of the web page): list of (lexem id, expression, resultIndex, level, posbind).
+    Expressions are distinct; about 1/4 (small sets) resp. 8/10 (>1024) are \\bWORD\\b literals of
+    the vocabulary (lexem id i+1 <-> vocabulary rank i+1), the rest are class / repeat / multi-word /
+    alternation patterns."""
     rng = np.random.default_rng(seed)
     out = []
+    seen = set()
     nlit = npatterns // 4 if npatterns <= 1024 else (npatterns * 8) // 10
-    for i in range(npatterns):
+    nlit = min(nlit, len(vocab))
+    generic = ["[0-9]+\\b", "\\b[A-Z][a-z]+\\b", "\\b[0-9]{1,3}'[0-9]{3}\\b", "\\b[0-9]{1,2}\\b"]
+    tries = 0
+    while len(out) < npatterns:
+        i = len(out)
         lid = i + 1
         level = 1 + int(rng.integers(0, 4))
         posbind = "content" if rng.random() < 0.85 else "predecessor"
         if i < nlit:
-            w = vocab[i % len(vocab)]
-            expr = "\\b" + w + "\\b"
-            if rng.random() < 0.1:
-                expr = "\\b" + w.capitalize() + "\\b"
+            expr = "\\b" + vocab[i] + "\\b"
+        elif generic:
+            expr = generic.pop(0)
         else:
-            fam = int(rng.integers(0, 8))
-            suf = "".join(_LETTERS[int(x)] for x in rng.integers(0, 12, size=int(rng.integers(2, 4))))
+            fam = int(rng.integers(0, 5))
+            suf = "".join(_LETTERS[int(x)] for x in rng.integers(0, 14, size=int(rng.integers(2, 4))))
             if fam == 0:
-                expr = "[0-9]+\\b"
-            elif fam == 1:
                 expr = "[a-z]+%s\\b" % suf
-            elif fam == 2:
-                expr = "\\b[A-Z][a-z]+\\b"
-            elif fam == 3:
-                expr = "\\b[0-9]{1,3}'[0-9]{3}\\b"
-            elif fam == 4:
+            elif fam == 1:
                 expr = "\\b%s[a-z]*\\b" % suf
-            elif fam == 5:
-                w2 = vocab[int(rng.integers(0, min(200, len(vocab))))]
+            elif fam == 2:
+                w2 = vocab[int(rng.integers(0, min(5000, len(vocab))))]
                 expr = "\\b%s\\s\\w+\\b" % w2
-            elif fam == 6:
-                a, b, c = (vocab[int(x)] for x in rng.integers(0, min(2000, len(vocab)), size=3))
+            elif fam == 3:
+                a, b, c = (vocab[int(x)] for x in rng.integers(0, len(vocab), size=3))
                 expr = "\\b(%s|%s|%s)\\b" % (a, b, c)
             else:
-                expr = "\\b[a-z]{%d}\\b" % int(rng.integers(2, 10))
+                expr = "\\b[A-Z]%s[a-z]*\\b" % suf[:2]
+        tries += 1
+        if expr in seen:
+            if tries > 50 * npatterns:
+                raise RuntimeError("cannot generate %d distinct expressions" % npatterns)
+            continue
+        seen.add(expr)
         out.append((lid, expr, 0, level, posbind))
     return out
 
@@ -202,3 +209,12 @@ def apply_lexer_patterns(lx, patterns, options=("DOTALL",)):
     for lid, expr, residx, level, posbind in patterns:
         lx.defineLexem(lid, expr, residx, level, posbind)
     lx.compile()
+
+
+def pipeline_workload(npatterns, nrules, vocab, seed):
+    """Config 5 of BASELINE.json: `npatterns` regexes (plus the sentence delimiter lexem) feeding
+    `nrules` two-term token rules over the lexem ids.  Returns (lexer patterns, rules)."""
+    pats = lexer_patterns(npatterns, vocab, seed)
+    pats.append((DELIM, "[.]", 0, 5, "content"))
+    rules = random_rules(nrules, npatterns, seed + 1)
+    return pats, rules
