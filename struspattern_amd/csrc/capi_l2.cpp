@@ -58,6 +58,10 @@ void layoutArena( ArenaLayout& L)
 	L.oRefs = o;	o += alignUp( L.maxRefs*2, 4);
 	L.oGStack = o;	o += alignUp( L.maxGStack, 4);
 	L.oStaged = o;	o += alignUp( L.maxStaged*8, 4);
+	L.oRuleFree = o; o += alignUp( L.maxRules, 4);
+	L.oTrigFree = o; o += alignUp( L.maxTrigs, 4);
+	L.oItemFree = o; o += alignUp( L.maxItems, 4);
+	L.oRefFree = o;	o += alignUp( L.maxRefs, 4);
 	L.totalWords = alignUp( o, 64);
 }
 

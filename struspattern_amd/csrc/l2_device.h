@@ -17,7 +17,7 @@ enum {SPC_RESULTS=0, SPC_ITEMS=1, SPC_EVENTS=2, SPC_FAILED=3, SPC_COUNT=8};
 struct ArenaLayout
 {
 	uint32_t maxRules, maxTrigs, bucketCap, maxItems, maxRefs, maxFollow, maxDispose, maxHeap, maxGStack, maxStaged, nStop;
-	uint32_t oRules, oTrigs, oBEvent, oBIdx, oBSize, oWindow, oHeap, oFollow, oDispose, oStop, oItems, oRefs, oGStack, oStaged;
+	uint32_t oRules, oTrigs, oBEvent, oBIdx, oBSize, oWindow, oHeap, oFollow, oDispose, oStop, oItems, oRefs, oGStack, oStaged, oRuleFree, oTrigFree, oItemFree, oRefFree;
 	uint32_t totalWords;
 };
 

@@ -70,9 +70,10 @@ struct WS		// per-wave state, lives in registers
 {
 	Rule* rules; Trig* trigs; u32* bEvent; u32* bIdx; u32* bSize; u32* window; u32* heap;
 	Follow* follow; u32* dispose; StopLog* stop; Item* items; u32* refs; u32* gstack; StagedResult* staged;
+	u32* ruleFree; u32* trigFree; u32* itemFree; u32* refFree;	// stacks of free record indices
 	u32 curpos, timestamp, nInstalled, nAlt, nSignals, nTrig;
 	u64 open;
-	u32 ruleFree, ruleUsed, trigFree, trigUsed, itemFree, itemUsed, refFree, refUsed;
+	u32 ruleFreeN, ruleUsed, trigFreeN, trigUsed, itemFreeN, itemUsed, refFreeN, refUsed;
 	u32 heapSize, nFollow, nDispose, nStaged, err;
 };
 
@@ -96,31 +97,37 @@ __device__ __forceinline__ void ldEv( EvData& d, const EvData* p)
 	d.sord = ldu( &p->sord); d.eord = ldu( &p->eord); d.sub = ldu( &p->sub); d.fmt = ldu( &p->fmt);
 }
 
-// ---------------------------------------------------------------- allocators (order is not observable)
+// ---------------------------------------------------------------- allocators
+// Which index a new record gets is not observable (only list orders are), so freed indices are
+// kept on plain stacks: a whole batch of lanes can pop its indices with one gather.
 __device__ __forceinline__ u32 allocRule( WS& w, const L2Params& P)
 {
 	u32 r;
-	if (w.ruleFree) { r = w.ruleFree-1; w.ruleFree = ldu( &w.rules[ r].next); }
+	if (w.ruleFreeN) { r = ldu( &w.ruleFree[ --w.ruleFreeN]); }
 	else if (w.ruleUsed < P.arena.maxRules) { r = w.ruleUsed++; }
 	else { w.err = SPD_ERR_ARENA; r = 0; }
 	return r;
 }
 __device__ __forceinline__ void freeRule( WS& w, u32 r)
 {
-	w.rules[ r].next = w.ruleFree; w.ruleFree = r+1;
+	w.ruleFree[ w.ruleFreeN++] = r;
 }
 __device__ __forceinline__ u32 allocTrig( WS& w, const L2Params& P)
 {
 	u32 t;
-	if (w.trigFree) { t = w.trigFree-1; w.trigFree = ldu( &w.trigs[ t].next); }
+	if (w.trigFreeN) { t = ldu( &w.trigFree[ --w.trigFreeN]); }
 	else if (w.trigUsed < P.arena.maxTrigs) { t = w.trigUsed++; }
 	else { w.err = SPD_ERR_ARENA; t = 0; }
 	return t;
 }
+__device__ __forceinline__ void freeTrig( WS& w, u32 t)
+{
+	w.trigFree[ w.trigFreeN++] = t;
+}
 __device__ __forceinline__ u32 allocItem( WS& w, const L2Params& P)
 {
 	u32 t;
-	if (w.itemFree) { t = w.itemFree-1; w.itemFree = ldu( &w.items[ t].next); }
+	if (w.itemFreeN) { t = ldu( &w.itemFree[ --w.itemFreeN]); }
 	else if (w.itemUsed < P.arena.maxItems) { t = w.itemUsed++; }
 	else { w.err = SPD_ERR_ARENA; t = 0; }
 	return t;
@@ -129,7 +136,7 @@ __device__ __forceinline__ u32 allocItem( WS& w, const L2Params& P)
 __device__ __forceinline__ u32 createRef( WS& w, const L2Params& P)	// cpp:750-753
 {
 	u32 t;
-	if (w.refFree) { t = w.refFree-1; w.refFree = ldu( &w.refs[ 2*t]); }
+	if (w.refFreeN) { t = ldu( &w.refFree[ --w.refFreeN]); }
 	else if (w.refUsed < P.arena.maxRefs) { t = w.refUsed++; }
 	else { w.err = SPD_ERR_ARENA; return 0; }
 	w.refs[ 2*t] = 0; w.refs[ 2*t+1] = 1;
@@ -148,11 +155,11 @@ __device__ void disposeRef( WS& w, u32 ref)				// cpp:710-732
 		{
 			if (guard > w.itemUsed) { w.err = SPD_ERR_INTERNAL; break; }
 			u32 nx = ldu( &w.items[ it-1].next);
-			w.items[ it-1].next = w.itemFree; w.itemFree = it;
+			w.itemFree[ w.itemFreeN++] = it-1;
 			it = nx;
 		}
 		w.refs[ 2*(ref-1)+1] = 0;
-		w.refs[ 2*(ref-1)] = w.refFree; w.refFree = ref;
+		w.refFree[ w.refFreeN++] = ref-1;
 	}
 	else { w.err = SPD_ERR_DATAREF; }
 }
@@ -222,7 +229,7 @@ __device__ void deactivateRule( WS& w, const L2Params& P, u32 r)	// cpp:679-702
 			if (guard > w.trigUsed) { w.err = SPD_ERR_INTERNAL; break; }
 			u32 nx = ldu( &w.trigs[ t-1].next);
 			removeTrigger( w, P, t-1);
-			w.trigs[ t-1].next = w.trigFree; w.trigFree = t;
+			freeTrig( w, t-1);
 			t = nx;
 		}
 		R->trigHead = 0;
@@ -598,6 +605,302 @@ __device__ void installProgram( WS& w, const L2Params& P, u32 keyevent, const De
 	}
 }
 
+
+// ---------------------------------------------------------------- lane-parallel installation
+// installEventPrograms (cpp:1137-1157) for up to 64 programs at a time: lane l instantiates program
+// l of the batch.  Everything whose ORDER is observable is placed exactly where the sequential
+// loop would have put it -- bucket positions, per-position dispose lists, follow events, results,
+// dispose entries all advance in lane order (= program order) through ballots and prefix sums.
+// Programs that need the rare machinery (alternative key replay, far expiry heap, more than MAXT
+// trigger templates, several key triggers, sub-match data to join) send their whole batch down
+// the sequential path, which keeps the order intact.
+enum {MAXT=3};
+
+__device__ __forceinline__ u64 lanesBelow() { return (1ull << LANE) - 1ull; }
+__device__ __forceinline__ u32 byteSum( u32 v) { return (v & 0xFFu) + ((v >> 8) & 0xFFu) + ((v >> 16) & 0xFFu) + (v >> 24); }
+__device__ __forceinline__ u32 byteField( u32 c0, u32 c1, u32 c2, u32 c3, u32 h)
+{
+	u32 wsel = h >> 2;
+	u32 v = wsel == 0 ? c0 : wsel == 1 ? c1 : wsel == 2 ? c2 : c3;
+	return (v >> ((h & 3u)*8)) & 0xFFu;
+}
+
+__device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u32 lc, const EvData& d)
+{
+	for (u32 base=0; base<lc && !w.err; base+=64)
+	{
+		const u32 nb = (lc - base) < 64u ? (lc - base) : 64u;
+		const bool have = LANE < nb;
+		u32 program = 0, pastEvent = 0;
+		u32 g_initsigval = 0, g_count = 0, g_event = 0, g_handle = 0, g_fmt = 0, g_range = 0, g_tb = 0, g_tc = 0;
+		if (have)
+		{
+			const DevKeyRef* K = &P.keylist[ lb + base + LANE];
+			program = K->program; pastEvent = K->pastEvent;
+			const DevProgram* G = &P.programs[ program];
+			g_initsigval = G->initsigval; g_count = G->initcount & 0xFFFFu; g_event = G->event; g_handle = G->resultHandle;
+			g_fmt = G->formatHandle; g_range = G->positionRange; g_tb = G->trigBegin; g_tc = G->trigCount;
+		}
+		const u32 expiry = d.sord + g_range;
+		const bool live = have && !(expiry < w.curpos);			// cpp:1171-1181
+
+		// trigger templates of my program (cpp:1204-1250)
+		u32 tEvent[ MAXT], tSigval[ MAXT], tTypevar[ MAXT];
+		bool tInstall[ MAXT], tKey[ MAXT];
+		u32 nofKey = 0;
+		bool hasKey = false;
+#pragma unroll
+		for (int j=0; j<MAXT; ++j)
+		{
+			tInstall[ j] = false; tKey[ j] = false; tEvent[ j] = 0; tSigval[ j] = 0; tTypevar[ j] = 0;
+			if (live && (u32)j < g_tc)
+			{
+				const DevTrigDef* D = &P.trigdefs[ g_tb + j];
+				u32 tev = D->event, fl = D->flags, sigtype = fl & 15u;
+				tEvent[ j] = tev; tSigval[ j] = D->sigval; tTypevar[ j] = sigtype | (D->variable << 4);
+				bool doInstall;
+				if (tev == keyevent)
+				{
+					tKey[ j] = true; ++nofKey;
+					bool needs = (sigtype == SIG_ANY && g_count > 1);
+					if ((fl & 0x100u) && !hasKey) { hasKey = true; doInstall = needs; }
+					else if (sigtype == SIG_DEL) doInstall = needs;
+					else doInstall = true;
+				}
+				else doInstall = true;
+				tInstall[ j] = doInstall;
+			}
+		}
+		const bool slow = live && (pastEvent != 0 || expiry >= w.curpos + 64u || g_tc > (u32)MAXT || nofKey > 1);
+		if (__ballot( slow))
+		{
+			for (u32 kk=0; kk<nb && !w.err; ++kk) installProgram( w, P, keyevent, &P.keylist[ lb+base+kk], d);
+			continue;
+		}
+		const u64 liveMask = __ballot( live);
+		if (!liveMask) continue;
+		const u32 nlive = (u32)__popcll( liveMask);
+		const u32 rank = (u32)__popcll( liveMask & lanesBelow());
+
+		// ---- rule records: pop from the free stack, then bump
+		u32 r = 0;
+		{
+			const u32 fromStack = w.ruleFreeN < nlive ? w.ruleFreeN : nlive;
+			const u32 bump = nlive - fromStack;
+			if (w.ruleUsed + bump > P.arena.maxRules) { w.err = SPD_ERR_ARENA; return; }
+			if (live) r = rank < fromStack ? w.ruleFree[ w.ruleFreeN - 1 - rank] : w.ruleUsed + (rank - fromStack);
+			w.ruleFreeN -= fromStack; w.ruleUsed += bump;
+		}
+		// ---- dispose window (cpp:1072-1076): each position's list grows at its head in program order
+		const u32 widx = expiry & 63u;
+		u32 nextLink = 0;
+		{
+			u64 todo = liveMask;
+			while (todo)
+			{
+				const u32 leader = (u32)__builtin_ctzll( todo);
+				const u32 wsel = (u32)__builtin_amdgcn_readlane( widx, leader);
+				const bool mine = live && widx == wsel;
+				const u64 grp = __ballot( mine);
+				const u32 oldHead = ldu( &w.window[ wsel]);
+				const u64 below = grp & lanesBelow();
+				const u32 srcLane = below ? 63u - (u32)__builtin_clzll( below) : LANE;
+				const u32 prevRule = __shfl( r, srcLane);
+				if (mine) nextLink = below ? prevRule + 1 : oldHead;
+				const u32 headLane = 63u - (u32)__builtin_clzll( grp);
+				w.window[ wsel] = (u32)__builtin_amdgcn_readlane( r, headLane) + 1;
+				todo &= ~grp;
+			}
+		}
+		// ---- triggers: bucket positions in (program, template) order
+		u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;		// my installs per bucket, 16 x 8 bit
+		u32 hB[ MAXT];
+#pragma unroll
+		for (int j=0; j<MAXT; ++j)
+		{
+			hB[ j] = evhash( tEvent[ j]) & 15u;
+			if (tInstall[ j])
+			{
+				u32 inc = 1u << ((hB[ j] & 3u)*8);
+				u32 ws = hB[ j] >> 2;
+				if (ws == 0) c0 += inc; else if (ws == 1) c1 += inc; else if (ws == 2) c2 += inc; else c3 += inc;
+			}
+		}
+		u32 i0 = c0, i1 = c1, i2 = c2, i3 = c3;		// inclusive prefix sums over the lanes (fields stay < 256: 64 x MAXT)
+		for (int dd=1; dd<64; dd<<=1)
+		{
+			u32 u0 = __shfl_up( i0, dd), u1 = __shfl_up( i1, dd), u2 = __shfl_up( i2, dd), u3 = __shfl_up( i3, dd);
+			if ((int)LANE >= dd) { i0 += u0; i1 += u1; i2 += u2; i3 += u3; }
+		}
+		const u32 e0 = i0 - c0, e1 = i1 - c1, e2 = i2 - c2, e3 = i3 - c3;
+		const u32 t0 = (u32)__builtin_amdgcn_readlane( i0, 63), t1 = (u32)__builtin_amdgcn_readlane( i1, 63);
+		const u32 t2 = (u32)__builtin_amdgcn_readlane( i2, 63), t3 = (u32)__builtin_amdgcn_readlane( i3, 63);
+		const u32 trigBefore = byteSum( e0 + e1 + e2 + e3);
+		const u32 totalTrig = byteSum( t0 + t1 + t2 + t3);
+		const u32 trigFromStack = w.trigFreeN < totalTrig ? w.trigFreeN : totalTrig;
+		if (w.trigUsed + (totalTrig - trigFromStack) > P.arena.maxTrigs) { w.err = SPD_ERR_ARENA; return; }
+		u32 head = 0, local = 0;
+		bool overflow = false;
+#pragma unroll
+		for (int j=0; j<MAXT; ++j)
+		{
+			if (tInstall[ j])
+			{
+				const u32 h = hB[ j];
+				u32 same = 0;
+#pragma unroll
+				for (int jj=0; jj<j; ++jj) if (tInstall[ jj] && hB[ jj] == h) ++same;
+				const u32 pos = w.bSize[ h] + byteField( e0, e1, e2, e3, h) + same;
+				const u32 seq = trigBefore + local;
+				const u32 t = seq < trigFromStack ? w.trigFree[ w.trigFreeN - 1 - seq] : w.trigUsed + (seq - trigFromStack);
+				if (pos >= P.arena.bucketCap) overflow = true;
+				else
+				{
+					w.bEvent[ h*P.arena.bucketCap + pos] = tEvent[ j];
+					w.bIdx[ h*P.arena.bucketCap + pos] = t;
+					Trig* T = &w.trigs[ t];
+					T->event = tEvent[ j]; T->rule = r; T->sigval = tSigval[ j]; T->typevar = tTypevar[ j];
+					T->link = (h << 28) | pos; T->next = head;
+					head = t+1;
+				}
+				++local;
+			}
+		}
+		if (__ballot( overflow)) { w.err = SPD_ERR_ARENA; return; }
+		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+		if (LANE < 16) w.bSize[ LANE] += byteField( t0, t1, t2, t3, LANE);
+		w.trigFreeN -= trigFromStack; w.trigUsed += totalTrig - trigFromStack;
+		w.nTrig += totalTrig;
+		w.nInstalled += nlive;
+
+		// ---- the key trigger fires on the fresh slot (cpp:1259-1269 -> fireSignal cpp:772-979), in registers
+		u32 value = g_initsigval, count = g_count, flags = F_ACTIVE, end_ordpos = 0;
+		u32 start_ordpos = 0, start_origseg = 0, start_origpos = 0, dataRef = 0;
+		bool match = false, take = false, fin = false, del = false;
+		u32 keyVariable = 0;
+#pragma unroll
+		for (int j=0; j<MAXT; ++j)
+		{
+			if (tKey[ j])
+			{
+				const u32 sigtype = tTypevar[ j] & 15u, sigval = tSigval[ j];
+				keyVariable = tTypevar[ j] >> 4;
+				switch (sigtype)
+				{
+					case SIG_ANY:
+						take = true;
+						if (count > 0) { match = true; --count; fin = (count == 0); if (end_ordpos < d.eord) end_ordpos = d.eord; }
+						break;
+					case SIG_AND:
+						if (count > 0)
+						{
+							if (!value) { value = d.sord; if (end_ordpos > d.eord) end_ordpos = d.eord; }
+							if (value == d.sord) { match = true; --count; fin = (count == 0); take = true; }
+						}
+						break;
+					case SIG_SEQUENCE:
+					case SIG_SEQUENCE_IMM:
+						if (sigval == value && ((sigtype == SIG_SEQUENCE) ? (end_ordpos <= d.sord) : (end_ordpos == d.sord)))
+						{
+							end_ordpos = d.eord; value = sigval-1;
+							if (count > 0) { --count; match = (count == 0); } else match = true;
+							fin = (value == 0); take = true;
+						}
+						break;
+					case SIG_WITHIN:
+						if ((sigval & value) != 0 && end_ordpos <= d.sord)
+						{
+							end_ordpos = d.eord; value &= ~sigval;
+							if (count > 0) { --count; match = (count == 0); } else match = true;
+							fin = (value == 0); take = true;
+						}
+						break;
+					default:	// SIG_DEL
+						count = 0; value = 0; del = true;
+						break;
+				}
+			}
+		}
+		if (del) { match = false; take = false; fin = false; }
+		w.nSignals += (u32)__popcll( __ballot( live && nofKey));
+		if (take) { start_ordpos = d.sord; start_origseg = d.sseg; start_origpos = d.spos; }
+		// captured variable: one item + one data reference per lane that needs them
+		const bool wantItem = P.withItems && live && take && keyVariable != 0;
+		const bool emitFollow = live && match && g_event != 0;
+		const bool emitResult = live && match && g_handle != 0;
+		{
+			const u64 im = __ballot( wantItem);
+			if (im)
+			{
+				const u32 ni = (u32)__popcll( im), ri = (u32)__popcll( im & lanesBelow());
+				const u32 itemFromStack = w.itemFreeN < ni ? w.itemFreeN : ni;
+				const u32 refFromStack = w.refFreeN < ni ? w.refFreeN : ni;
+				if (w.itemUsed + (ni - itemFromStack) > P.arena.maxItems || w.refUsed + (ni - refFromStack) > P.arena.maxRefs) { w.err = SPD_ERR_ARENA; return; }
+				if (wantItem)
+				{
+					const u32 it = ri < itemFromStack ? w.itemFree[ w.itemFreeN - 1 - ri] : w.itemUsed + (ri - itemFromStack);
+					const u32 rf = ri < refFromStack ? w.refFree[ w.refFreeN - 1 - ri] : w.refUsed + (ri - refFromStack);
+					Item* I = &w.items[ it];
+					I->variable = keyVariable; I->next = 0; I->d = d;
+					w.refs[ 2*rf] = it+1;
+					w.refs[ 2*rf+1] = 1u + (emitFollow ? 1u : 0u) + (emitResult ? 1u : 0u);	// rule + follow + result (cpp:941-953)
+					dataRef = rf+1;
+				}
+				w.itemFreeN -= itemFromStack; w.itemUsed += ni - itemFromStack;
+				w.refFreeN -= refFromStack; w.refUsed += ni - refFromStack;
+			}
+		}
+		if (match) flags |= F_DONE;
+		{
+			const u64 fm = __ballot( emitFollow);
+			if (fm)
+			{
+				const u32 nf = (u32)__popcll( fm);
+				if (w.nFollow + nf > P.arena.maxFollow) { w.err = SPD_ERR_ARENA; return; }
+				if (emitFollow)
+				{
+					Follow* F = &w.follow[ w.nFollow + (u32)__popcll( fm & lanesBelow())];
+					F->d.sseg = start_origseg; F->d.spos = start_origpos; F->d.eseg = d.eseg; F->d.epos = d.epos;
+					F->d.sord = start_ordpos; F->d.eord = end_ordpos; F->d.sub = dataRef; F->d.fmt = g_fmt;
+					F->event = g_event;
+				}
+				w.nFollow += nf;
+			}
+			const u64 rm = __ballot( emitResult);
+			if (rm)
+			{
+				const u32 nr = (u32)__popcll( rm);
+				if (w.nStaged + nr > P.arena.maxStaged) { w.err = SPD_ERR_ARENA; return; }
+				if (emitResult)
+				{
+					StagedResult* S = &w.staged[ w.nStaged + (u32)__popcll( rm & lanesBelow())];
+					S->handle = g_handle; S->sord = start_ordpos; S->eord = end_ordpos;
+					S->sseg = start_origseg; S->spos = start_origpos; S->eseg = d.eseg; S->epos = d.epos;
+					S->dataRef = dataRef;
+				}
+				w.nStaged += nr;
+			}
+			const bool wantDispose = live && (del || (match && fin));
+			const u64 dm = __ballot( wantDispose);
+			if (dm)
+			{
+				const u32 nd = (u32)__popcll( dm);
+				if (w.nDispose + nd > P.arena.maxDispose) { w.err = SPD_ERR_ARENA; return; }
+				if (wantDispose) w.dispose[ w.nDispose + (u32)__popcll( dm & lanesBelow())] = r;
+				w.nDispose += nd;
+			}
+		}
+		if (live)
+		{
+			Rule* R = &w.rules[ r];
+			R->value = value; R->count = count; R->flags = flags; R->start_ordpos = start_ordpos;
+			R->end_ordpos = end_ordpos; R->start_origseg = start_origseg; R->start_origpos = start_origpos; R->program = program;
+			R->trigHead = head; R->dataRef = dataRef; R->next = nextLink; R->expiry = expiry;
+		}
+		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+	}
+}
+
 // ---------------------------------------------------------------- doTransition (cpp:981-1064)
 __device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData& data)
 {
@@ -643,7 +946,8 @@ __device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData&
 			stopIdx = ldu( &e->stopIdx);
 			u32 lb = ldu( &e->listBegin), lc = ldu( &e->listCount);
 			TRACE2( 10, lc);
-			for (u32 k=0; k<lc && !w.err; ++k) { TRACE2( 11, k); installProgram( w, P, ev, &P.keylist[ lb+k], d); }
+			if (lc >= 4 && !(P.withItems && d.sub)) installBatch( w, P, ev, lb, lc, d);
+			else for (u32 k=0; k<lc && !w.err; ++k) { TRACE2( 11, k); installProgram( w, P, ev, &P.keylist[ lb+k], d); }
 		}
 		TRACE2( 9, 3);
 		// deactivate rules that finished or were deleted
@@ -713,6 +1017,8 @@ void spa_l2_match_kernel( L2Params P)
 	w.dispose = A + P.arena.oDispose;	w.stop = (StopLog*)(A + P.arena.oStop);
 	w.items = (Item*)(A + P.arena.oItems);	w.refs = A + P.arena.oRefs;
 	w.gstack = A + P.arena.oGStack;		w.staged = (StagedResult*)(A + P.arena.oStaged);
+	w.ruleFree = A + P.arena.oRuleFree;	w.trigFree = A + P.arena.oTrigFree;
+	w.itemFree = A + P.arena.oItemFree;	w.refFree = A + P.arena.oRefFree;
 
 	// documents are dealt round-robin to the resident waves (document d -> wave d mod nwaves)
 	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
@@ -724,8 +1030,8 @@ void spa_l2_match_kernel( L2Params P)
 		w.window[ LANE] = 0;
 		for (u32 s=LANE; s<P.nofStopWords; s+=64) w.stop[ s].timestamp = 0;
 		w.curpos = 0; w.timestamp = 0; w.nInstalled = 0; w.nAlt = 0; w.nSignals = 0; w.nTrig = 0; w.open = 0;
-		w.ruleFree = 0; w.ruleUsed = 0; w.trigFree = 0; w.trigUsed = 0; w.itemFree = 0; w.itemUsed = 0;
-		w.refFree = 0; w.refUsed = 0; w.heapSize = 0; w.nFollow = 0; w.nDispose = 0; w.nStaged = 0; w.err = 0;
+		w.ruleFreeN = 0; w.ruleUsed = 0; w.trigFreeN = 0; w.trigUsed = 0; w.itemFreeN = 0; w.itemUsed = 0;
+		w.refFreeN = 0; w.refUsed = 0; w.heapSize = 0; w.nFollow = 0; w.nDispose = 0; w.nStaged = 0; w.err = 0;
 
 		u64 lbeg, lend;
 		if (P.docRangesIn)
