@@ -161,7 +161,7 @@ class PatternMatcherContext:
         rc = self._L.sp_matcher_ctx_batch_counters(self._h, arr)
         if rc != 0:
             raise PatternError("reading batch counters failed: " + self._err())
-        return {"results": arr[0], "items": arr[1], "events": arr[2], "failed_docs": arr[3]}
+        return {"results": arr[0], "items": arr[1], "events": arr[2], "failed_docs": arr[3], "prof": [arr[4], arr[5], arr[6], arr[7]]}
 
     def batchStatus(self, ndocs):
         st = np.zeros(ndocs, np.int32)

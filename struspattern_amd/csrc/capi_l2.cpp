@@ -62,6 +62,8 @@ void layoutArena( ArenaLayout& L)
 	L.oTrigFree = o; o += alignUp( L.maxTrigs, 4);
 	L.oItemFree = o; o += alignUp( L.maxItems, 4);
 	L.oRefFree = o;	o += alignUp( L.maxRefs, 4);
+	L.oWinArr = o;	o += alignUp( 64*L.winCap, 4);
+	L.oScratch = o;	o += alignUp( 16*L.scratchCap, 4);
 	L.totalWords = alignUp( o, 64);
 }
 
@@ -100,7 +102,7 @@ struct sp_matcher_ctx
 		// defaults sized for 10k-rule tables over ~1000-token documents; sp_matcher_ctx_set_arena overrides
 		arena.maxRules = 8192; arena.maxTrigs = 8192; arena.bucketCap = 2048; arena.maxItems = 16384;
 		arena.maxRefs = 8192; arena.maxFollow = 1024; arena.maxDispose = 2048; arena.maxHeap = 8192;
-		arena.maxGStack = 256; arena.maxStaged = 8192;
+		arena.maxGStack = 256; arena.maxStaged = 8192; arena.winCap = 1024; arena.scratchCap = 256;
 	}
 };
 
@@ -293,7 +295,7 @@ int sp_matcher_ctx_grow_arena( sp_matcher_ctx_t* c)
 	if (c->arena.maxRules >= (1u<<20)) { c->lasterror = "arena at its maximum size"; return SP_ERR_INVALID; }
 	c->arena.maxRules *= 2; c->arena.maxTrigs *= 2; c->arena.bucketCap *= 2; c->arena.maxItems *= 2;
 	c->arena.maxRefs *= 2; c->arena.maxFollow *= 2; c->arena.maxDispose *= 2; c->arena.maxHeap *= 2;
-	c->arena.maxStaged *= 2; c->arena.maxGStack *= 2;
+	c->arena.maxStaged *= 2; c->arena.maxGStack *= 2; c->arena.winCap *= 2;
 	c->arenaWaves = 0;
 	return SP_OK;
 }

@@ -16,8 +16,8 @@ enum {SPC_RESULTS=0, SPC_ITEMS=1, SPC_EVENTS=2, SPC_FAILED=3, SPC_COUNT=8};
 // item 12, follow 12, stop-log 12, staged result 8, data reference 2, heap entry 2.
 struct ArenaLayout
 {
-	uint32_t maxRules, maxTrigs, bucketCap, maxItems, maxRefs, maxFollow, maxDispose, maxHeap, maxGStack, maxStaged, nStop;
-	uint32_t oRules, oTrigs, oBEvent, oBIdx, oBSize, oWindow, oHeap, oFollow, oDispose, oStop, oItems, oRefs, oGStack, oStaged, oRuleFree, oTrigFree, oItemFree, oRefFree;
+	uint32_t maxRules, maxTrigs, bucketCap, maxItems, maxRefs, maxFollow, maxDispose, maxHeap, maxGStack, maxStaged, nStop, winCap, scratchCap;
+	uint32_t oRules, oTrigs, oBEvent, oBIdx, oBSize, oWindow, oHeap, oFollow, oDispose, oStop, oItems, oRefs, oGStack, oStaged, oRuleFree, oTrigFree, oItemFree, oRefFree, oWinArr, oScratch;
 	uint32_t totalWords;
 };
 

@@ -40,6 +40,14 @@ typedef uint64_t u64;
 #else
 #define TRACE( SLOT, VALUE) do {} while (0)
 #endif
+// Phase profile (make PROF=1): wave-cycles per phase summed into counters[4..7]
+#ifdef SPA_PROF
+#define PROF_DECL u64 prof_t0 = __builtin_amdgcn_s_memtime()
+#define PROF_ADD( SLOT) do { u64 prof_t1 = __builtin_amdgcn_s_memtime(); w.prof[ SLOT] += prof_t1 - prof_t0; prof_t0 = prof_t1; } while (0)
+#else
+#define PROF_DECL do {} while (0)
+#define PROF_ADD( SLOT) do {} while (0)
+#endif
 #ifdef SPA_TRACE2
 #define TRACE2( SLOT, VALUE) TRACE( SLOT, VALUE)
 #else
@@ -68,13 +76,16 @@ struct StagedResult { u32 handle, sord, eord, sseg, spos, eseg, epos, dataRef; }
 
 struct WS		// per-wave state, lives in registers
 {
-	Rule* rules; Trig* trigs; u32* bEvent; u32* bIdx; u32* bSize; u32* window; u32* heap;
+	Rule* rules; Trig* trigs; u32* bEvent; u32* bIdx; u32* bSize; u32* window; u32* winArr; u32* scratch; u32* heap;
 	Follow* follow; u32* dispose; StopLog* stop; Item* items; u32* refs; u32* gstack; StagedResult* staged;
 	u32* ruleFree; u32* trigFree; u32* itemFree; u32* refFree;	// stacks of free record indices
 	u32 curpos, timestamp, nInstalled, nAlt, nSignals, nTrig;
 	u64 open;
 	u32 ruleFreeN, ruleUsed, trigFreeN, trigUsed, itemFreeN, itemUsed, refFreeN, refUsed;
 	u32 heapSize, nFollow, nDispose, nStaged, err;
+#ifdef SPA_PROF
+	u64 prof[4];
+#endif
 };
 
 __device__ __forceinline__ u32 evhash( u32 a)		// src/ruleMatcherAutomaton.cpp:34-40
@@ -238,6 +249,224 @@ __device__ void deactivateRule( WS& w, const L2Params& P, u32 r)	// cpp:679-702
 	}
 }
 
+
+__device__ __forceinline__ u64 lanesBelow() { return (1ull << LANE) - 1ull; }
+__device__ __forceinline__ u32 byteSum( u32 v) { return (v & 0xFFu) + ((v >> 8) & 0xFFu) + ((v >> 16) & 0xFFu) + (v >> 24); }
+__device__ __forceinline__ u32 byteField( u32 c0, u32 c1, u32 c2, u32 c3, u32 h)
+{
+	u32 wsel = h >> 2;
+	u32 v = wsel == 0 ? c0 : wsel == 1 ? c1 : wsel == 2 ? c2 : c3;
+	return (v >> ((h & 3u)*8)) & 0xFFu;
+}
+
+// ---------------------------------------------------------------- batched deactivation
+// deactivateRule (cpp:679-702) for a list of rules, in list order.  The only order-dependent part
+// is the swap-with-last removal of triggers from the 16 buckets; removals in different buckets do
+// not interact, so after a stable partition of the triggers by bucket, lane b replays bucket b's
+// removals in their original order while the other 15 buckets advance in the other lanes.
+// Everything else (clearing the rule, releasing trigger / item / reference records) has no observable
+// order and is done one rule per lane.
+enum {DEACT_MAXCHAIN=4};
+
+__device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 n, bool reversed, bool freeRules, bool checkDup)
+{
+	for (u32 base=0; base<n && !w.err; base+=64)
+	{
+		const u32 nb = (n - base) < 64u ? (n - base) : 64u;
+		const bool have = LANE < nb;
+		u32 r = 0;
+		if (have) r = reversed ? list[ n - 1 - (base + LANE)] : list[ base + LANE];
+		bool act = false;
+		u32 head = 0, ref = 0;
+		if (have)
+		{
+			Rule* R = &w.rules[ r];
+			u32 flags = R->flags;
+			act = (flags & F_ACTIVE) != 0;
+			if (act) { head = R->trigHead; ref = R->dataRef; }
+		}
+		if (checkDup)
+		{
+			// the same rule may be listed twice (deleted and finished in one step): only its first entry acts
+			for (u32 k=0; k+1<nb; ++k)
+			{
+				u32 rk = (u32)__builtin_amdgcn_readlane( r, k);
+				if (LANE > k && have && r == rk) act = false;
+			}
+			// ... and entries of earlier 64-blocks have already cleared F_ACTIVE in memory
+		}
+		if (act)
+		{
+			Rule* R = &w.rules[ r];
+			R->flags = R->flags & ~F_ACTIVE; R->trigHead = 0; R->dataRef = 0;
+		}
+		// trigger chains (short: one per installed template)
+		u32 t[ DEACT_MAXCHAIN]; u32 nt = 0; bool longChain = false;
+#pragma unroll
+		for (int c=0; c<DEACT_MAXCHAIN; ++c)
+		{
+			t[ c] = 0;
+			if (act && head) { t[ c] = head-1; head = w.trigs[ head-1].next; ++nt; }
+		}
+		if (act && head) longChain = true;
+		if (__ballot( longChain))
+		{
+			// rare: finish this block one rule at a time (flags were cleared above: restore, then serial)
+			if (act) { Rule* R = &w.rules[ r]; R->flags = R->flags | F_ACTIVE; R->trigHead = t[0]+1; R->dataRef = ref; }
+			__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+			for (u32 k=0; k<nb && !w.err; ++k)
+			{
+				u32 rk = (u32)__builtin_amdgcn_readlane( r, k);
+				deactivateRule( w, P, rk);
+				if (freeRules) freeRule( w, rk);
+			}
+			continue;
+		}
+		// stable partition of the triggers by bucket: scratch[b*cap + rank]
+		u32 hOf[ DEACT_MAXCHAIN];
+#pragma unroll
+		for (int c=0; c<DEACT_MAXCHAIN; ++c) hOf[ c] = ((u32)c < nt) ? (w.trigs[ t[ c]].link >> 28) : 16u;
+		u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+		for (int c=0; c<DEACT_MAXCHAIN; ++c)
+		{
+			if (hOf[ c] < 16u)
+			{
+				u32 inc = 1u << ((hOf[ c] & 3u)*8), ws = hOf[ c] >> 2;
+				if (ws == 0) c0 += inc; else if (ws == 1) c1 += inc; else if (ws == 2) c2 += inc; else c3 += inc;
+			}
+		}
+		u32 i0 = c0, i1 = c1, i2 = c2, i3 = c3;
+		// 64 lanes x DEACT_MAXCHAIN = 256 could overflow an 8-bit field: scan in 16-bit halves
+		u32 lo0 = i0 & 0x00FF00FFu, hi0 = (i0 >> 8) & 0x00FF00FFu, lo1 = i1 & 0x00FF00FFu, hi1 = (i1 >> 8) & 0x00FF00FFu;
+		u32 lo2 = i2 & 0x00FF00FFu, hi2 = (i2 >> 8) & 0x00FF00FFu, lo3 = i3 & 0x00FF00FFu, hi3 = (i3 >> 8) & 0x00FF00FFu;
+		for (int dd=1; dd<64; dd<<=1)
+		{
+			u32 a0 = __shfl_up( lo0, dd), b0 = __shfl_up( hi0, dd), a1 = __shfl_up( lo1, dd), b1 = __shfl_up( hi1, dd);
+			u32 a2 = __shfl_up( lo2, dd), b2 = __shfl_up( hi2, dd), a3 = __shfl_up( lo3, dd), b3 = __shfl_up( hi3, dd);
+			if ((int)LANE >= dd) { lo0 += a0; hi0 += b0; lo1 += a1; hi1 += b1; lo2 += a2; hi2 += b2; lo3 += a3; hi3 += b3; }
+		}
+		// field h of word ws: h&3 == 0 -> lo bits 0..15, 1 -> hi bits 0..15, 2 -> lo bits 16..31, 3 -> hi bits 16..31
+		auto incl = [&]( u32 h) -> u32 {
+			u32 ws = h >> 2, f = h & 3u;
+			u32 lo = ws == 0 ? lo0 : ws == 1 ? lo1 : ws == 2 ? lo2 : lo3;
+			u32 hi = ws == 0 ? hi0 : ws == 1 ? hi1 : ws == 2 ? hi2 : hi3;
+			u32 v = (f & 1u) ? hi : lo;
+			return (f & 2u) ? (v >> 16) : (v & 0xFFFFu);
+		};
+		auto own = [&]( u32 h) -> u32 { return byteField( c0, c1, c2, c3, h); };
+		const u32 scap = P.arena.scratchCap;
+		u32 seen0 = 0, seen1 = 0, seen2 = 0, seen3 = 0;	// my own earlier triggers per bucket
+		u32 ntot = 0;
+#pragma unroll
+		for (int c=0; c<DEACT_MAXCHAIN; ++c)
+		{
+			if (hOf[ c] < 16u)
+			{
+				const u32 h = hOf[ c];
+				const u32 mineBefore = byteField( seen0, seen1, seen2, seen3, h);
+				const u32 rankInBucket = incl( h) - own( h) + mineBefore;
+				if (rankInBucket < scap) w.scratch[ h*scap + rankInBucket] = t[ c]; else w.err = SPD_ERR_ARENA;
+				u32 inc = 1u << ((h & 3u)*8), ws = h >> 2;
+				if (ws == 0) seen0 += inc; else if (ws == 1) seen1 += inc; else if (ws == 2) seen2 += inc; else seen3 += inc;
+				++ntot;
+			}
+		}
+		if (__ballot( w.err != 0)) { w.err = SPD_ERR_ARENA; return; }
+		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+		// lane b replays the removals of bucket b (cpp:133-152)
+		{
+			u32 myCount = 0;
+			if (LANE < 16u)
+			{
+				// totals = inclusive value of lane 63
+			}
+			const u32 tl0 = (u32)__builtin_amdgcn_readlane( lo0, 63), th0 = (u32)__builtin_amdgcn_readlane( hi0, 63);
+			const u32 tl1 = (u32)__builtin_amdgcn_readlane( lo1, 63), th1 = (u32)__builtin_amdgcn_readlane( hi1, 63);
+			const u32 tl2 = (u32)__builtin_amdgcn_readlane( lo2, 63), th2 = (u32)__builtin_amdgcn_readlane( hi2, 63);
+			const u32 tl3 = (u32)__builtin_amdgcn_readlane( lo3, 63), th3 = (u32)__builtin_amdgcn_readlane( hi3, 63);
+			if (LANE < 16u)
+			{
+				const u32 ws = LANE >> 2, f = LANE & 3u;
+				const u32 lo = ws == 0 ? tl0 : ws == 1 ? tl1 : ws == 2 ? tl2 : tl3;
+				const u32 hi = ws == 0 ? th0 : ws == 1 ? th1 : ws == 2 ? th2 : th3;
+				const u32 v = (f & 1u) ? hi : lo;
+				myCount = (f & 2u) ? (v >> 16) : (v & 0xFFFFu);
+			}
+			if (myCount)
+			{
+				const u32 b = LANE;
+				u32* be = w.bEvent + b*P.arena.bucketCap;
+				u32* bi = w.bIdx + b*P.arena.bucketCap;
+				u32 size = w.bSize[ b];
+				for (u32 k=0; k<myCount; ++k)
+				{
+					const u32 tk = w.scratch[ b*scap + k];
+					const u32 link = w.trigs[ tk].link;
+					const u32 pos = link & 0x0FFFFFFFu;
+					const u32 last = size-1;
+					if (pos != last)
+					{
+						const u32 me = be[ last], mi = bi[ last];
+						be[ pos] = me; bi[ pos] = mi;
+						w.trigs[ mi].link = link;
+					}
+					size = last;
+				}
+				w.bSize[ b] = size;
+			}
+		}
+		// release the trigger records
+		{
+			u32 incT = ntot;
+			for (int dd=1; dd<64; dd<<=1) { u32 up = __shfl_up( incT, dd); if ((int)LANE >= dd) incT += up; }
+			const u32 totalT = (u32)__builtin_amdgcn_readlane( incT, 63);
+			u32 at = w.trigFreeN + incT - ntot;
+#pragma unroll
+			for (int c=0; c<DEACT_MAXCHAIN; ++c) if ((u32)c < nt) w.trigFree[ at++] = t[ c];
+			w.trigFreeN += totalT;
+			w.nTrig -= totalT;
+		}
+		// release the data references (cpp:696-700 -> :710-732): one rule per lane
+		if (P.withItems)
+		{
+			bool bad = false;
+			u32 nfree = 0; bool freeRef = false;
+			if (act && ref)
+			{
+				u32 cnt = w.refs[ 2*(ref-1)+1];
+				if (cnt > 1) w.refs[ 2*(ref-1)+1] = cnt-1;
+				else if (cnt == 1)
+				{
+					freeRef = true;
+					for (u32 it=w.refs[ 2*(ref-1)], g=0; it; it=w.items[ it-1].next, ++g) { ++nfree; if (g > w.itemUsed) { bad = true; break; } }
+					w.refs[ 2*(ref-1)+1] = 0;
+				}
+				else bad = true;
+			}
+			if (__ballot( bad)) { w.err = SPD_ERR_DATAREF; return; }
+			u32 incI = nfree;
+			for (int dd=1; dd<64; dd<<=1) { u32 up = __shfl_up( incI, dd); if ((int)LANE >= dd) incI += up; }
+			const u32 totalI = (u32)__builtin_amdgcn_readlane( incI, 63);
+			if (freeRef)
+			{
+				u32 at = w.itemFreeN + incI - nfree;
+				for (u32 it=w.refs[ 2*(ref-1)]; it; ) { u32 nx = w.items[ it-1].next; w.itemFree[ at++] = it-1; it = nx; }
+			}
+			const u64 fm = __ballot( freeRef);
+			if (freeRef) w.refFree[ w.refFreeN + (u32)__popcll( fm & lanesBelow())] = ref-1;
+			w.itemFreeN += totalI;
+			w.refFreeN += (u32)__popcll( fm);
+		}
+		if (freeRules)
+		{
+			if (have) w.ruleFree[ w.ruleFreeN + LANE] = r;
+			w.ruleFreeN += nb;
+		}
+		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+	}
+}
+
 // ---------------------------------------------------------------- expiry (cpp:1066-1135)
 // far-expiry queue: binary heap on `pos` (min-heap via the inverted comparison of hpp:425-428),
 // sifted exactly like libstdc++'s __push_heap/__adjust_heap so ties come out in the same order.
@@ -295,8 +524,10 @@ __device__ __forceinline__ void defineDisposeRule( WS& w, const L2Params& P, u32
 	if (pos < w.curpos + 64u)
 	{
 		u32 widx = pos & 63u;
-		w.rules[ r].next = ldu( &w.window[ widx]);
-		w.window[ widx] = r+1;
+		const u32 cnt = ldu( &w.window[ widx]);
+		if (cnt >= P.arena.winCap) { w.err = SPD_ERR_ARENA; return; }
+		w.winArr[ widx*P.arena.winCap + cnt] = r;
+		w.window[ widx] = cnt+1;
 	}
 	else heapPush( w, P, pos, r);
 }
@@ -320,21 +551,18 @@ __device__ void setCurrentPos( WS& w, const L2Params& P, u32 pos)	// cpp:1084-11
 			{
 				wcnt = 0;
 				u32 hp = ldu( &w.heap[0]), hr = ldu( &w.heap[1]);
-				w.rules[ hr].next = ldu( &w.window[ hp & 63u]);
-				w.window[ hp & 63u] = hr+1;
+				const u32 hcnt = ldu( &w.window[ hp & 63u]);
+				if (hcnt >= P.arena.winCap) { w.err = SPD_ERR_ARENA; return; }
+				w.winArr[ (hp & 63u)*P.arena.winCap + hcnt] = hr;
+				w.window[ hp & 63u] = hcnt+1;
 				heapPop( w);
 			}
 		}
-		u32 lst = ldu( &w.window[ widx]);
-		if (lst)
+		const u32 cnt = ldu( &w.window[ widx]);
+		if (cnt)
 		{
-			for (u32 guard=0; lst; ++guard)
-			{
-				if (guard > w.ruleUsed) { w.err = SPD_ERR_INTERNAL; break; }
-				u32 r = lst-1;
-				lst = ldu( &w.rules[ r].next);
-				disposeRule( w, P, r);
-			}
+			// the rules of this position, last defined first (the reference's LIFO list order)
+			deactivateBatch( w, P, w.winArr + widx*P.arena.winCap, cnt, true/*reversed*/, true/*free the rules*/, false);
 			w.window[ widx] = 0;
 		}
 	}
@@ -616,14 +844,6 @@ __device__ void installProgram( WS& w, const L2Params& P, u32 keyevent, const De
 // the sequential path, which keeps the order intact.
 enum {MAXT=3};
 
-__device__ __forceinline__ u64 lanesBelow() { return (1ull << LANE) - 1ull; }
-__device__ __forceinline__ u32 byteSum( u32 v) { return (v & 0xFFu) + ((v >> 8) & 0xFFu) + ((v >> 16) & 0xFFu) + (v >> 24); }
-__device__ __forceinline__ u32 byteField( u32 c0, u32 c1, u32 c2, u32 c3, u32 h)
-{
-	u32 wsel = h >> 2;
-	u32 v = wsel == 0 ? c0 : wsel == 1 ? c1 : wsel == 2 ? c2 : c3;
-	return (v >> ((h & 3u)*8)) & 0xFFu;
-}
 
 __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u32 lc, const EvData& d)
 {
@@ -671,12 +891,23 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 				tInstall[ j] = doInstall;
 			}
 		}
-		const bool slow = live && (pastEvent != 0 || expiry >= w.curpos + 64u || g_tc > (u32)MAXT || nofKey > 1);
-		if (__ballot( slow))
+		const bool slowLane = live && (pastEvent != 0 || expiry >= w.curpos + 64u || g_tc > (u32)MAXT || nofKey > 1);
+		const bool liveAll = live;
+		const u64 slowMask = __ballot( slowLane);
+		// the batch is cut into runs of ordinary programs (handled by all lanes at once) separated by
+		// the rare programs that take the sequential path; runs and singles are processed in list order
+		for (u32 segStart=0; segStart<nb && !w.err; )
 		{
-			for (u32 kk=0; kk<nb && !w.err; ++kk) installProgram( w, P, keyevent, &P.keylist[ lb+base+kk], d);
+		const u64 slowAhead = slowMask & ~((1ull << segStart) - 1ull);
+		const u32 cut = slowAhead ? (u32)__builtin_ctzll( slowAhead) : nb;
+		if (cut == segStart)
+		{
+			installProgram( w, P, keyevent, &P.keylist[ lb+base+cut], d);
+			segStart = cut+1;
 			continue;
 		}
+		const bool live = liveAll && LANE >= segStart && LANE < cut;
+		segStart = cut;
 		const u64 liveMask = __ballot( live);
 		if (!liveMask) continue;
 		const u32 nlive = (u32)__popcll( liveMask);
@@ -691,27 +922,27 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 			if (live) r = rank < fromStack ? w.ruleFree[ w.ruleFreeN - 1 - rank] : w.ruleUsed + (rank - fromStack);
 			w.ruleFreeN -= fromStack; w.ruleUsed += bump;
 		}
-		// ---- dispose window (cpp:1072-1076): each position's list grows at its head in program order
+		// ---- dispose window (cpp:1072-1076): the rules of one expiry position are kept in definition order
 		const u32 widx = expiry & 63u;
-		u32 nextLink = 0;
 		{
 			u64 todo = liveMask;
+			bool full = false;
 			while (todo)
 			{
 				const u32 leader = (u32)__builtin_ctzll( todo);
 				const u32 wsel = (u32)__builtin_amdgcn_readlane( widx, leader);
 				const bool mine = live && widx == wsel;
 				const u64 grp = __ballot( mine);
-				const u32 oldHead = ldu( &w.window[ wsel]);
-				const u64 below = grp & lanesBelow();
-				const u32 srcLane = below ? 63u - (u32)__builtin_clzll( below) : LANE;
-				const u32 prevRule = __shfl( r, srcLane);
-				if (mine) nextLink = below ? prevRule + 1 : oldHead;
-				const u32 headLane = 63u - (u32)__builtin_clzll( grp);
-				w.window[ wsel] = (u32)__builtin_amdgcn_readlane( r, headLane) + 1;
+				const u32 cnt = ldu( &w.window[ wsel]);
+				const u32 ng = (u32)__popcll( grp);
+				if (cnt + ng > P.arena.winCap) { full = true; break; }
+				if (mine) w.winArr[ wsel*P.arena.winCap + cnt + (u32)__popcll( grp & lanesBelow())] = r;
+				w.window[ wsel] = cnt + ng;
 				todo &= ~grp;
 			}
+			if (full) { w.err = SPD_ERR_ARENA; return; }
 		}
+		const u32 nextLink = 0;
 		// ---- triggers: bucket positions in (program, template) order
 		u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;		// my installs per bucket, 16 x 8 bit
 		u32 hB[ MAXT];
@@ -719,7 +950,7 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 		for (int j=0; j<MAXT; ++j)
 		{
 			hB[ j] = evhash( tEvent[ j]) & 15u;
-			if (tInstall[ j])
+			if (live && tInstall[ j])
 			{
 				u32 inc = 1u << ((hB[ j] & 3u)*8);
 				u32 ws = hB[ j] >> 2;
@@ -744,12 +975,12 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 #pragma unroll
 		for (int j=0; j<MAXT; ++j)
 		{
-			if (tInstall[ j])
+			if (live && tInstall[ j])
 			{
 				const u32 h = hB[ j];
 				u32 same = 0;
 #pragma unroll
-				for (int jj=0; jj<j; ++jj) if (tInstall[ jj] && hB[ jj] == h) ++same;
+				for (int jj=0; jj<j; ++jj) if (tInstall[ jj] && hB[ jj] == h) ++same;	// my own earlier templates
 				const u32 pos = w.bSize[ h] + byteField( e0, e1, e2, e3, h) + same;
 				const u32 seq = trigBefore + local;
 				const u32 t = seq < trigFromStack ? w.trigFree[ w.trigFreeN - 1 - seq] : w.trigUsed + (seq - trigFromStack);
@@ -781,7 +1012,7 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 #pragma unroll
 		for (int j=0; j<MAXT; ++j)
 		{
-			if (tKey[ j])
+			if (live && tKey[ j])
 			{
 				const u32 sigtype = tTypevar[ j] & 15u, sigval = tSigval[ j];
 				keyVariable = tTypevar[ j] >> 4;
@@ -898,6 +1129,7 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 			R->trigHead = head; R->dataRef = dataRef; R->next = nextLink; R->expiry = expiry;
 		}
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+		} // segments
 	}
 }
 
@@ -915,6 +1147,7 @@ __device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData&
 		w.nDispose = 0;
 		TRACE2( 6, fi); TRACE2( 7, ev);
 
+		PROF_DECL;
 		// fire the triggers waiting for this event: 64 bucket entries per step, one ballot
 		if (ev)
 		{
@@ -936,6 +1169,7 @@ __device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData&
 				}
 			}
 		}
+		PROF_ADD( 0);
 		// install the programs keyed by this event
 		TRACE2( 9, 1);
 		const DevKeyEntry* e = lookupKey( P, ev);
@@ -950,8 +1184,11 @@ __device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData&
 			else for (u32 k=0; k<lc && !w.err; ++k) { TRACE2( 11, k); installProgram( w, P, ev, &P.keylist[ lb+k], d); }
 		}
 		TRACE2( 9, 3);
+		PROF_ADD( 1);
 		// deactivate rules that finished or were deleted
-		for (u32 di=0; di<w.nDispose; ++di) deactivateRule( w, P, ldu( &w.dispose[ di]));
+		if (w.nDispose >= 3) deactivateBatch( w, P, w.dispose, w.nDispose, false, false, true);
+		else for (u32 di=0; di<w.nDispose; ++di) deactivateRule( w, P, ldu( &w.dispose[ di]));
+		PROF_ADD( 2);
 
 		if (stopIdx)
 		{
@@ -1013,6 +1250,7 @@ void spa_l2_match_kernel( L2Params P)
 	w.rules = (Rule*)(A + P.arena.oRules);	w.trigs = (Trig*)(A + P.arena.oTrigs);
 	w.bEvent = A + P.arena.oBEvent;		w.bIdx = A + P.arena.oBIdx;
 	w.bSize = A + P.arena.oBSize;		w.window = A + P.arena.oWindow;
+	w.winArr = A + P.arena.oWinArr;		w.scratch = A + P.arena.oScratch;
 	w.heap = A + P.arena.oHeap;		w.follow = (Follow*)(A + P.arena.oFollow);
 	w.dispose = A + P.arena.oDispose;	w.stop = (StopLog*)(A + P.arena.oStop);
 	w.items = (Item*)(A + P.arena.oItems);	w.refs = A + P.arena.oRefs;
@@ -1031,6 +1269,9 @@ void spa_l2_match_kernel( L2Params P)
 		for (u32 s=LANE; s<P.nofStopWords; s+=64) w.stop[ s].timestamp = 0;
 		w.curpos = 0; w.timestamp = 0; w.nInstalled = 0; w.nAlt = 0; w.nSignals = 0; w.nTrig = 0; w.open = 0;
 		w.ruleFreeN = 0; w.ruleUsed = 0; w.trigFreeN = 0; w.trigUsed = 0; w.itemFreeN = 0; w.itemUsed = 0;
+#ifdef SPA_PROF
+		w.prof[0] = w.prof[1] = w.prof[2] = w.prof[3] = 0;
+#endif
 		w.refFreeN = 0; w.refUsed = 0; w.heapSize = 0; w.nFollow = 0; w.nDispose = 0; w.nStaged = 0; w.err = 0;
 
 		u64 lbeg, lend;
@@ -1063,7 +1304,7 @@ void spa_l2_match_kernel( L2Params P)
 				u32 origseg = __builtin_amdgcn_readlane( seg, k);
 				// PatternMatcherContext::putInput (patternMatcher.cpp:131-162)
 				if (curPosition > ordpos) { w.err = SPD_ERR_ORDER; break; }
-				else if (curPosition < ordpos) { curPosition = ordpos; setCurrentPos( w, P, ordpos); }
+				else if (curPosition < ordpos) { curPosition = ordpos; PROF_DECL; setCurrentPos( w, P, ordpos); PROF_ADD( 3); }
 				else if (origsize >= 0x7FFFFFFFu || origseg >= 0x7FFFFFFFu || origpos >= 0x7FFFFFFFu) { w.err = SPD_ERR_RANGE; break; }
 				if (id >= (1u<<29)) { w.err = SPD_ERR_RANGE; break; }
 				EvData d;
@@ -1137,6 +1378,9 @@ void spa_l2_match_kernel( L2Params P)
 			P.docStatus[ doc] = (int32_t)w.err;
 			atomicAdd( (unsigned long long*)&P.counters[ SPC_EVENTS], (unsigned long long)nEvents);
 			if (w.err) atomicAdd( (unsigned long long*)&P.counters[ SPC_FAILED], 1ull);
+#ifdef SPA_PROF
+			for (int pi=0; pi<4; ++pi) atomicAdd( (unsigned long long*)&P.counters[ 4+pi], (unsigned long long)w.prof[ pi]);
+#endif
 		}
 	}
 }
