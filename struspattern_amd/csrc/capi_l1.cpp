@@ -14,7 +14,7 @@
 #include <vector>
 
 namespace spa {
-hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, hipStream_t stream);
+hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, hipStream_t stream);
 }
 using namespace spa;
 
@@ -41,7 +41,8 @@ struct sp_lexer_ctx
 	int device;
 	std::string lasterror;
 	DeviceBuffer dByteClass, dClassCtx, dCharMask, dStartMask, dAcceptMask, dShiftDst, dSelfLoop, dExSrc, dExDst, dExCount,
-		dWordPatBegin, dWordPats, dPatterns, dSymbols, dSymbolText;
+		dWordPatBegin, dWordPats, dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage;
+	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf; unsigned blockThreads;
 	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus;
 	uint32_t queueCap, eventCap;
 	unsigned arenaWaves; uint64_t arenaWords;
@@ -49,7 +50,7 @@ struct sp_lexer_ctx
 	unsigned numCUs;
 	hipEvent_t evStart, evStop; bool evValid;
 	hipStream_t lastStream; size_t lastNdocs;
-	sp_lexer_ctx() :inst(0),device(0),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
+	sp_lexer_ctx() :inst(0),device(0),ldsWords(0),ldsAccept(0),ldsStart(0),ldsShift(0),ldsSelf(0),blockThreads(256),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
 		,numCUs(256),evStart(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0){}
 };
 
@@ -99,6 +100,16 @@ size_t sp_lexer_dump_tables( const sp_lexer_t* l, uint64_t** out)
 		b.push_back( p.id); b.push_back( p.word); b.push_back( p.levelBind); b.push_back( p.prefixLen); b.push_back( p.suffixLen);
 		b.push_back( ((uint64_t)p.maskHi << 32) | p.maskLo);
 	}
+	// whole-word literals: count, then per literal {len, patCount, bytes..., pattern indices...}
+	b[5] = T.nofLiterals;
+	for (size_t i=0; i<T.literals.size(); ++i)
+	{
+		const DevLiteral& e = T.literals[i];
+		if (!e.hash) continue;
+		b.push_back( e.len); b.push_back( e.patCount);
+		for (uint32_t k=0; k<e.len; ++k) b.push_back( T.literalText[ e.textOffset+k]);
+		for (uint32_t k=0; k<e.patCount; ++k) b.push_back( T.litPats[ e.patBegin+k]);
+	}
 	*out = (uint64_t*)std::malloc( (b.size()+1)*sizeof(uint64_t));
 	if (!*out) return 0;
 	std::memcpy( *out, b.data(), b.size()*sizeof(uint64_t));
@@ -145,6 +156,26 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 		c->dPatterns.upload( T.patterns.data(), T.patterns.size()*sizeof(DevLexPattern));
 		c->dSymbols.upload( T.symbols.data(), T.symbols.size()*sizeof(DevSymbol));
 		c->dSymbolText.upload( T.symbolText.data(), T.symbolText.size());
+		c->dLiterals.upload( T.literals.data(), T.literals.size()*sizeof(DevLiteral));
+		c->dLiteralText.upload( T.literalText.data(), T.literalText.size());
+		c->dLitPats.upload( T.litPats.data(), T.litPats.size()*4);
+		{
+			// LDS image of the hot tables when it fits (one copy per workgroup; bigger workgroups when the copy is big)
+			std::vector<uint64_t> img;
+			img.insert( img.end(), T.charMask.begin(), T.charMask.end());
+			c->ldsAccept = (uint32_t)img.size(); img.insert( img.end(), T.acceptMask.begin(), T.acceptMask.end());
+			c->ldsStart = (uint32_t)img.size(); img.insert( img.end(), T.startMask.begin(), T.startMask.end());
+			c->ldsShift = (uint32_t)img.size(); img.insert( img.end(), T.shiftDst.begin(), T.shiftDst.end());
+			c->ldsSelf = (uint32_t)img.size(); img.insert( img.end(), T.selfLoop.begin(), T.selfLoop.end());
+			size_t bytes = img.size()*8;
+			c->dTableImage.upload( img.data(), bytes);
+			if (bytes <= 144*1024 && T.nofPasses <= 8)
+			{
+				c->ldsWords = (uint32_t)img.size();
+				c->blockThreads = bytes <= 20*1024 ? 256 : bytes <= 40*1024 ? 512 : 1024;
+			}
+			else { c->ldsWords = 0; c->blockThreads = 256; }
+		}
 		c->dCounters.alloc( L1C_COUNT*sizeof(uint64_t));
 		uint32_t npat = (uint32_t)T.patterns.size();
 		c->queueCap = 4096 > 2*npat+256 ? 4096 : 2*npat+256;
@@ -190,14 +221,15 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	HIP_CHECK( hipSetDevice( c->device));
 	const LexTables& T = c->inst->compiler.tables();
 	unsigned wavesWanted = (unsigned)((ndocs < (size_t)c->numCUs*16) ? ndocs : (size_t)c->numCUs*16);
-	unsigned nblocks = (wavesWanted + 3) / 4;
+	const unsigned wpb = c->blockThreads / 64;
+	unsigned nblocks = (wavesWanted + wpb-1) / wpb;
 	if (nblocks == 0) nblocks = 1;
-	unsigned nwaves = nblocks*4;
+	unsigned nwaves = nblocks*wpb;
 	uint64_t perWaveWords = 4ull*c->queueCap + 4ull*c->eventCap;
 	{
 		size_t maxWaves = ((size_t)48 << 30) / (perWaveWords*4);
 		if (maxWaves < 4) maxWaves = 4;
-		if (nwaves > maxWaves) { nblocks = (unsigned)(maxWaves/4); nwaves = nblocks*4; }
+		if (nwaves > maxWaves) { nblocks = (unsigned)(maxWaves/wpb); if (!nblocks) nblocks = 1; nwaves = nblocks*wpb; }
 	}
 	if (c->arenaWaves < nwaves || c->arenaWords != perWaveWords)
 	{
@@ -224,6 +256,8 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.wordPats = (const uint32_t*)c->dWordPats.ptr; P.patterns = (const DevLexPattern*)c->dPatterns.ptr;
 	P.symbols = (const DevSymbol*)c->dSymbols.ptr; P.symbolText = (const uint8_t*)c->dSymbolText.ptr;
 	P.symbolMask = (uint32_t)T.symbols.size()-1;
+	P.literals = (const DevLiteral*)c->dLiterals.ptr; P.literalText = (const uint8_t*)c->dLiteralText.ptr;
+	P.litPats = (const uint32_t*)c->dLitPats.ptr; P.literalMask = (uint32_t)T.literals.size()-1; P.nofLiterals = T.nofLiterals;
 	P.nofPasses = T.nofPasses; P.nofClasses = T.nofClasses; P.maxExceptions = T.maxExceptions ? T.maxExceptions : 1;
 	P.nofPatterns = (uint32_t)T.patterns.size();
 	P.text = (const uint8_t*)d_text; P.docOffsets = (const uint64_t*)d_doc_offsets; P.ndocs = (uint32_t)ndocs;
@@ -231,7 +265,9 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.counters = (uint64_t*)c->dCounters.ptr; P.lexems = (uint32_t*)c->dLexems.ptr; P.lexemCapacity = c->lexemCapacity;
 	P.docRange = (uint64_t*)c->dDocRange.ptr; P.docStatus = (int32_t*)c->dDocStatus.ptr;
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
-	HIP_CHECK( launchL1Lex( P, nblocks, stream));
+	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = c->ldsWords;
+	P.ldsAccept = c->ldsAccept; P.ldsStart = c->ldsStart; P.ldsShift = c->ldsShift; P.ldsSelf = c->ldsSelf;
+	HIP_CHECK( launchL1Lex( P, nblocks, c->blockThreads, stream));
 	HIP_CHECK( hipEventRecord( c->evStop, stream));
 	c->evValid = true; c->lastStream = stream; c->lastNdocs = ndocs;
 }

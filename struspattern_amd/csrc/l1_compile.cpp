@@ -510,6 +510,26 @@ struct Glushkov
 	}
 };
 
+// Is the expression exactly  \b <word characters> \b  ?  Then it matches precisely the maximal runs of
+// word characters that equal the literal, and (from,to) = the run: no automaton bits are needed.
+bool wholeWordLiteral( const Tree& t, std::string& word)
+{
+	if (t.op != T_CAT || t.kids.size() < 3) return false;
+	if (t.kids.front().op != T_ASSERT || t.kids.front().assertion != A_WB) return false;
+	if (t.kids.back().op != T_ASSERT || t.kids.back().assertion != A_WB) return false;
+	word.clear();
+	for (size_t i=1; i+1<t.kids.size(); ++i)
+	{
+		const Tree& k = t.kids[i];
+		if (k.op != T_SET) return false;
+		int only = -1, n = 0;
+		for (unsigned c=0; c<256; ++c) if (k.set.has( c)) { only = (int)c; ++n; }
+		if (n != 1 || !isWordChar( (unsigned)only)) return false;
+		word.push_back( (char)only);
+	}
+	return !word.empty() && word.size() <= 64;
+}
+
 int ctxOfByte( unsigned c) { return c == '\n' ? CTX_NEWLINE : isWordChar( c) ? CTX_WORD : CTX_OTHER; }
 bool ctxIsWord( int ctx) { return ctx == CTX_WORD; }
 // does the conjunction `cond` hold between a byte of context `prev` and one of context `next`?
@@ -692,6 +712,7 @@ void LexCompiler::compile()
 
 	// 1. per pattern automata
 	std::vector<Automaton> autos;
+	std::map<std::string,std::vector<uint32_t> > literalWords;
 	T.patterns.clear();
 	for (size_t di=0; di<m_defs.size(); ++di)
 	{
@@ -713,6 +734,16 @@ void LexCompiler::compile()
 			dp.levelBind |= (1u << 17);
 		}
 		if (m_symbols.count( d.id)) dp.levelBind |= (1u << 16);
+		std::string word;
+		if (wholeWordLiteral( tree, word))
+		{
+			dp.word = L1_WORD_LITERAL;
+			literalWords[ word].push_back( (uint32_t)di);
+			T.patterns.push_back( dp);
+			autos.push_back( Automaton());
+			for (int c=0; c<CTX_COUNT; ++c) { autos.back().start[c] = 0; autos.back().accept[c] = 0; }
+			continue;
+		}
 		T.patterns.push_back( dp);
 		autos.push_back( makeAutomaton( tree, d.expression));
 	}
@@ -727,6 +758,7 @@ void LexCompiler::compile()
 	for (size_t pi=0; pi<autos.size(); ++pi)
 	{
 		uint32_t n = (uint32_t)autos[ pi].pos.size();
+		if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
 		T.nofPositions += n;
 		if (used + n > 64) { ++word; used = 0; T.wordPatBegin.push_back( (uint32_t)T.wordPats.size()); }
 		bitBase[ pi] = used;
@@ -736,7 +768,7 @@ void LexCompiler::compile()
 		T.wordPats.push_back( (uint32_t)pi);
 		used += n;
 	}
-	uint32_t nwords = autos.empty() ? 0 : word+1;
+	uint32_t nwords = T.wordPats.empty() ? 0 : word+1;
 	T.nofPasses = (nwords + L1_WORDS_PER_PASS-1) / L1_WORDS_PER_PASS;
 	if (T.nofPasses == 0) T.nofPasses = 1;
 	const uint32_t totalWords = T.nofPasses * L1_WORDS_PER_PASS;
@@ -781,6 +813,7 @@ void LexCompiler::compile()
 	for (size_t pi=0; pi<autos.size(); ++pi)
 	{
 		const Automaton& a = autos[ pi];
+		if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
 		const uint32_t w = T.patterns[ pi].word, base = bitBase[ pi];
 		const uint32_t pass = w / 64, lane = w % 64;
 		const uint32_t n = (uint32_t)a.pos.size();
@@ -819,6 +852,32 @@ void LexCompiler::compile()
 			size_t at = ((size_t)(w/64) * (T.maxExceptions ? T.maxExceptions : 1) + e)*64 + (w%64);
 			T.exDst[ at] = it->first; T.exSrc[ at] = it->second;
 		}
+	}
+
+	// 4b. whole-word literals: hash table keyed by the word
+	{
+		size_t size = 1;
+		while (size < literalWords.size()*2+1) size <<= 1;
+		DevLiteral none; std::memset( &none, 0, sizeof(none));
+		T.literals.assign( size, none);
+		T.literalText.clear(); T.litPats.clear();
+		T.nofLiterals = (uint32_t)literalWords.size();
+		for (std::map<std::string,std::vector<uint32_t> >::const_iterator li=literalWords.begin(); li!=literalWords.end(); ++li)
+		{
+			uint32_t h = 2166136261u;
+			for (size_t k=0; k<li->first.size(); ++k) h = symbolHashStep( h, (unsigned char)li->first[k]);
+			if (!h) h = 1;
+			DevLiteral e; std::memset( &e, 0, sizeof(e));
+			e.hash = h; e.textOffset = (uint32_t)T.literalText.size(); e.len = (uint32_t)li->first.size();
+			e.patBegin = (uint32_t)T.litPats.size(); e.patCount = (uint32_t)li->second.size();
+			T.literalText.insert( T.literalText.end(), li->first.begin(), li->first.end());
+			T.litPats.insert( T.litPats.end(), li->second.begin(), li->second.end());	// definition order = ascending
+			size_t slot = h & (size-1);
+			while (T.literals[ slot].hash) slot = (slot+1) & (size-1);
+			T.literals[ slot] = e;
+		}
+		if (T.literalText.empty()) T.literalText.push_back( 0);
+		if (T.litPats.empty()) T.litPats.push_back( 0);
 	}
 
 	// 5. symbols: one hash table keyed by (lexem id, text)

@@ -34,6 +34,10 @@ struct LexTables
 	std::vector<DevLexPattern> patterns;
 	std::vector<DevSymbol> symbols;		// power-of-two size (>=1)
 	std::vector<uint8_t> symbolText;
+	std::vector<DevLiteral> literals;	// power-of-two size (>=1)
+	std::vector<uint8_t> literalText;
+	std::vector<uint32_t> litPats;
+	uint32_t nofLiterals;
 	uint32_t nofPositions;
 };
 

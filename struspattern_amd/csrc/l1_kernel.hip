@@ -38,6 +38,9 @@ __device__ __forceinline__ u32 ldu( const u32* p) { return __builtin_amdgcn_read
 
 struct Event { u32 id, origpos, origsize, levelBind; };	// levelBind = level | posbind<<8   (MatchEvent, patternLexer.cpp:665-679)
 
+// hot tables: pointers either into the LDS image of the block or into global memory
+struct LexTab { const u64* charMask; const u64* acceptMask; const u64* startMask; const u64* shiftDst; const u64* selfLoop; };
+
 struct LexWave
 {
 	u32* queue;		// raw reports: 4 words {to, pattern, accLo, accHi}; after SOM word 2 holds `from`
@@ -55,25 +58,26 @@ __device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* do
 
 // ---------------------------------------------------------------- stage 2: leftmost start per report
 // lane-parallel: lane i resolves report base+i
-__device__ void resolveStarts( LexWave& w, const L1Params& P, u32 base, u32 count)
+__device__ void resolveStarts( LexWave& w, const L1Params& P, const LexTab& T, u32 base, u32 count)
 {
 	u32 i = base + LANE;
 	if (LANE < count)
 	{
 		u32* q = w.queue + 4*(u64)i;
 		u32 to = q[0], pi = q[1];
+		if (pi & L1_LITERAL_FLAG) { q[1] = pi & ~L1_LITERAL_FLAG; return; }	// whole-word literal: start already known
 		u64 R = ((u64)q[3] << 32) | q[2];
 		const DevLexPattern pat = P.patterns[ pi];
 		const u32 pass = pat.word >> 6, ln = pat.word & 63u;
 		const u64 mask = ((u64)pat.maskHi << 32) | pat.maskLo;
-		const u64 shiftDst = P.shiftDst[ pass*64 + ln], selfLoop = P.selfLoop[ pass*64 + ln];
+		const u64 shiftDst = T.shiftDst[ pass*64 + ln], selfLoop = T.selfLoop[ pass*64 + ln];
 		const u32 nEx = P.exCount[ pass];
 		u32 from = to;
 		long j = (long)to;			// R = positions that consumed byte j-1
 		while (R && j > 0)
 		{
 			int prevctx = ctxAt( P, w.doc, w.docLen, j-2);
-			if (R & P.startMask[ ((u64)pass*CTX_COUNT + prevctx)*64 + ln]) from = (u32)(j-1);
+			if (R & T.startMask[ ((u64)pass*CTX_COUNT + prevctx)*64 + ln]) from = (u32)(j-1);
 			if (j-1 == 0) break;
 			u64 Rp = ((R & shiftDst) >> 1) | (R & selfLoop);
 			for (u32 e=0; e<nEx; ++e)
@@ -82,7 +86,7 @@ __device__ void resolveStarts( LexWave& w, const L1Params& P, u32 base, u32 coun
 				if (R & P.exDst[ at]) Rp |= P.exSrc[ at];
 			}
 			u32 cls = P.byteClass[ w.doc[ j-2]];
-			R = Rp & mask & P.charMask[ ((u64)pass*P.nofClasses + cls)*64 + ln];
+			R = Rp & mask & T.charMask[ ((u64)pass*P.nofClasses + cls)*64 + ln];
 			--j;
 		}
 		q[2] = from;
@@ -203,12 +207,12 @@ __device__ void handleReport( LexWave& w, const L1Params& P, u32 pi, u32 from, u
 }
 
 // drain the report queue: SOM in batches of 64 lanes, handler in report order
-__device__ void drainQueue( LexWave& w, const L1Params& P)
+__device__ void drainQueue( LexWave& w, const L1Params& P, const LexTab& T)
 {
 	for (u32 base=0; base<w.nQueue && !w.err; base+=64)
 	{
 		u32 count = w.nQueue - base < 64 ? w.nQueue - base : 64;
-		resolveStarts( w, P, base, count);
+		resolveStarts( w, P, T, base, count);
 		for (u32 k=0; k<count && !w.err; ++k)
 		{
 			const u32* q = w.queue + 4*(u64)(base+k);
@@ -218,9 +222,54 @@ __device__ void drainQueue( LexWave& w, const L1Params& P)
 	w.nQueue = 0;
 }
 
+
+// ---------------------------------------------------------------- whole-word literals (\bWORD\b patterns)
+// A maximal run of word characters [from,to) has ended: if it equals a literal, every pattern defined
+// by that literal reports (from,to).  The reports are merged into the current end-offset group of the
+// queue in ascending pattern index (the order the automaton reports have there already).
+__device__ void literalReports( LexWave& w, const L1Params& P, u32 groupStart, u32 from, u32 to, u32 hash)
+{
+	const u32 len = to - from;
+	u32 h = hash ? hash : 1u;
+	u32 slot = h & P.literalMask;
+	for (u32 probes=0; probes<=P.literalMask; ++probes)
+	{
+		const DevLiteral* e = &P.literals[ slot];
+		const u32 eh = ldu( &e->hash);
+		if (!eh) return;
+		if (eh == h && ldu( &e->len) == len)
+		{
+			const u32 off = ldu( &e->textOffset);
+			const bool differ = LANE < len && w.doc[ from + LANE] != P.literalText[ off + LANE];	// one byte per lane (len <= 64)
+			if (!__ballot( differ))
+			{
+				const u32 pb = ldu( &e->patBegin), pc = ldu( &e->patCount);
+				for (u32 k=0; k<pc; ++k)
+				{
+					const u32 pi = ldu( &P.litPats[ pb+k]);
+					if (w.nQueue + 1 > P.queueCap) { w.err = L1D_ERR_ARENA; return; }
+					u32 at = groupStart;
+					while (at < w.nQueue && (ldu( &w.queue[ 4*(u64)at+1]) & ~L1_LITERAL_FLAG) < pi) ++at;
+					for (u32 m=w.nQueue; m>at; --m)
+					{
+						u32* dst = w.queue + 4*(u64)m; const u32* src = w.queue + 4*(u64)(m-1);
+						u32 a0 = ldu( &src[0]), a1 = ldu( &src[1]), a2 = ldu( &src[2]), a3 = ldu( &src[3]);
+						dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+					}
+					u32* q = w.queue + 4*(u64)at;
+					q[0] = to; q[1] = pi | L1_LITERAL_FLAG; q[2] = from; q[3] = 0;
+					w.nQueue += 1;
+				}
+				return;
+			}
+		}
+		slot = (slot+1) & P.literalMask;
+	}
+}
+
 // ---------------------------------------------------------------- stage 1: forward scan
 template <int PASSES>
-__device__ void scanDocument( LexWave& w, const L1Params& P)
+__device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab& T)
 {
 	u64 state[ PASSES];
 #pragma unroll
@@ -228,6 +277,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P)
 	const u32 len = w.docLen;
 	const u32 drainAt = P.queueCap > P.nofPatterns + 64 ? P.queueCap - P.nofPatterns - 64 : 0;
 	int prevctx = CTX_EDGE;
+	bool inWord = false; u32 runStart = 0, runHash = 0;		// token hash of the current run of word characters
 	for (u32 tile=0; tile<=len && !w.err; tile+=64)
 	{
 		// 64 document bytes per load, one per lane; replayed byte by byte through a scalar register
@@ -241,13 +291,14 @@ __device__ void scanDocument( LexWave& w, const L1Params& P)
 			const u32 b = atEnd ? 0u : (u32)__builtin_amdgcn_readlane( mine, k);
 			const u32 cls = atEnd ? 0u : uni( P.byteClass[ b]);
 			const int ctx = atEnd ? (int)CTX_EDGE : (int)uni( P.classCtx[ cls]);
+			const u32 groupStart = w.nQueue;	// reports of this end offset start here
 #pragma unroll
 			for (int p=0; p<PASSES; ++p)
 			{
 				if ((u32)p >= P.nofPasses) break;
 				const u64 st = state[ p];
 				// reports for matches ending before byte i
-				const u64 acc = st & P.acceptMask[ ((u64)p*CTX_COUNT + ctx)*64 + LANE];
+				const u64 acc = st & T.acceptMask[ ((u64)p*CTX_COUNT + ctx)*64 + LANE];
 				const u64 hit = __ballot( acc != 0);
 				if (hit)
 				{
@@ -294,29 +345,43 @@ __device__ void scanDocument( LexWave& w, const L1Params& P)
 				}
 				if (!atEnd)
 				{
-					u64 nxt = ((st << 1) & P.shiftDst[ p*64 + LANE]) | (st & P.selfLoop[ p*64 + LANE])
-						| P.startMask[ ((u64)p*CTX_COUNT + prevctx)*64 + LANE];
+					u64 nxt = ((st << 1) & T.shiftDst[ p*64 + LANE]) | (st & T.selfLoop[ p*64 + LANE])
+						| T.startMask[ ((u64)p*CTX_COUNT + prevctx)*64 + LANE];
 					const u32 nEx = P.exCount[ p];
 					for (u32 e=0; e<nEx; ++e)
 					{
 						u64 at = ((u64)p*P.maxExceptions + e)*64 + LANE;
 						if (st & P.exSrc[ at]) nxt |= P.exDst[ at];
 					}
-					state[ p] = nxt & P.charMask[ ((u64)p*P.nofClasses + cls)*64 + LANE];
+					state[ p] = nxt & T.charMask[ ((u64)p*P.nofClasses + cls)*64 + LANE];
+				}
+			}
+			if (P.nofLiterals)
+			{
+				const bool isW = (ctx == CTX_WORD);
+				if (inWord && !isW)
+				{
+					inWord = false;
+					if (i - runStart <= 64u) { __builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront"); literalReports( w, P, groupStart, runStart, i, runHash); }
+				}
+				if (isW)
+				{
+					if (!inWord) { inWord = true; runStart = i; runHash = 2166136261u; }
+					runHash = symbolHashStep( runHash, b);
 				}
 			}
 			prevctx = ctx;
 			if (w.nQueue >= drainAt && w.nQueue)
 			{
 				__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
-				drainQueue( w, P);
+				drainQueue( w, P, T);
 			}
 		}
 	}
 	if (!w.err && w.nQueue)
 	{
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
-		drainQueue( w, P);
+		drainQueue( w, P, T);
 	}
 }
 
@@ -390,6 +455,20 @@ __device__ void emitLexems( LexWave& w, const L1Params& P, u32 doc)
 template <int PASSES>
 __device__ void lexDocuments( const L1Params& P)
 {
+	extern __shared__ u64 ldsImage[];
+	LexTab T;
+	if (P.ldsWords)
+	{
+		// the block stages the hot tables once: [charMask][acceptMask][startMask][shiftDst][selfLoop]
+		for (u32 k=threadIdx.x; k<P.ldsWords; k+=blockDim.x) ldsImage[ k] = P.tableImage[ k];
+		__syncthreads();
+		T.charMask = ldsImage; T.acceptMask = ldsImage + P.ldsAccept; T.startMask = ldsImage + P.ldsStart;
+		T.shiftDst = ldsImage + P.ldsShift; T.selfLoop = ldsImage + P.ldsSelf;
+	}
+	else
+	{
+		T.charMask = P.charMask; T.acceptMask = P.acceptMask; T.startMask = P.startMask; T.shiftDst = P.shiftDst; T.selfLoop = P.selfLoop;
+	}
 	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
 	u32* A = P.arenaBase + (u64)waveSlot * P.arenaWords;
@@ -402,7 +481,7 @@ __device__ void lexDocuments( const L1Params& P)
 		const u64 end = ((u64)ldu( (const u32*)&P.docOffsets[ doc+1]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc+1]);
 		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
 		w.nQueue = 0; w.nEvents = 0; w.err = 0;
-		scanDocument<PASSES>( w, P);
+		scanDocument<PASSES>( w, P, T);
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		if (!w.err) emitLexems( w, P, doc);
 		else if (LANE == 0) { P.docRange[ 2*(u64)doc] = 0; P.docRange[ 2*(u64)doc+1] = 0; }
@@ -417,24 +496,28 @@ __device__ void lexDocuments( const L1Params& P)
 
 } // anonymous namespace
 
-#define SPA_L1_KERNEL( N) \
-extern "C" __global__ __launch_bounds__(256) void spa_l1_lex_kernel_p##N( L1Params P) { lexDocuments<N>( P); }
-SPA_L1_KERNEL( 1)
-SPA_L1_KERNEL( 2)
-SPA_L1_KERNEL( 4)
-SPA_L1_KERNEL( 8)
-SPA_L1_KERNEL( 16)
-SPA_L1_KERNEL( 32)
+#define SPA_L1_KERNEL( N, T) \
+extern "C" __global__ __launch_bounds__(T) void spa_l1_lex_kernel_p##N( L1Params P) { lexDocuments<N>( P); }
+SPA_L1_KERNEL( 1, 1024)
+SPA_L1_KERNEL( 2, 1024)
+SPA_L1_KERNEL( 4, 1024)
+SPA_L1_KERNEL( 8, 1024)
+SPA_L1_KERNEL( 16, 256)
+SPA_L1_KERNEL( 32, 256)
 
 namespace spa {
-hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, hipStream_t stream)
+hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, hipStream_t stream)
 {
-	if (P.nofPasses <= 1) hipLaunchKernelGGL( spa_l1_lex_kernel_p1, dim3( nblocks), dim3( 256), 0, stream, P);
-	else if (P.nofPasses <= 2) hipLaunchKernelGGL( spa_l1_lex_kernel_p2, dim3( nblocks), dim3( 256), 0, stream, P);
-	else if (P.nofPasses <= 4) hipLaunchKernelGGL( spa_l1_lex_kernel_p4, dim3( nblocks), dim3( 256), 0, stream, P);
-	else if (P.nofPasses <= 8) hipLaunchKernelGGL( spa_l1_lex_kernel_p8, dim3( nblocks), dim3( 256), 0, stream, P);
-	else if (P.nofPasses <= 16) hipLaunchKernelGGL( spa_l1_lex_kernel_p16, dim3( nblocks), dim3( 256), 0, stream, P);
-	else if (P.nofPasses <= 32) hipLaunchKernelGGL( spa_l1_lex_kernel_p32, dim3( nblocks), dim3( 256), 0, stream, P);
+	const size_t lds = (size_t)P.ldsWords * 8;
+#define SPA_L1_LAUNCH( N) do { \
+	if (lds > 65536) { hipError_t e = hipFuncSetAttribute( (const void*)spa_l1_lex_kernel_p##N, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
+	hipLaunchKernelGGL( spa_l1_lex_kernel_p##N, dim3( nblocks), dim3( nthreads), lds, stream, P); } while (0)
+	if (P.nofPasses <= 1) SPA_L1_LAUNCH( 1);
+	else if (P.nofPasses <= 2) SPA_L1_LAUNCH( 2);
+	else if (P.nofPasses <= 4) SPA_L1_LAUNCH( 4);
+	else if (P.nofPasses <= 8) SPA_L1_LAUNCH( 8);
+	else if (P.nofPasses <= 16) SPA_L1_LAUNCH( 16);
+	else if (P.nofPasses <= 32) SPA_L1_LAUNCH( 32);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }

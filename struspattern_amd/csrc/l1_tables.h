@@ -19,11 +19,13 @@ namespace spa {
 enum {CTX_WORD=0, CTX_OTHER=1, CTX_NEWLINE=2, CTX_EDGE=3, CTX_COUNT=4};	// EDGE = begin/end of document
 
 enum {L1_WORDS_PER_PASS=64};
+enum {L1_WORD_LITERAL=0xFFFFFFFFu};	// pattern \bWORD\b handled by the token hash instead of automaton bits
+enum {L1_LITERAL_FLAG=0x80000000u};	// queue records: start offset already known
 
 struct DevLexPattern		// 32 B, one per defineLexem call, index = definition index (0-based)
 {
 	uint32_t id;		// lexem id reported
-	uint32_t word;		// global word index (pass*64 + lane) holding the pattern's positions
+	uint32_t word;		// global word index (pass*64 + lane) holding the pattern's positions; L1_WORD_LITERAL = none
 	uint32_t levelBind;	// level | posbind<<8 | hasSymbols<<16 | hasSubexpr<<17
 	uint32_t prefixLen;	// sub-expression selection: bytes cut at the front ...
 	uint32_t suffixLen;	// ... and at the back of the raw match (fixed-length context)
@@ -38,6 +40,16 @@ struct DevSymbol		// 32 B, open addressing (linear probing), hash==0 = empty
 	uint32_t textOffset;
 	uint32_t len;
 	uint32_t symbolId;
+	uint32_t _pad[3];
+};
+
+struct DevLiteral		// 32 B, open addressing, hash==0 = empty: a whole-word literal and the patterns defined by it
+{
+	uint32_t hash;
+	uint32_t textOffset;	// into the literal text pool
+	uint32_t len;
+	uint32_t patBegin;	// litPats[patBegin .. patBegin+patCount): pattern indices, ascending
+	uint32_t patCount;
 	uint32_t _pad[3];
 };
 

@@ -12,7 +12,7 @@ CTX_EDGE = 3
 class Tables:
     def __init__(self, dump):
         d = [int(x) for x in dump]
-        self.nofPasses, self.nofClasses, self.maxEx, self.nofPatterns, self.nofPositions = d[0:5]
+        self.nofPasses, self.nofClasses, self.maxEx, self.nofPatterns, self.nofPositions, self.nofLiterals = d[0:6]
         p = 8
         self.byteClass = d[p:p + 256]; p += 256
         self.classCtx = d[p:p + self.nofClasses]; p += self.nofClasses
@@ -37,6 +37,11 @@ class Tables:
         for i in range(self.nofPatterns):
             pid, word, lb, pre, suf, mask = take(6)
             self.patterns.append(dict(id=pid, word=word, levelBind=lb, prefixLen=pre, suffixLen=suf, mask=mask))
+        self.literals = {}
+        for i in range(self.nofLiterals):
+            ln, pc = take(2)
+            word = bytes(take(ln))
+            self.literals[word] = take(pc)
         assert p == len(d)
 
     def ctx(self, text, pos):
@@ -72,6 +77,19 @@ class Tables:
                     new[w] = nxt & self.charMask[(p * C + cls) * 64 + ln]
             state = new
             prevctx = ctx
+        # whole-word literals: maximal runs of word characters that equal a literal
+        i = 0
+        n = len(text)
+        while i < n:
+            if self.ctx(text, i) == 0:
+                j = i
+                while j < n and self.ctx(text, j) == 0:
+                    j += 1
+                for pi in self.literals.get(bytes(text[i:j]), []):
+                    out.append((pi + 1, i, j))
+                i = j
+            else:
+                i += 1
         out.sort(key=lambda r: (r[2], r[0]))
         return out
 
