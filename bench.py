@@ -89,7 +89,7 @@ def main():
     nbytes = 0
     if wl in ("pipeline", "lexer"):
         nreg = args.regexes or (10000 if wl == "pipeline" else 256)
-        ndocs = args.docs or (256 if wl == "pipeline" else 4096)
+        ndocs = args.docs or (4096 if wl == "pipeline" else 8192)
         vocab = synth.vocabulary(30000, 1)
         if wl == "pipeline":
             pats, rules = synth.pipeline_workload(nreg, args.rules, vocab, seed=4)

@@ -42,7 +42,7 @@ struct sp_lexer_ctx
 	std::string lasterror;
 	DeviceBuffer dByteClass, dClassCtx, dCharMask, dStartMask, dAcceptMask, dShiftDst, dSelfLoop, dExSrc, dExDst, dExCount,
 		dWordPatBegin, dWordPats, dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage;
-	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf; unsigned blockThreads;
+	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst; unsigned blockThreads;
 	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus;
 	uint32_t queueCap, eventCap;
 	unsigned arenaWaves; uint64_t arenaWords;
@@ -50,7 +50,7 @@ struct sp_lexer_ctx
 	unsigned numCUs;
 	hipEvent_t evStart, evStop; bool evValid;
 	hipStream_t lastStream; size_t lastNdocs;
-	sp_lexer_ctx() :inst(0),device(0),ldsWords(0),ldsAccept(0),ldsStart(0),ldsShift(0),ldsSelf(0),blockThreads(256),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
+	sp_lexer_ctx() :inst(0),device(0),ldsWords(0),ldsAccept(0),ldsStart(0),ldsShift(0),ldsSelf(0),ldsExSrc(0),ldsExDst(0),blockThreads(256),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
 		,numCUs(256),evStart(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0){}
 };
 
@@ -167,6 +167,8 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 			c->ldsStart = (uint32_t)img.size(); img.insert( img.end(), T.startMask.begin(), T.startMask.end());
 			c->ldsShift = (uint32_t)img.size(); img.insert( img.end(), T.shiftDst.begin(), T.shiftDst.end());
 			c->ldsSelf = (uint32_t)img.size(); img.insert( img.end(), T.selfLoop.begin(), T.selfLoop.end());
+			c->ldsExSrc = (uint32_t)img.size(); img.insert( img.end(), T.exSrc.begin(), T.exSrc.end());
+			c->ldsExDst = (uint32_t)img.size(); img.insert( img.end(), T.exDst.begin(), T.exDst.end());
 			size_t bytes = img.size()*8;
 			c->dTableImage.upload( img.data(), bytes);
 			if (bytes <= 144*1024 && T.nofPasses <= 8)
@@ -267,6 +269,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
 	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = c->ldsWords;
 	P.ldsAccept = c->ldsAccept; P.ldsStart = c->ldsStart; P.ldsShift = c->ldsShift; P.ldsSelf = c->ldsSelf;
+	P.ldsExSrc = c->ldsExSrc; P.ldsExDst = c->ldsExDst;
 	HIP_CHECK( launchL1Lex( P, nblocks, c->blockThreads, stream));
 	HIP_CHECK( hipEventRecord( c->evStop, stream));
 	c->evValid = true; c->lastStream = stream; c->lastNdocs = ndocs;

@@ -20,6 +20,10 @@ hipError_t launchL2Match( const L2Params& P, unsigned nblocks, hipStream_t strea
 
 using namespace spa;
 
+#ifndef SPA_L2_WAVES_PER_CU
+#define SPA_L2_WAVES_PER_CU 20
+#endif
+
 struct sp_matcher
 {
 	RuleCompiler compiler;
@@ -317,7 +321,7 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 {
 	HIP_CHECK( hipSetDevice( c->device));
 	// geometry: 4 waves per 256-thread block; as many blocks as keep every CU busy, never more waves than documents
-	unsigned wavesWanted = (unsigned)((ndocs < (size_t)c->numCUs*12) ? ndocs : (size_t)c->numCUs*12);
+	unsigned wavesWanted = (unsigned)((ndocs < (size_t)c->numCUs*SPA_L2_WAVES_PER_CU) ? ndocs : (size_t)c->numCUs*SPA_L2_WAVES_PER_CU);
 	unsigned nblocks = (wavesWanted + 3) / 4;
 	if (nblocks == 0) nblocks = 1;
 	unsigned nwaves = nblocks*4;
@@ -332,7 +336,7 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	if (c->arenaWaves < nwaves)
 	{
 		size_t perWave = (size_t)c->arena.totalWords * sizeof(uint32_t);
-		size_t full = (size_t)c->numCUs*12;
+		size_t full = (size_t)c->numCUs*SPA_L2_WAVES_PER_CU;
 		if (full * perWave > ((size_t)48 << 30)) full = ((size_t)48 << 30) / perWave;
 		unsigned alloc = nwaves < full ? (unsigned)full : nwaves;	// allocate for the full machine once
 		c->dArena.alloc( (size_t)alloc * perWave);

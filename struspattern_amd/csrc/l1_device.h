@@ -31,9 +31,9 @@ struct L1Params
 	const uint8_t* literalText;
 	const uint32_t* litPats;
 	uint32_t literalMask, nofLiterals;
-	const uint64_t* tableImage;	// [charMask][acceptMask][startMask][shiftDst][selfLoop] back to back, for LDS staging
+	const uint64_t* tableImage;	// [charMask][acceptMask][startMask][shiftDst][selfLoop][exSrc][exDst] back to back, for LDS staging
 	uint32_t ldsWords;		// 0 = read the tables from global memory
-	uint32_t ldsAccept, ldsStart, ldsShift, ldsSelf;	// word offsets inside the image
+	uint32_t ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst;	// word offsets inside the image
 	uint32_t nofPasses, nofClasses, maxExceptions, nofPatterns;
 	// input
 	const uint8_t* text;		// all documents back to back

@@ -31,6 +31,14 @@ typedef uint64_t u64;
 
 #define LANE ((u32)(threadIdx.x & 63u))
 
+#ifdef SPA_PROF
+#define PROF_T() __builtin_amdgcn_s_memtime()
+#define PROF_ACC( SLOT, T0) do { w.prof[ SLOT] += __builtin_amdgcn_s_memtime() - (T0); } while (0)
+#else
+#define PROF_T() 0ull
+#define PROF_ACC( SLOT, T0) do { (void)(T0); } while (0)
+#endif
+
 enum {L1D_OK=0, L1D_ERR_ARENA=2, L1D_ERR_LEXEMSIZE=7, L1D_ERR_INTERNAL=8, L1D_ERR_OUTPUT=9};
 
 __device__ __forceinline__ u32 uni( u32 v) { return __builtin_amdgcn_readfirstlane( v); }
@@ -38,8 +46,16 @@ __device__ __forceinline__ u32 ldu( const u32* p) { return __builtin_amdgcn_read
 
 struct Event { u32 id, origpos, origsize, levelBind; };	// levelBind = level | posbind<<8   (MatchEvent, patternLexer.cpp:665-679)
 
-// hot tables: pointers either into the LDS image of the block or into global memory
-struct LexTab { const u64* charMask; const u64* acceptMask; const u64* startMask; const u64* shiftDst; const u64* selfLoop; };
+// hot tables: one image [charMask][acceptMask][startMask][shiftDst][selfLoop][exSrc][exDst], read either
+// from the workgroup's LDS copy (ds_read, LDS=true) or from global memory (LDS=false)
+extern __shared__ u64 ldsImage[];
+template <bool LDS>
+struct LexTab
+{
+	const u64* g;		// global image
+	u32 oAccept, oStart, oShift, oSelf, oExSrc, oExDst;
+	__device__ __forceinline__ u64 at( u32 off) const { if (LDS) return ldsImage[ off]; else return g[ off]; }
+};
 
 struct LexWave
 {
@@ -48,6 +64,9 @@ struct LexWave
 	u32 nQueue, nEvents, err;
 	const unsigned char* doc;
 	u32 docLen;
+#ifdef SPA_PROF
+	u64 prof[4];
+#endif
 };
 
 __device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* doc, u32 len, long pos)
@@ -58,7 +77,8 @@ __device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* do
 
 // ---------------------------------------------------------------- stage 2: leftmost start per report
 // lane-parallel: lane i resolves report base+i
-__device__ void resolveStarts( LexWave& w, const L1Params& P, const LexTab& T, u32 base, u32 count)
+template <bool LDS>
+__device__ void resolveStarts( LexWave& w, const L1Params& P, const LexTab<LDS>& T, u32 base, u32 count)
 {
 	u32 i = base + LANE;
 	if (LANE < count)
@@ -70,23 +90,24 @@ __device__ void resolveStarts( LexWave& w, const L1Params& P, const LexTab& T, u
 		const DevLexPattern pat = P.patterns[ pi];
 		const u32 pass = pat.word >> 6, ln = pat.word & 63u;
 		const u64 mask = ((u64)pat.maskHi << 32) | pat.maskLo;
-		const u64 shiftDst = T.shiftDst[ pass*64 + ln], selfLoop = T.selfLoop[ pass*64 + ln];
+		const u64 shiftDst = T.at( T.oShift + pass*64 + ln), selfLoop = T.at( T.oSelf + pass*64 + ln);
 		const u32 nEx = P.exCount[ pass];
 		u32 from = to;
 		long j = (long)to;			// R = positions that consumed byte j-1
 		while (R && j > 0)
 		{
 			int prevctx = ctxAt( P, w.doc, w.docLen, j-2);
-			if (R & T.startMask[ ((u64)pass*CTX_COUNT + prevctx)*64 + ln]) from = (u32)(j-1);
+			if (R & T.at( T.oStart + (pass*CTX_COUNT + prevctx)*64 + ln)) from = (u32)(j-1);
 			if (j-1 == 0) break;
 			u64 Rp = ((R & shiftDst) >> 1) | (R & selfLoop);
 			for (u32 e=0; e<nEx; ++e)
 			{
-				u64 at = ((u64)pass*P.maxExceptions + e)*64 + ln;
-				if (R & P.exDst[ at]) Rp |= P.exSrc[ at];
+				const u32 at = (pass*P.maxExceptions + e)*64 + ln;
+				const u64 es = T.at( T.oExSrc + at), ed = T.at( T.oExDst + at);
+				Rp |= (R & ed) ? es : 0ull;
 			}
 			u32 cls = P.byteClass[ w.doc[ j-2]];
-			R = Rp & mask & T.charMask[ ((u64)pass*P.nofClasses + cls)*64 + ln];
+			R = Rp & mask & T.at( (pass*P.nofClasses + cls)*64 + ln);
 			--j;
 		}
 		q[2] = from;
@@ -131,11 +152,11 @@ __device__ u32 lookupSymbol( const LexWave& w, const L1Params& P, u32 lexemId, u
 __device__ void handleReport( LexWave& w, const L1Params& P, u32 pi, u32 from, u32 to)
 {
 	if (to - from >= 65535u) { w.err = L1D_ERR_LEXEMSIZE; return; }			// :727-730
-	const DevLexPattern* pat = &P.patterns[ pi];
-	u32 lb = ldu( &pat->levelBind), id = ldu( &pat->id);
+	const u32 pw = (LANE < 8u) ? ((const u32*)&P.patterns[ pi])[ LANE] : 0u;	// the 32-byte pattern record in one load
+	u32 lb = (u32)__builtin_amdgcn_readlane( pw, 2), id = (u32)__builtin_amdgcn_readlane( pw, 0);
 	if (lb & (1u<<17))										// sub expression selection
 	{
-		u32 pre = ldu( &pat->prefixLen), suf = ldu( &pat->suffixLen);
+		u32 pre = (u32)__builtin_amdgcn_readlane( pw, 3), suf = (u32)__builtin_amdgcn_readlane( pw, 4);
 		if (pre + suf > to - from) return;
 		from += pre; to -= suf;
 	}
@@ -207,17 +228,20 @@ __device__ void handleReport( LexWave& w, const L1Params& P, u32 pi, u32 from, u
 }
 
 // drain the report queue: SOM in batches of 64 lanes, handler in report order
-__device__ void drainQueue( LexWave& w, const L1Params& P, const LexTab& T)
+template <bool LDS>
+__device__ void drainQueue( LexWave& w, const L1Params& P, const LexTab<LDS>& T)
 {
 	for (u32 base=0; base<w.nQueue && !w.err; base+=64)
 	{
 		u32 count = w.nQueue - base < 64 ? w.nQueue - base : 64;
+		u64 t0 = PROF_T();
 		resolveStarts( w, P, T, base, count);
 		for (u32 k=0; k<count && !w.err; ++k)
 		{
 			const u32* q = w.queue + 4*(u64)(base+k);
 			handleReport( w, P, ldu( &q[1]), ldu( &q[2]), ldu( &q[0]));
 		}
+		PROF_ACC( 1, t0);
 	}
 	w.nQueue = 0;
 }
@@ -234,16 +258,17 @@ __device__ void literalReports( LexWave& w, const L1Params& P, u32 groupStart, u
 	u32 slot = h & P.literalMask;
 	for (u32 probes=0; probes<=P.literalMask; ++probes)
 	{
-		const DevLiteral* e = &P.literals[ slot];
-		const u32 eh = ldu( &e->hash);
+		// one 32-byte entry = one load: lane k < 8 fetches word k
+		const u32 ew = (LANE < 8u) ? ((const u32*)&P.literals[ slot])[ LANE] : 0u;
+		const u32 eh = (u32)__builtin_amdgcn_readlane( ew, 0);
 		if (!eh) return;
-		if (eh == h && ldu( &e->len) == len)
+		if (eh == h && (u32)__builtin_amdgcn_readlane( ew, 2) == len)
 		{
-			const u32 off = ldu( &e->textOffset);
+			const u32 off = (u32)__builtin_amdgcn_readlane( ew, 1);
 			const bool differ = LANE < len && w.doc[ from + LANE] != P.literalText[ off + LANE];	// one byte per lane (len <= 64)
 			if (!__ballot( differ))
 			{
-				const u32 pb = ldu( &e->patBegin), pc = ldu( &e->patCount);
+				const u32 pb = (u32)__builtin_amdgcn_readlane( ew, 3), pc = (u32)__builtin_amdgcn_readlane( ew, 4);
 				for (u32 k=0; k<pc; ++k)
 				{
 					const u32 pi = ldu( &P.litPats[ pb+k]);
@@ -268,8 +293,8 @@ __device__ void literalReports( LexWave& w, const L1Params& P, u32 groupStart, u
 }
 
 // ---------------------------------------------------------------- stage 1: forward scan
-template <int PASSES>
-__device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab& T)
+template <int PASSES, bool LDS>
+__device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& T)
 {
 	u64 state[ PASSES];
 #pragma unroll
@@ -278,6 +303,23 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab& T)
 	const u32 drainAt = P.queueCap > P.nofPatterns + 64 ? P.queueCap - P.nofPatterns - 64 : 0;
 	int prevctx = CTX_EDGE;
 	bool inWord = false; u32 runStart = 0, runHash = 0;		// token hash of the current run of word characters
+	// byte -> class / context without touching memory: lane l keeps the entries of bytes 4l..4l+3
+	u32 clsReg = 0, ctxReg = 0;
+	for (u32 k=0; k<4; ++k)
+	{
+		const u32 c = P.byteClass[ 4*LANE + k];
+		clsReg |= c << (8*k);
+		ctxReg |= (u32)P.classCtx[ c] << (8*k);
+	}
+	// per-pass constants in registers
+	u64 shiftDst[ PASSES], selfLoop[ PASSES]; u32 nExOf[ PASSES];
+#pragma unroll
+	for (int p=0; p<PASSES; ++p)
+	{
+		const bool on = (u32)p < P.nofPasses;
+		shiftDst[ p] = on ? T.at( T.oShift + p*64 + LANE) : 0; selfLoop[ p] = on ? T.at( T.oSelf + p*64 + LANE) : 0;
+		nExOf[ p] = on ? uni( P.exCount[ p]) : 0;
+	}
 	for (u32 tile=0; tile<=len && !w.err; tile+=64)
 	{
 		// 64 document bytes per load, one per lane; replayed byte by byte through a scalar register
@@ -289,31 +331,60 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab& T)
 			const u32 i = tile + k;
 			const bool atEnd = (i >= len);
 			const u32 b = atEnd ? 0u : (u32)__builtin_amdgcn_readlane( mine, k);
-			const u32 cls = atEnd ? 0u : uni( P.byteClass[ b]);
-			const int ctx = atEnd ? (int)CTX_EDGE : (int)uni( P.classCtx[ cls]);
+			const u32 sh = (b & 3u)*8;
+			const u32 cls = atEnd ? 0u : (((u32)__builtin_amdgcn_readlane( clsReg, b >> 2) >> sh) & 0xFFu);
+			const int ctx = atEnd ? (int)CTX_EDGE : (int)(((u32)__builtin_amdgcn_readlane( ctxReg, b >> 2) >> sh) & 0xFFu);
 			const u32 groupStart = w.nQueue;	// reports of this end offset start here
+			// every table row this byte needs, for all passes, before anything depends on them
+			u64 accRow[ PASSES], cmRow[ PASSES], stRow[ PASSES];
 #pragma unroll
 			for (int p=0; p<PASSES; ++p)
 			{
-				if ((u32)p >= P.nofPasses) break;
+				accRow[ p] = T.at( T.oAccept + (p*CTX_COUNT + ctx)*64 + LANE);
+				cmRow[ p] = T.at( (p*P.nofClasses + cls)*64 + LANE);
+				stRow[ p] = T.at( T.oStart + (p*CTX_COUNT + prevctx)*64 + LANE);
+			}
+			u64 acc[ PASSES];
+			u64 anyAcc = 0;
+#pragma unroll
+			for (int p=0; p<PASSES; ++p)
+			{
 				const u64 st = state[ p];
-				// reports for matches ending before byte i
-				const u64 acc = st & T.acceptMask[ ((u64)p*CTX_COUNT + ctx)*64 + LANE];
-				const u64 hit = __ballot( acc != 0);
-				if (hit)
+				acc[ p] = st & accRow[ p];			// matches ending before byte i
+				anyAcc |= acc[ p];
+				if (!atEnd)
 				{
+					u64 nxt = ((st << 1) & shiftDst[ p]) | (st & selfLoop[ p]) | stRow[ p];
+					const u32 nEx = nExOf[ p];
+					for (u32 e=0; e<nEx; ++e)
+					{
+						const u32 at = (p*P.maxExceptions + e)*64 + LANE;
+						const u64 es = T.at( T.oExSrc + at), ed = T.at( T.oExDst + at);
+						nxt |= (st & es) ? ed : 0ull;
+					}
+					state[ p] = nxt & cmRow[ p];
+				}
+			}
+			if (__ballot( anyAcc != 0))
+			{
+				u64 tHit = PROF_T();
+#pragma unroll
+				for (int p=0; p<PASSES; ++p)
+				{
+					const u64 a = acc[ p];
+					if (!__ballot( a != 0)) continue;
 					// per lane: which of the patterns packed into my word fired
 					const u32 word = p*64 + LANE;
 					u32 mycount = 0;
 					u32 pb = 0, pe = 0;
-					if (acc)
+					if (a)
 					{
 						pb = P.wordPatBegin[ word]; pe = P.wordPatBegin[ word+1];
 						for (u32 x=pb; x<pe; ++x)
 						{
 							const DevLexPattern* pat = &P.patterns[ P.wordPats[ x]];
 							u64 m = ((u64)pat->maskHi << 32) | pat->maskLo;
-							if (acc & m) ++mycount;
+							if (a & m) ++mycount;
 						}
 					}
 					// exclusive prefix sum of the counts over the lanes (report order = lane order)
@@ -326,35 +397,24 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab& T)
 					u32 total = uni( __shfl( incl, 63));
 					u32 at = w.nQueue + incl - mycount;
 					if (w.nQueue + total > P.queueCap) { w.err = L1D_ERR_ARENA; break; }
-					if (acc)
+					if (a)
 					{
 						for (u32 x=pb; x<pe; ++x)
 						{
 							u32 pi = P.wordPats[ x];
 							const DevLexPattern* pat = &P.patterns[ pi];
 							u64 m = ((u64)pat->maskHi << 32) | pat->maskLo;
-							if (acc & m)
+							if (a & m)
 							{
 								u32* q = w.queue + 4*(u64)at;
-								q[0] = i; q[1] = pi; q[2] = (u32)(acc & m); q[3] = (u32)((acc & m) >> 32);
+								q[0] = i; q[1] = pi; q[2] = (u32)(a & m); q[3] = (u32)((a & m) >> 32);
 								++at;
 							}
 						}
 					}
 					w.nQueue += total;
 				}
-				if (!atEnd)
-				{
-					u64 nxt = ((st << 1) & T.shiftDst[ p*64 + LANE]) | (st & T.selfLoop[ p*64 + LANE])
-						| T.startMask[ ((u64)p*CTX_COUNT + prevctx)*64 + LANE];
-					const u32 nEx = P.exCount[ p];
-					for (u32 e=0; e<nEx; ++e)
-					{
-						u64 at = ((u64)p*P.maxExceptions + e)*64 + LANE;
-						if (st & P.exSrc[ at]) nxt |= P.exDst[ at];
-					}
-					state[ p] = nxt & T.charMask[ ((u64)p*P.nofClasses + cls)*64 + LANE];
-				}
+				PROF_ACC( 2, tHit);
 			}
 			if (P.nofLiterals)
 			{
@@ -362,7 +422,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab& T)
 				if (inWord && !isW)
 				{
 					inWord = false;
-					if (i - runStart <= 64u) { __builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront"); literalReports( w, P, groupStart, runStart, i, runHash); }
+					if (i - runStart <= 64u) { u64 t0 = PROF_T(); __builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront"); literalReports( w, P, groupStart, runStart, i, runHash); PROF_ACC( 3, t0); }
 				}
 				if (isW)
 				{
@@ -452,22 +512,17 @@ __device__ void emitLexems( LexWave& w, const L1Params& P, u32 doc)
 	}
 }
 
-template <int PASSES>
+template <int PASSES, bool LDS>
 __device__ void lexDocuments( const L1Params& P)
 {
-	extern __shared__ u64 ldsImage[];
-	LexTab T;
-	if (P.ldsWords)
+	LexTab<LDS> T;
+	T.g = P.tableImage; T.oAccept = P.ldsAccept; T.oStart = P.ldsStart; T.oShift = P.ldsShift; T.oSelf = P.ldsSelf;
+	T.oExSrc = P.ldsExSrc; T.oExDst = P.ldsExDst;
+	if (LDS)
 	{
-		// the block stages the hot tables once: [charMask][acceptMask][startMask][shiftDst][selfLoop]
+		// the workgroup stages the hot tables once
 		for (u32 k=threadIdx.x; k<P.ldsWords; k+=blockDim.x) ldsImage[ k] = P.tableImage[ k];
 		__syncthreads();
-		T.charMask = ldsImage; T.acceptMask = ldsImage + P.ldsAccept; T.startMask = ldsImage + P.ldsStart;
-		T.shiftDst = ldsImage + P.ldsShift; T.selfLoop = ldsImage + P.ldsSelf;
-	}
-	else
-	{
-		T.charMask = P.charMask; T.acceptMask = P.acceptMask; T.startMask = P.startMask; T.shiftDst = P.shiftDst; T.selfLoop = P.selfLoop;
 	}
 	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
@@ -481,7 +536,10 @@ __device__ void lexDocuments( const L1Params& P)
 		const u64 end = ((u64)ldu( (const u32*)&P.docOffsets[ doc+1]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc+1]);
 		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
 		w.nQueue = 0; w.nEvents = 0; w.err = 0;
-		scanDocument<PASSES>( w, P, T);
+#ifdef SPA_PROF
+		w.prof[0] = w.prof[1] = w.prof[2] = w.prof[3] = 0;
+#endif
+		{ u64 t0 = PROF_T(); scanDocument<PASSES,LDS>( w, P, T); PROF_ACC( 0, t0); }
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		if (!w.err) emitLexems( w, P, doc);
 		else if (LANE == 0) { P.docRange[ 2*(u64)doc] = 0; P.docRange[ 2*(u64)doc+1] = 0; }
@@ -490,6 +548,9 @@ __device__ void lexDocuments( const L1Params& P)
 			P.docStatus[ doc] = (int32_t)w.err;
 			atomicAdd( (unsigned long long*)&P.counters[ L1C_BYTES], (unsigned long long)w.docLen);
 			if (w.err) atomicAdd( (unsigned long long*)&P.counters[ L1C_FAILED], 1ull);
+#ifdef SPA_PROF
+			for (int pi=0; pi<4; ++pi) atomicAdd( (unsigned long long*)&P.counters[ 4+pi], (unsigned long long)w.prof[ pi]);
+#endif
 		}
 	}
 }
@@ -497,7 +558,7 @@ __device__ void lexDocuments( const L1Params& P)
 } // anonymous namespace
 
 #define SPA_L1_KERNEL( N, T) \
-extern "C" __global__ __launch_bounds__(T) void spa_l1_lex_kernel_p##N( L1Params P) { lexDocuments<N>( P); }
+extern "C" __global__ __launch_bounds__(T) void spa_l1_lex_kernel_p##N( L1Params P) { if (P.ldsWords) lexDocuments<N,true>( P); else lexDocuments<N,false>( P); }
 SPA_L1_KERNEL( 1, 1024)
 SPA_L1_KERNEL( 2, 1024)
 SPA_L1_KERNEL( 4, 1024)

@@ -32,6 +32,9 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #define LANE ((u32)(threadIdx.x & 63u))
+#ifndef SPA_L2_WAVES_PER_EU
+#define SPA_L2_WAVES_PER_EU 5
+#endif
 
 // Debug build only (make TRACE=1): progress words written to host-mapped memory by wave 0 so a
 // stuck kernel can be diagnosed from the host without waiting for it.
@@ -1240,7 +1243,7 @@ __device__ u32 walkItems( WS& w, const L2Params& P, u32 ref, u32* out)
 } // anonymous namespace
 
 // ================================================================== kernel
-extern "C" __global__ __launch_bounds__(256)
+extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPA_L2_WAVES_PER_EU, 8)))
 void spa_l2_match_kernel( L2Params P)
 {
 	const u32 waveSlot = bcast0( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
