@@ -218,7 +218,8 @@ def cpu_baseline(args, wl, pats, rules, text, offs, lex, gpu_value, unit):
     the scalar NFA restatement ("port"), not Hyperscan."""
     import oracle
     from struspattern_amd import synth
-    ncores = os.cpu_count() or 1
+    # a one-GPU box grants about 16 host cores to the job whatever os.cpu_count() says
+    ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     if wl == "l2":
         o = oracle.L2Matcher()
         synth.apply_rules(o, rules)
@@ -235,7 +236,7 @@ def cpu_baseline(args, wl, pats, rules, text, offs, lex, gpu_value, unit):
     t0 = time.perf_counter()
     ol.matchDocs(text[:int(offs[1])], offs[:2], nthreads=1)
     t_doc = max(1e-3, time.perf_counter() - t0)
-    nd = max(1, min(len(offs) - 1, int(args.cpu_seconds * ncores / t_doc)))
+    nd = max(1, min(len(offs) - 1, int(args.cpu_seconds * ncores / t_doc / 1.5)))
     sub_text = text[:int(offs[nd])]
     t0 = time.perf_counter()
     lexems, loffs = ol.matchDocs(sub_text, offs[:nd + 1], nthreads=min(ncores, nd))
