@@ -103,10 +103,11 @@ struct sp_matcher_ctx
 	{
 		std::memset( &arena, 0, sizeof(arena));
 		std::memset( &lastStats, 0, sizeof(lastStats));
-		// defaults sized for 10k-rule tables over ~1000-token documents; sp_matcher_ctx_set_arena overrides
-		arena.maxRules = 8192; arena.maxTrigs = 8192; arena.bucketCap = 2048; arena.maxItems = 16384;
-		arena.maxRefs = 8192; arena.maxFollow = 1024; arena.maxDispose = 2048; arena.maxHeap = 8192;
-		arena.maxGStack = 256; arena.maxStaged = 8192; arena.winCap = 1024; arena.scratchCap = 256;
+		// small defaults (a document's hot state should stay cache and TLB friendly); every capacity
+		// doubles automatically when a document overflows it (SP_DOC_ERR_ARENA -> grow -> rerun)
+		arena.maxRules = 1024; arena.maxTrigs = 1024; arena.bucketCap = 256; arena.maxItems = 2048;
+		arena.maxRefs = 1024; arena.maxFollow = 256; arena.maxDispose = 512; arena.maxHeap = 256;
+		arena.maxGStack = 64; arena.maxStaged = 1024; arena.winCap = 128; arena.scratchCap = 256;
 	}
 };
 
@@ -219,7 +220,7 @@ const char* sp_matcher_ctx_last_error( const sp_matcher_ctx_t* c) { return c->la
 int sp_matcher_ctx_set_arena( sp_matcher_ctx_t* c, uint32_t max_rules, uint32_t max_triggers, uint32_t bucket_capacity,
 				uint32_t max_items, uint32_t max_follow)
 {
-	if (max_rules) { c->arena.maxRules = max_rules; c->arena.maxHeap = max_rules; c->arena.maxDispose = max_rules < 2048 ? 2048 : max_rules; }
+	if (max_rules) { c->arena.maxRules = max_rules; c->arena.maxHeap = max_rules; c->arena.maxDispose = max_rules; c->arena.winCap = max_rules/4 < 64 ? 64 : max_rules/4; }
 	if (max_triggers) c->arena.maxTrigs = max_triggers;
 	if (bucket_capacity) c->arena.bucketCap = bucket_capacity;
 	if (max_items) { c->arena.maxItems = max_items; c->arena.maxRefs = max_items; }
@@ -300,6 +301,7 @@ int sp_matcher_ctx_grow_arena( sp_matcher_ctx_t* c)
 	c->arena.maxRules *= 2; c->arena.maxTrigs *= 2; c->arena.bucketCap *= 2; c->arena.maxItems *= 2;
 	c->arena.maxRefs *= 2; c->arena.maxFollow *= 2; c->arena.maxDispose *= 2; c->arena.maxHeap *= 2;
 	c->arena.maxStaged *= 2; c->arena.maxGStack *= 2; c->arena.winCap *= 2;
+	if (c->arena.scratchCap < 256) c->arena.scratchCap = 256;
 	c->arenaWaves = 0;
 	return SP_OK;
 }

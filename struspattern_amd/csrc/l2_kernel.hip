@@ -105,10 +105,21 @@ __device__ __forceinline__ u32 bcast0( u32 v) { return __builtin_amdgcn_readfirs
 // that everything computed from it (indices, loop bounds, branch conditions) stays scalar and the
 // control flow of the automaton is made of scalar branches, not exec-masked vector loops.
 __device__ __forceinline__ u32 ldu( const u32* p) { return __builtin_amdgcn_readfirstlane( *p); }
+// 16-byte accesses: one vector-memory instruction moves a quarter/third/half of a record
+__device__ __forceinline__ uint4 ld4( const void* p) { return *(const uint4*)p; }
+__device__ __forceinline__ uint4 ldu4( const void* p)
+{
+	uint4 v = *(const uint4*)p;
+	v.x = __builtin_amdgcn_readfirstlane( v.x); v.y = __builtin_amdgcn_readfirstlane( v.y);
+	v.z = __builtin_amdgcn_readfirstlane( v.z); v.w = __builtin_amdgcn_readfirstlane( v.w);
+	return v;
+}
+__device__ __forceinline__ void st4( void* p, u32 a, u32 b, u32 c, u32 d) { *(uint4*)p = make_uint4( a, b, c, d); }
+
 __device__ __forceinline__ void ldEv( EvData& d, const EvData* p)
 {
-	d.sseg = ldu( &p->sseg); d.eseg = ldu( &p->eseg); d.spos = ldu( &p->spos); d.epos = ldu( &p->epos);
-	d.sord = ldu( &p->sord); d.eord = ldu( &p->eord); d.sub = ldu( &p->sub); d.fmt = ldu( &p->fmt);
+	const uint4 a = ldu4( p), b = ldu4( (const u32*)p + 4);
+	d.sseg = a.x; d.eseg = a.y; d.spos = a.z; d.epos = a.w; d.sord = b.x; d.eord = b.y; d.sub = b.z; d.fmt = b.w;
 }
 
 // ---------------------------------------------------------------- allocators
@@ -286,7 +297,7 @@ __device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 
 			Rule* R = &w.rules[ r];
 			u32 flags = R->flags;
 			act = (flags & F_ACTIVE) != 0;
-			if (act) { head = R->trigHead; ref = R->dataRef; }
+			if (act) { const uint4 q2 = ld4( (const u32*)R + 8); head = q2.x; ref = q2.y; }
 		}
 		if (checkDup)
 		{
@@ -585,7 +596,8 @@ __device__ void setCurrentPos( WS& w, const L2Params& P, u32 pos)	// cpp:1084-11
 __device__ void fireSignal( WS& w, const L2Params& P, u32 r, u32 sigtype, u32 sigval, u32 variable, const EvData& d)
 {
 	Rule* R = &w.rules[ r];
-	u32 value = ldu( &R->value), count = ldu( &R->count), flags = ldu( &R->flags), end_ordpos = ldu( &R->end_ordpos);
+	const uint4 q0 = ldu4( R), q1 = ldu4( (const u32*)R + 4);		// {value,count,flags,start_ordpos} {end_ordpos,start_origseg,start_origpos,program}
+	u32 value = q0.x, count = q0.y, flags = q0.z, end_ordpos = q1.x;
 	bool match = false, take = false, fin = false;
 	w.nSignals += 1;
 
@@ -635,8 +647,7 @@ __device__ void fireSignal( WS& w, const L2Params& P, u32 r, u32 sigtype, u32 si
 			if (w.nDispose < P.arena.maxDispose) w.dispose[ w.nDispose++] = r; else w.err = SPD_ERR_ARENA;
 			return;
 	}
-	R->value = value; R->count = count; R->end_ordpos = end_ordpos;
-	u32 start_ordpos = ldu( &R->start_ordpos), start_origseg = ldu( &R->start_origseg), start_origpos = ldu( &R->start_origpos);
+	u32 start_ordpos = q0.w, start_origseg = q1.y, start_origpos = q1.z;
 	u32 dataRef = ldu( &R->dataRef);
 	if (take)
 	{
@@ -665,21 +676,23 @@ __device__ void fireSignal( WS& w, const L2Params& P, u32 r, u32 sigtype, u32 si
 				start_origseg = d.sseg; start_origpos = d.spos;
 			}
 		}
-		R->start_ordpos = start_ordpos; R->start_origseg = start_origseg; R->start_origpos = start_origpos;
 	}
+	const u32 newFlags = (match && !(flags & F_DONE)) ? (flags | F_DONE) : flags;
+	st4( R, value, count, newFlags, start_ordpos);
+	st4( (u32*)R + 4, end_ordpos, start_origseg, start_origpos, q1.w);
 	if (match)
 	{
 		if (!(flags & F_DONE))
 		{
-			const DevProgram* G = &P.programs[ ldu( &R->program)];
-			u32 fevent = ldu( &G->event), handle = ldu( &G->resultHandle), fmt = ldu( &G->formatHandle);
+			const uint4 g0 = ldu4( &P.programs[ q1.w]), g1 = ldu4( (const u32*)&P.programs[ q1.w] + 4);	// {initsigval,initcount,event,resultHandle} {formatHandle,..}
+			u32 fevent = g0.z, handle = g0.w, fmt = g1.x;
 			if (fevent)
 			{
 				if (w.nFollow < P.arena.maxFollow)
 				{
 					Follow* F = &w.follow[ w.nFollow++];
-					F->d.sseg = start_origseg; F->d.spos = start_origpos; F->d.eseg = d.eseg; F->d.epos = d.epos;
-					F->d.sord = start_ordpos; F->d.eord = end_ordpos; F->d.sub = dataRef; F->d.fmt = fmt;
+					st4( F, start_origseg, d.eseg, start_origpos, d.epos);
+					st4( (u32*)F + 4, start_ordpos, end_ordpos, dataRef, fmt);
 					F->event = fevent;
 					if (dataRef) addRef( w, dataRef);
 				}
@@ -690,14 +703,12 @@ __device__ void fireSignal( WS& w, const L2Params& P, u32 r, u32 sigtype, u32 si
 				if (w.nStaged < P.arena.maxStaged)
 				{
 					StagedResult* S = &w.staged[ w.nStaged++];
-					S->handle = handle; S->sord = start_ordpos; S->eord = end_ordpos;
-					S->sseg = start_origseg; S->spos = start_origpos; S->eseg = d.eseg; S->epos = d.epos;
-					S->dataRef = dataRef;
+					st4( S, handle, start_ordpos, end_ordpos, start_origseg);
+					st4( (u32*)S + 4, start_origpos, d.eseg, d.epos, dataRef);
 					if (dataRef) addRef( w, dataRef);
 				}
 				else w.err = SPD_ERR_ARENA;
 			}
-			R->flags = flags | F_DONE;
 		}
 		if (fin)
 		{
@@ -858,11 +869,11 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 		u32 g_initsigval = 0, g_count = 0, g_event = 0, g_handle = 0, g_fmt = 0, g_range = 0, g_tb = 0, g_tc = 0;
 		if (have)
 		{
-			const DevKeyRef* K = &P.keylist[ lb + base + LANE];
-			program = K->program; pastEvent = K->pastEvent;
-			const DevProgram* G = &P.programs[ program];
-			g_initsigval = G->initsigval; g_count = G->initcount & 0xFFFFu; g_event = G->event; g_handle = G->resultHandle;
-			g_fmt = G->formatHandle; g_range = G->positionRange; g_tb = G->trigBegin; g_tc = G->trigCount;
+			const uint4 kq = ld4( &P.keylist[ lb + base + LANE]);		// {program, pastEvent, pastStopIdx, -}
+			program = kq.x; pastEvent = kq.y;
+			const uint4 g0 = ld4( &P.programs[ program]), g1 = ld4( (const u32*)&P.programs[ program] + 4);
+			g_initsigval = g0.x; g_count = g0.y & 0xFFFFu; g_event = g0.z; g_handle = g0.w;
+			g_fmt = g1.x; g_range = g1.y; g_tb = g1.z; g_tc = g1.w;
 		}
 		const u32 expiry = d.sord + g_range;
 		const bool live = have && !(expiry < w.curpos);			// cpp:1171-1181
@@ -878,9 +889,9 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 			tInstall[ j] = false; tKey[ j] = false; tEvent[ j] = 0; tSigval[ j] = 0; tTypevar[ j] = 0;
 			if (live && (u32)j < g_tc)
 			{
-				const DevTrigDef* D = &P.trigdefs[ g_tb + j];
-				u32 tev = D->event, fl = D->flags, sigtype = fl & 15u;
-				tEvent[ j] = tev; tSigval[ j] = D->sigval; tTypevar[ j] = sigtype | (D->variable << 4);
+				const uint4 dq = ld4( &P.trigdefs[ g_tb + j]);			// {event, sigval, variable, flags}
+				u32 tev = dq.x, fl = dq.w, sigtype = fl & 15u;
+				tEvent[ j] = tev; tSigval[ j] = dq.y; tTypevar[ j] = sigtype | (dq.z << 4);
 				bool doInstall;
 				if (tev == keyevent)
 				{
@@ -993,8 +1004,8 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 					w.bEvent[ h*P.arena.bucketCap + pos] = tEvent[ j];
 					w.bIdx[ h*P.arena.bucketCap + pos] = t;
 					Trig* T = &w.trigs[ t];
-					T->event = tEvent[ j]; T->rule = r; T->sigval = tSigval[ j]; T->typevar = tTypevar[ j];
-					T->link = (h << 28) | pos; T->next = head;
+					st4( T, tEvent[ j], r, tSigval[ j], tTypevar[ j]);
+					st4( (u32*)T + 4, (h << 28) | pos, head, 0, 0);
 					head = t+1;
 				}
 				++local;
@@ -1075,7 +1086,9 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 					const u32 it = ri < itemFromStack ? w.itemFree[ w.itemFreeN - 1 - ri] : w.itemUsed + (ri - itemFromStack);
 					const u32 rf = ri < refFromStack ? w.refFree[ w.refFreeN - 1 - ri] : w.refUsed + (ri - refFromStack);
 					Item* I = &w.items[ it];
-					I->variable = keyVariable; I->next = 0; I->d = d;
+					st4( I, keyVariable, 0, 0, 0);
+					st4( (u32*)I + 4, d.sseg, d.eseg, d.spos, d.epos);
+					st4( (u32*)I + 8, d.sord, d.eord, d.sub, d.fmt);
 					w.refs[ 2*rf] = it+1;
 					w.refs[ 2*rf+1] = 1u + (emitFollow ? 1u : 0u) + (emitResult ? 1u : 0u);	// rule + follow + result (cpp:941-953)
 					dataRef = rf+1;
@@ -1094,8 +1107,8 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 				if (emitFollow)
 				{
 					Follow* F = &w.follow[ w.nFollow + (u32)__popcll( fm & lanesBelow())];
-					F->d.sseg = start_origseg; F->d.spos = start_origpos; F->d.eseg = d.eseg; F->d.epos = d.epos;
-					F->d.sord = start_ordpos; F->d.eord = end_ordpos; F->d.sub = dataRef; F->d.fmt = g_fmt;
+					st4( F, start_origseg, d.eseg, start_origpos, d.epos);
+					st4( (u32*)F + 4, start_ordpos, end_ordpos, dataRef, g_fmt);
 					F->event = g_event;
 				}
 				w.nFollow += nf;
@@ -1108,9 +1121,8 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 				if (emitResult)
 				{
 					StagedResult* S = &w.staged[ w.nStaged + (u32)__popcll( rm & lanesBelow())];
-					S->handle = g_handle; S->sord = start_ordpos; S->eord = end_ordpos;
-					S->sseg = start_origseg; S->spos = start_origpos; S->eseg = d.eseg; S->epos = d.epos;
-					S->dataRef = dataRef;
+					st4( S, g_handle, start_ordpos, end_ordpos, start_origseg);
+					st4( (u32*)S + 4, start_origpos, d.eseg, d.epos, dataRef);
 				}
 				w.nStaged += nr;
 			}
@@ -1127,9 +1139,9 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 		if (live)
 		{
 			Rule* R = &w.rules[ r];
-			R->value = value; R->count = count; R->flags = flags; R->start_ordpos = start_ordpos;
-			R->end_ordpos = end_ordpos; R->start_origseg = start_origseg; R->start_origpos = start_origpos; R->program = program;
-			R->trigHead = head; R->dataRef = dataRef; R->next = nextLink; R->expiry = expiry;
+			st4( R, value, count, flags, start_ordpos);
+			st4( (u32*)R + 4, end_ordpos, start_origseg, start_origpos, program);
+			st4( (u32*)R + 8, head, dataRef, nextLink, expiry);
 		}
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		} // segments
@@ -1166,8 +1178,8 @@ __device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData&
 				{
 					u32 p = (u32)__builtin_ctzll( m);
 					m &= m-1;
-					const Trig* T = &w.trigs[ ldu( &bi[ base+p])];
-					u32 tr = ldu( &T->rule), typevar = ldu( &T->typevar), sigval = ldu( &T->sigval);
+					const uint4 tq = ldu4( &w.trigs[ ldu( &bi[ base+p])]);	// {event, rule, sigval, typevar}
+					u32 tr = tq.y, typevar = tq.w, sigval = tq.z;
 					fireSignal( w, P, tr, typevar & 15u, sigval, typevar >> 4, d);
 				}
 			}
@@ -1180,8 +1192,9 @@ __device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData&
 		u32 stopIdx = 0;
 		if (e)
 		{
-			stopIdx = ldu( &e->stopIdx);
-			u32 lb = ldu( &e->listBegin), lc = ldu( &e->listCount);
+			const uint4 eq = ldu4( e);				// {event, listBegin, listCount, stopIdx}
+			stopIdx = eq.w;
+			u32 lb = eq.y, lc = eq.z;
 			TRACE2( 10, lc);
 			if (lc >= 4 && !(P.withItems && d.sub)) installBatch( w, P, ev, lb, lc, d);
 			else for (u32 k=0; k<lc && !w.err; ++k) { TRACE2( 11, k); installProgram( w, P, ev, &P.keylist[ lb+k], d); }
