@@ -774,6 +774,13 @@ void LexCompiler::compile()
 	const uint32_t totalWords = T.nofPasses * L1_WORDS_PER_PASS;
 	while (T.wordPatBegin.size() < totalWords+1) T.wordPatBegin.push_back( (uint32_t)T.wordPats.size());
 
+	T.patOfBit.assign( (size_t)totalWords*64, 0);
+	for (size_t pi=0; pi<autos.size(); ++pi)
+	{
+		if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
+		for (uint32_t k=0; k<(uint32_t)autos[ pi].pos.size(); ++k) T.patOfBit[ (size_t)T.patterns[ pi].word*64 + bitBase[ pi] + k] = (uint32_t)pi;
+	}
+
 	// 3. byte classes: bytes that no position distinguishes (and that share a context) are one class
 	{
 		std::vector<uint64_t> sig( 256, 1469598103934665603ull);

@@ -31,6 +31,7 @@ struct LexTables
 	std::vector<uint64_t> exDst;		// [pass][maxExceptions][64]
 	std::vector<uint32_t> wordPatBegin;	// [nofPasses*64+1] -> wordPats
 	std::vector<uint32_t> wordPats;		// pattern indices (0-based) per word, ascending
+	std::vector<uint32_t> patOfBit;		// [nofPasses*64][64]: pattern owning each automaton bit
 	std::vector<DevLexPattern> patterns;
 	std::vector<DevSymbol> symbols;		// power-of-two size (>=1)
 	std::vector<uint8_t> symbolText;

@@ -23,6 +23,7 @@ struct L1Params
 	const uint32_t* exCount;	// [pass]
 	const uint32_t* wordPatBegin;
 	const uint32_t* wordPats;
+	const uint32_t* patOfBit;	// [word][64]: pattern owning automaton bit
 	const DevLexPattern* patterns;
 	const DevSymbol* symbols;
 	const uint8_t* symbolText;

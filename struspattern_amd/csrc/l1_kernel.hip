@@ -373,18 +373,23 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 				{
 					const u64 a = acc[ p];
 					if (!__ballot( a != 0)) continue;
-					// per lane: which of the patterns packed into my word fired
+					// per lane: which patterns packed into my word fired.  patOfBit maps an automaton bit to its
+					// pattern; the pattern's mask then retires all of its bits at once (two loads per report).
 					const u32 word = p*64 + LANE;
 					u32 mycount = 0;
-					u32 pb = 0, pe = 0;
-					if (a)
+					u32 pi0 = 0, pi1 = 0; u64 m0 = 0, m1 = 0;
 					{
-						pb = P.wordPatBegin[ word]; pe = P.wordPatBegin[ word+1];
-						for (u32 x=pb; x<pe; ++x)
+						u64 rem = a;
+						while (rem)
 						{
-							const DevLexPattern* pat = &P.patterns[ P.wordPats[ x]];
-							u64 m = ((u64)pat->maskHi << 32) | pat->maskLo;
-							if (a & m) ++mycount;
+							const u32 bit = (u32)__builtin_ctzll( rem);
+							const u32 pi = P.patOfBit[ word*64 + bit];
+							const DevLexPattern* pat = &P.patterns[ pi];
+							const uint2 mm = *(const uint2*)&pat->maskLo;
+							const u64 m = ((u64)mm.y << 32) | mm.x;
+							if (mycount == 0) { pi0 = pi; m0 = m; } else if (mycount == 1) { pi1 = pi; m1 = m; }
+							rem &= ~m;
+							++mycount;
 						}
 					}
 					// exclusive prefix sum of the counts over the lanes (report order = lane order)
@@ -397,19 +402,24 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 					u32 total = uni( __shfl( incl, 63));
 					u32 at = w.nQueue + incl - mycount;
 					if (w.nQueue + total > P.queueCap) { w.err = L1D_ERR_ARENA; break; }
-					if (a)
+					if (mycount)
 					{
-						for (u32 x=pb; x<pe; ++x)
+						u64 rem = a;
+						for (u32 x=0; x<mycount; ++x)
 						{
-							u32 pi = P.wordPats[ x];
-							const DevLexPattern* pat = &P.patterns[ pi];
-							u64 m = ((u64)pat->maskHi << 32) | pat->maskLo;
-							if (a & m)
+							u32 pi; u64 m;
+							if (x == 0) { pi = pi0; m = m0; }
+							else if (x == 1) { pi = pi1; m = m1; }
+							else
 							{
-								u32* q = w.queue + 4*(u64)at;
-								q[0] = i; q[1] = pi; q[2] = (u32)(a & m); q[3] = (u32)((a & m) >> 32);
-								++at;
+								const u32 bit = (u32)__builtin_ctzll( rem);
+								pi = P.patOfBit[ word*64 + bit];
+								const uint2 mm = *(const uint2*)&P.patterns[ pi].maskLo;
+								m = ((u64)mm.y << 32) | mm.x;
 							}
+							*(uint4*)(w.queue + 4*(u64)at) = make_uint4( i, pi, (u32)(a & m), (u32)((a & m) >> 32));
+							rem &= ~m;
+							++at;
 						}
 					}
 					w.nQueue += total;
