@@ -62,6 +62,7 @@ struct LexWave
 	u32* queue;		// raw reports: 4 words {to, pattern, accLo, accHi}; after SOM word 2 holds `from`
 	Event* events;
 	u32 nQueue, nEvents, err;
+	Event tail; bool tailValid;	// copy of events[nEvents-1] in scalar registers: most reports only touch the tail
 	const unsigned char* doc;
 	u32 docLen;
 #ifdef SPA_PROF
@@ -77,19 +78,23 @@ __device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* do
 
 // ---------------------------------------------------------------- stage 2: leftmost start per report
 // lane-parallel: lane i resolves report base+i
+struct LaneReport { u32 to, from, id, levelBind, prefixLen, suffixLen; };	// one queued report per lane, pattern attributes attached
+
 template <bool LDS>
-__device__ void resolveStarts( LexWave& w, const L1Params& P, const LexTab<LDS>& T, u32 base, u32 count)
+__device__ void resolveStarts( LexWave& w, const L1Params& P, const LexTab<LDS>& T, u32 base, u32 count, LaneReport& out)
 {
 	u32 i = base + LANE;
+	out.to = 0; out.from = 0; out.id = 0; out.levelBind = 0; out.prefixLen = 0; out.suffixLen = 0;
 	if (LANE < count)
 	{
-		u32* q = w.queue + 4*(u64)i;
-		u32 to = q[0], pi = q[1];
-		if (pi & L1_LITERAL_FLAG) { q[1] = pi & ~L1_LITERAL_FLAG; return; }	// whole-word literal: start already known
-		u64 R = ((u64)q[3] << 32) | q[2];
-		const DevLexPattern pat = P.patterns[ pi];
-		const u32 pass = pat.word >> 6, ln = pat.word & 63u;
-		const u64 mask = ((u64)pat.maskHi << 32) | pat.maskLo;
+		const uint4 q = *(const uint4*)(w.queue + 4*(u64)i);	// {to, pattern, accLo|from, accHi}
+		u32 to = q.x, pi = q.y & ~L1_LITERAL_FLAG;
+		const uint4 p0 = *(const uint4*)&P.patterns[ pi], p1 = *((const uint4*)&P.patterns[ pi] + 1);	// {id,word,levelBind,prefixLen} {suffixLen,maskLo,maskHi,-}
+		out.to = to; out.id = p0.x; out.levelBind = p0.z; out.prefixLen = p0.w; out.suffixLen = p1.x;
+		if (q.y & L1_LITERAL_FLAG) { out.from = q.z; return; }		// whole-word literal: start already known
+		u64 R = ((u64)q.w << 32) | q.z;
+		const u32 pass = p0.y >> 6, ln = p0.y & 63u;
+		const u64 mask = ((u64)p1.z << 32) | p1.y;
 		const u64 shiftDst = T.at( T.oShift + pass*64 + ln), selfLoop = T.at( T.oSelf + pass*64 + ln);
 		const u32 nEx = P.exCount[ pass];
 		u32 from = to;
@@ -110,7 +115,7 @@ __device__ void resolveStarts( LexWave& w, const L1Params& P, const LexTab<LDS>&
 			R = Rp & mask & T.at( (pass*P.nofClasses + cls)*64 + ln);
 			--j;
 		}
-		q[2] = from;
+		out.from = from;
 	}
 }
 
@@ -149,14 +154,11 @@ __device__ u32 lookupSymbol( const LexWave& w, const L1Params& P, u32 lexemId, u
 	return 0;
 }
 
-__device__ void handleReport( LexWave& w, const L1Params& P, u32 pi, u32 from, u32 to)
+__device__ void handleReport( LexWave& w, const L1Params& P, u32 id, u32 lb, u32 pre, u32 suf, u32 from, u32 to)
 {
 	if (to - from >= 65535u) { w.err = L1D_ERR_LEXEMSIZE; return; }			// :727-730
-	const u32 pw = (LANE < 8u) ? ((const u32*)&P.patterns[ pi])[ LANE] : 0u;	// the 32-byte pattern record in one load
-	u32 lb = (u32)__builtin_amdgcn_readlane( pw, 2), id = (u32)__builtin_amdgcn_readlane( pw, 0);
 	if (lb & (1u<<17))										// sub expression selection
 	{
-		u32 pre = (u32)__builtin_amdgcn_readlane( pw, 3), suf = (u32)__builtin_amdgcn_readlane( pw, 4);
 		if (pre + suf > to - from) return;
 		from += pre; to -= suf;
 	}
@@ -171,19 +173,22 @@ __device__ void handleReport( LexWave& w, const L1Params& P, u32 pi, u32 from, u
 	const bool twin = (patternid != id);
 	u32 n = w.nEvents;
 	if (n + 2 > P.eventCap) { w.err = L1D_ERR_ARENA; return; }
+	if (n && !w.tailValid) { ldEvent( w.tail, &w.events[ n-1]); w.tailValid = true; }
 	if (n == 0)
 	{
-		stEvent( &w.events[0], ev); n = 1;
-		if (twin) { Event t = ev; t.id = patternid; stEvent( &w.events[1], t); n = 2; }
-		w.nEvents = n;
+		stEvent( &w.events[0], ev); n = 1; w.tail = ev;
+		if (twin) { Event t = ev; t.id = patternid; stEvent( &w.events[1], t); n = 2; w.tail = t; }
+		w.nEvents = n; w.tailValid = true;
 		return;
 	}
+	const u32 n0 = n;
 	// delete pass (:757-777): from the back while origpos >= the new origpos
 	const u32 lastPos = from + (to-from);
 	u32 nofDeletes = 0;
 	for (u32 k=n; k>0; --k)
 	{
-		Event m; ldEvent( m, &w.events[ k-1]);
+		Event m;
+		if (k == n0 && w.tailValid) m = w.tail; else ldEvent( m, &w.events[ k-1]);
 		if (!(m.origpos >= ev.origpos)) break;
 		u32 mlevel = m.levelBind & 0xFFu;
 		if ((ev.id == m.id && m.origpos == ev.origpos && mlevel == level)
@@ -197,6 +202,7 @@ __device__ void handleReport( LexWave& w, const L1Params& P, u32 pi, u32 from, u
 				w.events[ t] = x;
 			}
 			--n; ++nofDeletes;
+			w.tailValid = false;
 		}
 	}
 	if (!nofDeletes)
@@ -204,7 +210,8 @@ __device__ void handleReport( LexWave& w, const L1Params& P, u32 pi, u32 from, u
 		// ignore pass (:778-792)
 		for (u32 k=n; k>0; --k)
 		{
-			Event m; ldEvent( m, &w.events[ k-1]);
+			Event m;
+			if (k == n0 && w.tailValid) m = w.tail; else ldEvent( m, &w.events[ k-1]);
 			if (!(m.origpos + m.origsize >= lastPos)) break;
 			if ((m.levelBind & 0xFFu) > level && m.origpos <= ev.origpos) { w.nEvents = n; return; }
 		}
@@ -212,6 +219,14 @@ __device__ void handleReport( LexWave& w, const L1Params& P, u32 pi, u32 from, u
 	// insert (:793-822), literal element moves of the reference (see oracle/l1_oracle.cpp for the
 	// two-slot quirk of the symbol twin variant)
 	const u32 newSlots = twin ? 2u : 1u;
+	if (!nofDeletes && w.tailValid && !(w.tail.origpos > ev.origpos))
+	{
+		// common case: the new event goes behind the current tail, nothing moves
+		stEvent( &w.events[ n], ev); w.tail = ev;
+		if (twin) { Event t = ev; t.id = patternid; stEvent( &w.events[ n+1], t); w.tail = t; }
+		w.nEvents = n + newSlots;
+		return;
+	}
 	Event zero; zero.id = 0; zero.origpos = 0; zero.origsize = 0; zero.levelBind = 0;
 	for (u32 s=0; s<newSlots; ++s) stEvent( &w.events[ n+s], zero);
 	long prev = (long)n + (long)newSlots - 1, mi = (long)n - 1;
@@ -225,6 +240,7 @@ __device__ void handleReport( LexWave& w, const L1Params& P, u32 pi, u32 from, u
 	stEvent( &w.events[ mi], ev);
 	if (twin) { Event t = ev; t.id = patternid; stEvent( &w.events[ mi+1], t); }
 	w.nEvents = n + newSlots;
+	w.tailValid = false;		// reloaded on the next report
 }
 
 // drain the report queue: SOM in batches of 64 lanes, handler in report order
@@ -235,11 +251,13 @@ __device__ void drainQueue( LexWave& w, const L1Params& P, const LexTab<LDS>& T)
 	{
 		u32 count = w.nQueue - base < 64 ? w.nQueue - base : 64;
 		u64 t0 = PROF_T();
-		resolveStarts( w, P, T, base, count);
+		LaneReport lr;
+		resolveStarts( w, P, T, base, count, lr);
 		for (u32 k=0; k<count && !w.err; ++k)
 		{
-			const u32* q = w.queue + 4*(u64)(base+k);
-			handleReport( w, P, ldu( &q[1]), ldu( &q[2]), ldu( &q[0]));
+			handleReport( w, P, (u32)__builtin_amdgcn_readlane( lr.id, k), (u32)__builtin_amdgcn_readlane( lr.levelBind, k),
+					(u32)__builtin_amdgcn_readlane( lr.prefixLen, k), (u32)__builtin_amdgcn_readlane( lr.suffixLen, k),
+					(u32)__builtin_amdgcn_readlane( lr.from, k), (u32)__builtin_amdgcn_readlane( lr.to, k));
 		}
 		PROF_ACC( 1, t0);
 	}
@@ -545,7 +563,7 @@ __device__ void lexDocuments( const L1Params& P)
 		const u64 beg = ((u64)ldu( (const u32*)&P.docOffsets[ doc]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc]);
 		const u64 end = ((u64)ldu( (const u32*)&P.docOffsets[ doc+1]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc+1]);
 		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
-		w.nQueue = 0; w.nEvents = 0; w.err = 0;
+		w.nQueue = 0; w.nEvents = 0; w.err = 0; w.tailValid = false;
 #ifdef SPA_PROF
 		w.prof[0] = w.prof[1] = w.prof[2] = w.prof[3] = 0;
 #endif
