@@ -345,13 +345,13 @@ int sp_lexer_ctx_match_docs( sp_lexer_ctx_t* c, const char* text, const uint64_t
 			if (ndocs) HIP_CHECK( hipMemcpy( st.data(), c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
 			bool grow = false;
 			if (counters[ L1C_LEXEMS] > c->lexemCapacity) { c->minLexemCapacity = counters[ L1C_LEXEMS] + counters[ L1C_LEXEMS]/8 + 1024; grow = true; }
-			if (!grow && counters[ L1C_FAILED])
+			if (counters[ L1C_FAILED])
 			{
 				bool arena = false;
 				for (size_t di=0; di<ndocs && !arena; ++di) arena = (st[ di] == SP_DOC_ERR_ARENA);
 				if (arena && sp_lexer_ctx_grow_arena( c) == SP_OK) grow = true;
 			}
-			if (!grow || attempt >= 8) break;
+			if (!grow || attempt >= 12) break;
 		}
 		std::vector<uint64_t> range( ndocs*2+2);
 		if (ndocs) HIP_CHECK( hipMemcpy( range.data(), c->dDocRange.ptr, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));

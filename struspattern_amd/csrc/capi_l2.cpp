@@ -510,7 +510,7 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 			bool grow = false;
 			if (counters[ SPC_RESULTS] > c->resultCapacity) { c->minResultCapacity = counters[ SPC_RESULTS] + counters[ SPC_RESULTS]/8 + 1024; grow = true; }
 			if (counters[ SPC_ITEMS] > c->itemCapacity) { c->minItemCapacity = counters[ SPC_ITEMS] + counters[ SPC_ITEMS]/8 + 1024; grow = true; }
-			if (!grow && counters[ SPC_FAILED])
+			if (counters[ SPC_FAILED])
 			{
 				// documents whose working set exceeded the per-wave arena: double the arena and rerun
 				std::vector<int32_t> st( ndocs);
@@ -519,7 +519,7 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 				for (size_t di=0; di<ndocs && !arena; ++di) arena = (st[ di] == SPD_ERR_ARENA);
 				if (arena && sp_matcher_ctx_grow_arena( c) == SP_OK) grow = true;
 			}
-			if (!grow || attempt >= 6) break;
+			if (!grow || attempt >= 12) break;
 		}
 		std::vector<uint64_t> range( ndocs*2+2);
 		if (ndocs) HIP_CHECK( hipMemcpy( range.data(), c->dDocRange.ptr, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
