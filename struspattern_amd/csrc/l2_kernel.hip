@@ -51,6 +51,15 @@ typedef uint64_t u64;
 #define PROF_DECL do {} while (0)
 #define PROF_ADD( SLOT) do {} while (0)
 #endif
+#ifdef SPA_PROF2
+#define P2C( SLOT, N) do { w.prof[ SLOT] += (N); } while (0)
+#define P2_DECL u64 p2_t0 = __builtin_amdgcn_s_memtime()
+#define P2_ADD( SLOT) do { u64 p2_t1 = __builtin_amdgcn_s_memtime(); w.prof[ SLOT] += p2_t1 - p2_t0; p2_t0 = p2_t1; } while (0)
+#else
+#define P2C( SLOT, N) do {} while (0)
+#define P2_DECL do {} while (0)
+#define P2_ADD( SLOT) do {} while (0)
+#endif
 #ifdef SPA_TRACE2
 #define TRACE2( SLOT, VALUE) TRACE( SLOT, VALUE)
 #else
@@ -86,7 +95,7 @@ struct WS		// per-wave state, lives in registers
 	u64 open;
 	u32 ruleFreeN, ruleUsed, trigFreeN, trigUsed, itemFreeN, itemUsed, refFreeN, refUsed;
 	u32 heapSize, nFollow, nDispose, nStaged, err;
-#ifdef SPA_PROF
+#if defined(SPA_PROF) || defined(SPA_PROF2)
 	u64 prof[4];
 #endif
 };
@@ -865,12 +874,12 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 	{
 		const u32 nb = (lc - base) < 64u ? (lc - base) : 64u;
 		const bool have = LANE < nb;
-		u32 program = 0, pastEvent = 0;
+		u32 program = 0, pastEvent = 0, pastStopIdx = 0;
 		u32 g_initsigval = 0, g_count = 0, g_event = 0, g_handle = 0, g_fmt = 0, g_range = 0, g_tb = 0, g_tc = 0;
 		if (have)
 		{
 			const uint4 kq = ld4( &P.keylist[ lb + base + LANE]);		// {program, pastEvent, pastStopIdx, -}
-			program = kq.x; pastEvent = kq.y;
+			program = kq.x; pastEvent = kq.y; pastStopIdx = kq.z;
 			const uint4 g0 = ld4( &P.programs[ program]), g1 = ld4( (const u32*)&P.programs[ program] + 4);
 			g_initsigval = g0.x; g_count = g0.y & 0xFFFFu; g_event = g0.z; g_handle = g0.w;
 			g_fmt = g1.x; g_range = g1.y; g_tb = g1.z; g_tc = g1.w;
@@ -905,9 +914,112 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 				tInstall[ j] = doInstall;
 			}
 		}
-		const bool slowLane = live && (pastEvent != 0 || expiry >= w.curpos + 64u || g_tc > (u32)MAXT || nofKey > 1);
+		// ---- signals on the fresh slot, computed in registers before anything is stored:
+		//      (1) alternative-keyed programs replay the logged original key event (cpp:1253-1258 -> :1272-1334),
+		//      (2) the key trigger fires (cpp:1259-1269 -> fireSignal cpp:772-979)
+		u32 value = g_initsigval, count = g_count, flags = F_ACTIVE, end_ordpos = 0;
+		u32 start_ordpos = 0, start_origseg = 0, start_origpos = 0, dataRef = 0;
+		bool match = false, fin = false, del = false, odd = false;
+		u32 nFires = 0;
+		u32 itemVar0 = 0, itemVar1 = 0;		// captured variables: [0] from the replayed event, [1] from the key event
+		EvData ld; ld.sseg = ld.eseg = ld.spos = ld.epos = ld.sord = ld.eord = ld.sub = ld.fmt = 0;
+		auto fireLocal = [&]( u32 sigtype, u32 sigval, const EvData& e, bool& took) {
+			bool m = false, f = false; took = false;
+			switch (sigtype)
+			{
+				case SIG_ANY:
+					took = true;
+					if (count > 0) { m = true; --count; f = (count == 0); if (end_ordpos < e.eord) end_ordpos = e.eord; }
+					break;
+				case SIG_AND:
+					if (count > 0)
+					{
+						if (!value) { value = e.sord; if (end_ordpos > e.eord) end_ordpos = e.eord; }
+						if (value == e.sord) { m = true; --count; f = (count == 0); took = true; }
+					}
+					break;
+				case SIG_SEQUENCE:
+				case SIG_SEQUENCE_IMM:
+					if (sigval == value && ((sigtype == SIG_SEQUENCE) ? (end_ordpos <= e.sord) : (end_ordpos == e.sord)))
+					{
+						end_ordpos = e.eord; value = sigval-1;
+						if (count > 0) { --count; m = (count == 0); } else m = true;
+						f = (value == 0); took = true;
+					}
+					break;
+				case SIG_WITHIN:
+					if ((sigval & value) != 0 && end_ordpos <= e.sord)
+					{
+						end_ordpos = e.eord; value &= ~sigval;
+						if (count > 0) { --count; m = (count == 0); } else m = true;
+						f = (value == 0); took = true;
+					}
+					break;
+				default:	// SIG_DEL
+					count = 0; value = 0; del = true;
+					break;
+			}
+			if (took)
+			{
+				if (start_ordpos == 0) { start_ordpos = e.sord; start_origseg = e.sseg; start_origpos = e.spos; }
+				else if (start_ordpos > e.sord)
+				{
+					start_ordpos = e.sord;
+					if (start_origseg > e.sseg || (start_origseg == e.sseg && start_origpos > e.spos)) { start_origseg = e.sseg; start_origpos = e.spos; }
+				}
+			}
+			if (m) { match = true; if (f) fin = true; }
+			++nFires;
+		};
+		bool hasDel = false;
+#pragma unroll
+		for (int j=0; j<MAXT; ++j) if (tInstall[ j] && (tTypevar[ j] & 15u) == SIG_DEL) hasDel = true;
+		if (live && pastEvent)
+		{
+			const u32 psi = pastStopIdx;
+			if (psi)
+			{
+				const u32* L = (const u32*)&w.stop[ psi-1];
+				const uint4 la = ld4( L), lbq = ld4( L+4), lc4 = ld4( L+8);
+				if (lc4.x /*timestamp*/ && lbq.x /*start_ordpos*/ + g_range >= w.curpos)
+				{
+					ld.sseg = la.x; ld.eseg = la.y; ld.spos = la.z; ld.epos = la.w; ld.sord = lbq.x; ld.eord = lbq.y; ld.sub = lbq.z; ld.fmt = lbq.w;
+					if (hasDel || ld.sub) odd = true;		// cancel check / sub-match data: sequential path
+					u32 replays = 0;
+#pragma unroll
+					for (int j=MAXT-1; j>=0; --j)			// the rule's trigger list: last installed first
+					{
+						if (tInstall[ j] && tEvent[ j] == pastEvent)
+						{
+							bool took;
+							fireLocal( tTypevar[ j] & 15u, tSigval[ j], ld, took);
+							if (took && (tTypevar[ j] >> 4)) itemVar0 = tTypevar[ j] >> 4;
+							++replays;
+						}
+					}
+					if (replays > 1 || match || del) odd = true;	// a replay that matches or deletes: sequential path
+				}
+			}
+		}
+		bool keyTook = false;
+#pragma unroll
+		for (int j=0; j<MAXT; ++j)
+		{
+			if (live && tKey[ j])
+			{
+				bool took;
+				fireLocal( tTypevar[ j] & 15u, tSigval[ j], d, took);
+				if (took) { if (keyTook) odd = true; keyTook = true; itemVar1 = tTypevar[ j] >> 4; }
+			}
+		}
+		if (nofKey > 1 && del) odd = true;		// several key triggers where one deletes, or two take: sequential path
+		if (del) { match = false; fin = false; }
+		const bool slowLane = live && (odd || expiry >= w.curpos + 64u || g_tc > (u32)MAXT);
 		const bool liveAll = live;
 		const u64 slowMask = __ballot( slowLane);
+		P2C( 0, __popcll( __ballot( live && odd)));
+		P2C( 1, __popcll( __ballot( live && expiry >= w.curpos + 64u)));
+		P2C( 3, __popcll( __ballot( live && g_tc > (u32)MAXT)));
 		// the batch is cut into runs of ordinary programs (handled by all lanes at once) separated by
 		// the rare programs that take the sequential path; runs and singles are processed in list order
 		for (u32 segStart=0; segStart<nb && !w.err; )
@@ -916,6 +1028,7 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 		const u32 cut = slowAhead ? (u32)__builtin_ctzll( slowAhead) : nb;
 		if (cut == segStart)
 		{
+			P2C( 2, 1);
 			installProgram( w, P, keyevent, &P.keylist[ lb+base+cut], d);
 			segStart = cut+1;
 			continue;
@@ -1018,83 +1131,51 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 		w.nTrig += totalTrig;
 		w.nInstalled += nlive;
 
-		// ---- the key trigger fires on the fresh slot (cpp:1259-1269 -> fireSignal cpp:772-979), in registers
-		u32 value = g_initsigval, count = g_count, flags = F_ACTIVE, end_ordpos = 0;
-		u32 start_ordpos = 0, start_origseg = 0, start_origpos = 0, dataRef = 0;
-		bool match = false, take = false, fin = false, del = false;
-		u32 keyVariable = 0;
-#pragma unroll
-		for (int j=0; j<MAXT; ++j)
-		{
-			if (live && tKey[ j])
-			{
-				const u32 sigtype = tTypevar[ j] & 15u, sigval = tSigval[ j];
-				keyVariable = tTypevar[ j] >> 4;
-				switch (sigtype)
-				{
-					case SIG_ANY:
-						take = true;
-						if (count > 0) { match = true; --count; fin = (count == 0); if (end_ordpos < d.eord) end_ordpos = d.eord; }
-						break;
-					case SIG_AND:
-						if (count > 0)
-						{
-							if (!value) { value = d.sord; if (end_ordpos > d.eord) end_ordpos = d.eord; }
-							if (value == d.sord) { match = true; --count; fin = (count == 0); take = true; }
-						}
-						break;
-					case SIG_SEQUENCE:
-					case SIG_SEQUENCE_IMM:
-						if (sigval == value && ((sigtype == SIG_SEQUENCE) ? (end_ordpos <= d.sord) : (end_ordpos == d.sord)))
-						{
-							end_ordpos = d.eord; value = sigval-1;
-							if (count > 0) { --count; match = (count == 0); } else match = true;
-							fin = (value == 0); take = true;
-						}
-						break;
-					case SIG_WITHIN:
-						if ((sigval & value) != 0 && end_ordpos <= d.sord)
-						{
-							end_ordpos = d.eord; value &= ~sigval;
-							if (count > 0) { --count; match = (count == 0); } else match = true;
-							fin = (value == 0); take = true;
-						}
-						break;
-					default:	// SIG_DEL
-						count = 0; value = 0; del = true;
-						break;
-				}
-			}
-		}
-		if (del) { match = false; take = false; fin = false; }
-		w.nSignals += (u32)__popcll( __ballot( live && nofKey));
-		if (take) { start_ordpos = d.sord; start_origseg = d.sseg; start_origpos = d.spos; }
-		// captured variable: one item + one data reference per lane that needs them
-		const bool wantItem = P.withItems && live && take && keyVariable != 0;
+		w.nSignals += (u32)__popcll( __ballot( live && (nFires & 1u))) + 2u*(u32)__popcll( __ballot( live && (nFires & 2u))) + 4u*(u32)__popcll( __ballot( live && (nFires & 4u)));
+		w.nAlt += (u32)__popcll( __ballot( live && pastEvent != 0));
+		// captured variables: up to two items per lane (the replayed event's, then the key event's on top: LIFO list)
+		const bool want0 = P.withItems && live && itemVar0 != 0;
+		const bool want1 = P.withItems && live && keyTook && itemVar1 != 0;
 		const bool emitFollow = live && match && g_event != 0;
 		const bool emitResult = live && match && g_handle != 0;
 		{
-			const u64 im = __ballot( wantItem);
-			if (im)
+			const u64 im0 = __ballot( want0), im1 = __ballot( want1), rmk = __ballot( want0 || want1);
+			if (rmk)
 			{
-				const u32 ni = (u32)__popcll( im), ri = (u32)__popcll( im & lanesBelow());
+				const u32 ni = (u32)__popcll( im0) + (u32)__popcll( im1), nr = (u32)__popcll( rmk);
+				const u32 ri = (u32)__popcll( im0 & lanesBelow()) + (u32)__popcll( im1 & lanesBelow());
+				const u32 rr = (u32)__popcll( rmk & lanesBelow());
 				const u32 itemFromStack = w.itemFreeN < ni ? w.itemFreeN : ni;
-				const u32 refFromStack = w.refFreeN < ni ? w.refFreeN : ni;
-				if (w.itemUsed + (ni - itemFromStack) > P.arena.maxItems || w.refUsed + (ni - refFromStack) > P.arena.maxRefs) { w.err = SPD_ERR_ARENA; return; }
-				if (wantItem)
+				const u32 refFromStack = w.refFreeN < nr ? w.refFreeN : nr;
+				if (w.itemUsed + (ni - itemFromStack) > P.arena.maxItems || w.refUsed + (nr - refFromStack) > P.arena.maxRefs) { w.err = SPD_ERR_ARENA; return; }
+				if (want0 || want1)
 				{
-					const u32 it = ri < itemFromStack ? w.itemFree[ w.itemFreeN - 1 - ri] : w.itemUsed + (ri - itemFromStack);
-					const u32 rf = ri < refFromStack ? w.refFree[ w.refFreeN - 1 - ri] : w.refUsed + (ri - refFromStack);
-					Item* I = &w.items[ it];
-					st4( I, keyVariable, 0, 0, 0);
-					st4( (u32*)I + 4, d.sseg, d.eseg, d.spos, d.epos);
-					st4( (u32*)I + 8, d.sord, d.eord, d.sub, d.fmt);
-					w.refs[ 2*rf] = it+1;
+					u32 seq = ri, below = 0;
+					if (want0)
+					{
+						const u32 it = seq < itemFromStack ? w.itemFree[ w.itemFreeN - 1 - seq] : w.itemUsed + (seq - itemFromStack);
+						Item* I = &w.items[ it];
+						st4( I, itemVar0, 0, 0, 0);
+						st4( (u32*)I + 4, ld.sseg, ld.eseg, ld.spos, ld.epos);
+						st4( (u32*)I + 8, ld.sord, ld.eord, ld.sub, ld.fmt);
+						below = it+1; ++seq;
+					}
+					if (want1)
+					{
+						const u32 it = seq < itemFromStack ? w.itemFree[ w.itemFreeN - 1 - seq] : w.itemUsed + (seq - itemFromStack);
+						Item* I = &w.items[ it];
+						st4( I, itemVar1, below, 0, 0);
+						st4( (u32*)I + 4, d.sseg, d.eseg, d.spos, d.epos);
+						st4( (u32*)I + 8, d.sord, d.eord, d.sub, d.fmt);
+						below = it+1;
+					}
+					const u32 rf = rr < refFromStack ? w.refFree[ w.refFreeN - 1 - rr] : w.refUsed + (rr - refFromStack);
+					w.refs[ 2*rf] = below;
 					w.refs[ 2*rf+1] = 1u + (emitFollow ? 1u : 0u) + (emitResult ? 1u : 0u);	// rule + follow + result (cpp:941-953)
 					dataRef = rf+1;
 				}
 				w.itemFreeN -= itemFromStack; w.itemUsed += ni - itemFromStack;
-				w.refFreeN -= refFromStack; w.refUsed += ni - refFromStack;
+				w.refFreeN -= refFromStack; w.refUsed += nr - refFromStack;
 			}
 		}
 		if (match) flags |= F_DONE;
@@ -1285,7 +1366,7 @@ void spa_l2_match_kernel( L2Params P)
 		for (u32 s=LANE; s<P.nofStopWords; s+=64) w.stop[ s].timestamp = 0;
 		w.curpos = 0; w.timestamp = 0; w.nInstalled = 0; w.nAlt = 0; w.nSignals = 0; w.nTrig = 0; w.open = 0;
 		w.ruleFreeN = 0; w.ruleUsed = 0; w.trigFreeN = 0; w.trigUsed = 0; w.itemFreeN = 0; w.itemUsed = 0;
-#ifdef SPA_PROF
+#if defined(SPA_PROF) || defined(SPA_PROF2)
 		w.prof[0] = w.prof[1] = w.prof[2] = w.prof[3] = 0;
 #endif
 		w.refFreeN = 0; w.refUsed = 0; w.heapSize = 0; w.nFollow = 0; w.nDispose = 0; w.nStaged = 0; w.err = 0;
@@ -1394,7 +1475,7 @@ void spa_l2_match_kernel( L2Params P)
 			P.docStatus[ doc] = (int32_t)w.err;
 			atomicAdd( (unsigned long long*)&P.counters[ SPC_EVENTS], (unsigned long long)nEvents);
 			if (w.err) atomicAdd( (unsigned long long*)&P.counters[ SPC_FAILED], 1ull);
-#ifdef SPA_PROF
+#if defined(SPA_PROF) || defined(SPA_PROF2)
 			for (int pi=0; pi<4; ++pi) atomicAdd( (unsigned long long*)&P.counters[ 4+pi], (unsigned long long)w.prof[ pi]);
 #endif
 		}

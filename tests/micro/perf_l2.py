@@ -10,7 +10,7 @@ for op in (None, "sequence"):
     ctx = m.createContext()
     d_lex = torch.from_numpy(lex.view(np.int32)).cuda(); d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
     best = None
-    for it in range(8):
+    for it in range(14):
         ctx.matchDocsDevice(d_lex.data_ptr(), d_offs.data_ptr(), nd, len(lex), 0)
         c = ctx.batchCounters()
         if c["failed_docs"]:
