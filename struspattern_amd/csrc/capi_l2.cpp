@@ -16,12 +16,13 @@
 
 namespace spa {
 hipError_t launchL2Match( const L2Params& P, unsigned nblocks, hipStream_t stream);
+hipError_t launchL2MatchLds( const L2Params& P, unsigned nwaves, hipStream_t stream);
 }
 
 using namespace spa;
 
 #ifndef SPA_L2_WAVES_PER_CU
-#define SPA_L2_WAVES_PER_CU 20
+#define SPA_L2_WAVES_PER_CU 8
 #endif
 
 struct sp_matcher
@@ -66,7 +67,13 @@ void layoutArena( ArenaLayout& L)
 	L.oTrigFree = o; o += alignUp( L.maxTrigs, 4);
 	L.oItemFree = o; o += alignUp( L.maxItems, 4);
 	L.oRefFree = o;	o += alignUp( L.maxRefs, 4);
-	L.oWinArr = o;	o += alignUp( 64*L.winCap, 4);
+	// expiry window: lists of up to 8 chunks per position; the pool covers every live rule plus one
+	// partly filled chunk per position
+	L.winChunk = L.winCap/8 < 16 ? 16 : L.winCap/8;
+	L.winChunks = L.maxRules/L.winChunk + 64;
+	L.oWinArr = o;	o += alignUp( L.winChunks*L.winChunk, 4);
+	L.oWinChunk = o; o += 64*8;
+	L.oWinFree = o;	o += alignUp( L.winChunks, 4);
 	L.oScratch = o;	o += alignUp( 16*L.scratchCap, 4);
 	L.totalWords = alignUp( o, 64);
 }
@@ -84,7 +91,7 @@ struct sp_matcher_ctx
 	// working memory
 	ArenaLayout arena;
 	DeviceBuffer dArena; unsigned arenaWaves;
-	DeviceBuffer dCursor, dCounters;
+	DeviceBuffer dCursor, dCounters, dRetry;
 	// batch buffers (grown on demand)
 	DeviceBuffer dLexems, dOrigseg, dDocOffsets, dResults, dItems, dDocRange, dDocStats, dDocStatus;
 	uint64_t resultCapacity, itemCapacity, minResultCapacity, minItemCapacity;
@@ -92,6 +99,8 @@ struct sp_matcher_ctx
 	hipEvent_t evStart, evStop; bool evValid;
 	hipStream_t lastStream;
 	bool withItems;
+	bool ldsOnly;			// diagnostics (SPA_L2_TIER=ldsonly): no second tier, overflowing documents fail
+	bool ldsTier;			// first tier: document state in LDS (SPA_L2_TIER=global switches it off)
 	unsigned numCUs;
 	// single-document mode
 	std::vector<sp_lexem_t> curLexems;
@@ -99,7 +108,7 @@ struct sp_matcher_ctx
 	sp_matcher_stats_t lastStats;
 
 	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),arenaWaves(0),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
-		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
+		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),ldsOnly(false),ldsTier(true),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
 		std::memset( &lastStats, 0, sizeof(lastStats));
@@ -195,6 +204,7 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 		c->nofStopWords = ft.nofStopWords;
 		c->arena.nStop = ft.nofStopWords;
 		c->dCursor.alloc( 64);
+		{ const char* tier = getenv( "SPA_L2_TIER"); if (tier && std::strcmp( tier, "global") == 0) c->ldsTier = false; if (tier && std::strcmp( tier, "ldsonly") == 0) c->ldsOnly = true; }
 		c->dCounters.alloc( SPC_COUNT*sizeof(uint64_t));
 		HIP_CHECK( hipEventCreate( &c->evStart));
 		HIP_CHECK( hipEventCreate( &c->evStop));
@@ -322,18 +332,18 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		  size_t ndocs, size_t nlexems, hipStream_t stream, const void* d_doc_ranges=0)
 {
 	HIP_CHECK( hipSetDevice( c->device));
-	// geometry: 4 waves per 256-thread block; as many blocks as keep every CU busy, never more waves than documents
+	// geometry: one wave per workgroup; as many as keep every CU busy, never more waves than documents
 	unsigned wavesWanted = (unsigned)((ndocs < (size_t)c->numCUs*SPA_L2_WAVES_PER_CU) ? ndocs : (size_t)c->numCUs*SPA_L2_WAVES_PER_CU);
-	unsigned nblocks = (wavesWanted + 3) / 4;
+	unsigned nblocks = wavesWanted;		// workgroups are single waves
 	if (nblocks == 0) nblocks = 1;
-	unsigned nwaves = nblocks*4;
+	unsigned nwaves = nblocks;
 	layoutArena( c->arena);
 	{
 		// keep the arena below ~48 GiB: fewer resident waves when documents need a large working set
 		size_t perWave = (size_t)c->arena.totalWords * sizeof(uint32_t);
 		size_t maxWaves = ((size_t)48 << 30) / perWave;
 		if (maxWaves < 4) maxWaves = 4;
-		if (nwaves > maxWaves) { nblocks = (unsigned)(maxWaves/4); nwaves = nblocks*4; }
+		if (nwaves > maxWaves) { nblocks = (unsigned)maxWaves; nwaves = nblocks; }
 	}
 	if (c->arenaWaves < nwaves)
 	{
@@ -404,6 +414,20 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	P.trace = (uint32_t*)traceDev;
 #endif
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
+	if (c->ldsTier)
+	{
+		// tier 1: one-wave workgroups with the document state in LDS (4 per CU); documents that outgrow
+		// the slice are queued on the device.  tier 2: the global-arena kernel takes the queue (usually
+		// empty: its waves read the count and leave).  No host round trip in between.
+		c->dRetry.reserve( (ndocs+1)*sizeof(uint32_t));
+		P.retryList = c->ldsOnly ? 0 : (uint32_t*)c->dRetry.ptr; P.retryCount = (uint32_t*)c->dCursor.ptr;
+		unsigned ldsWaves = (unsigned)((ndocs < (size_t)c->numCUs*4) ? ndocs : (size_t)c->numCUs*4);
+		if (ldsWaves > c->arenaWaves) ldsWaves = c->arenaWaves;
+		if (ldsWaves == 0) ldsWaves = 1;
+		HIP_CHECK( launchL2MatchLds( P, ldsWaves, stream));
+		P.retryList = 0; P.retryCount = 0;
+		P.docList = (const uint32_t*)c->dRetry.ptr; P.docListCount = (const uint32_t*)c->dCursor.ptr;
+	}
 	HIP_CHECK( launchL2Match( P, nblocks, stream));
 	HIP_CHECK( hipEventRecord( c->evStop, stream));
 #if defined(SPA_TRACE) || defined(SPA_POLL)
@@ -469,6 +493,12 @@ int sp_matcher_ctx_batch_counters( sp_matcher_ctx_t* c, uint64_t counters[8])
 		HIP_CHECK( hipSetDevice( c->device));
 		HIP_CHECK( hipStreamSynchronize( c->lastStream));
 		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, SPC_COUNT*sizeof(uint64_t), hipMemcpyDeviceToHost));
+#if !defined(SPA_PROF) && !defined(SPA_PROF2)
+		// diagnostic: how many documents went to the second tier
+		uint32_t retried = 0;
+		if (c->ldsTier) HIP_CHECK( hipMemcpy( &retried, c->dCursor.ptr, sizeof(retried), hipMemcpyDeviceToHost));
+		counters[ 7] = retried;
+#endif
 	});
 }
 

@@ -16,8 +16,8 @@ enum {SPC_RESULTS=0, SPC_ITEMS=1, SPC_EVENTS=2, SPC_FAILED=3, SPC_COUNT=8};
 // item 12, follow 12, stop-log 12, staged result 8, data reference 2, heap entry 2.
 struct ArenaLayout
 {
-	uint32_t maxRules, maxTrigs, bucketCap, maxItems, maxRefs, maxFollow, maxDispose, maxHeap, maxGStack, maxStaged, nStop, winCap, scratchCap;
-	uint32_t oRules, oTrigs, oBEvent, oBIdx, oBSize, oWindow, oHeap, oFollow, oDispose, oStop, oItems, oRefs, oGStack, oStaged, oRuleFree, oTrigFree, oItemFree, oRefFree, oWinArr, oScratch;
+	uint32_t maxRules, maxTrigs, bucketCap, maxItems, maxRefs, maxFollow, maxDispose, maxHeap, maxGStack, maxStaged, nStop, winCap, scratchCap, winChunk, winChunks;
+	uint32_t oRules, oTrigs, oBEvent, oBIdx, oBSize, oWindow, oHeap, oFollow, oDispose, oStop, oItems, oRefs, oGStack, oStaged, oRuleFree, oTrigFree, oItemFree, oRefFree, oWinArr, oScratch, oWinChunk, oWinFree;
 	uint32_t totalWords;
 };
 
@@ -41,6 +41,12 @@ struct L2Params
 	uint32_t* arenaBase;
 	ArenaLayout arena;
 	uint32_t* docCursor;
+	// two tiers: the LDS kernel appends the documents that outgrow its slice to retryList; the
+	// global-arena kernel then takes its documents from docList/docListCount (same buffers)
+	uint32_t* retryList;
+	uint32_t* retryCount;
+	const uint32_t* docList;
+	const uint32_t* docListCount;
 	// output
 	uint64_t* counters;		// SPC_*
 	uint32_t* results;		// sp_result_t[resultCapacity] (9 words each)

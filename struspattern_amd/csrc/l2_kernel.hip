@@ -33,7 +33,7 @@ typedef uint64_t u64;
 
 #define LANE ((u32)(threadIdx.x & 63u))
 #ifndef SPA_L2_WAVES_PER_EU
-#define SPA_L2_WAVES_PER_EU 5
+#define SPA_L2_WAVES_PER_EU 2
 #endif
 
 // Debug build only (make TRACE=1): progress words written to host-mapped memory by wave 0 so a
@@ -46,25 +46,36 @@ typedef uint64_t u64;
 // Phase profile (make PROF=1): wave-cycles per phase summed into counters[4..7]
 #ifdef SPA_PROF
 #define PROF_DECL u64 prof_t0 = __builtin_amdgcn_s_memtime()
-#define PROF_ADD( SLOT) do { u64 prof_t1 = __builtin_amdgcn_s_memtime(); w.prof[ SLOT] += prof_t1 - prof_t0; prof_t0 = prof_t1; } while (0)
+#define PROF_ADD( SLOT) do { u64 prof_t1 = __builtin_amdgcn_s_memtime(); w.raw->prof[ SLOT] += prof_t1 - prof_t0; prof_t0 = prof_t1; } while (0)
 #else
 #define PROF_DECL do {} while (0)
 #define PROF_ADD( SLOT) do {} while (0)
 #endif
 #ifdef SPA_PROF2
-#define P2C( SLOT, N) do { w.prof[ SLOT] += (N); } while (0)
+#define P2C( SLOT, N) do { w.raw->prof[ SLOT] += (N); } while (0)
 #define P2_DECL u64 p2_t0 = __builtin_amdgcn_s_memtime()
-#define P2_ADD( SLOT) do { u64 p2_t1 = __builtin_amdgcn_s_memtime(); w.prof[ SLOT] += p2_t1 - p2_t0; p2_t0 = p2_t1; } while (0)
+#define P2_ADD( SLOT) do { u64 p2_t1 = __builtin_amdgcn_s_memtime(); w.raw->prof[ SLOT] += p2_t1 - p2_t0; p2_t0 = p2_t1; } while (0)
 #else
 #define P2C( SLOT, N) do {} while (0)
 #define P2_DECL do {} while (0)
 #define P2_ADD( SLOT) do {} while (0)
+#endif
+// capacity overflow of the per-document state (PROF2 builds remember where)
+#ifdef SPA_PROF2
+#define ARENA_FAIL do { w.err = SPD_ERR_ARENA; w.raw->prof[3] = __LINE__; } while (0)
+#else
+#define ARENA_FAIL w.err = SPD_ERR_ARENA
 #endif
 #ifdef SPA_TRACE2
 #define TRACE2( SLOT, VALUE) TRACE( SLOT, VALUE)
 #else
 #define TRACE2( SLOT, VALUE) do {} while (0)
 #endif
+
+// The launch parameters are read where they are: in the kernel argument segment (constant address
+// space, scalar loads through the scalar cache), also from the functions the kernel calls.
+typedef const __attribute__((address_space(4))) L2Params& KP;
+__device__ __forceinline__ KP kernelParams() { return *(const __attribute__((address_space(4))) L2Params*)__builtin_amdgcn_kernarg_segment_ptr(); }
 
 enum {F_ACTIVE=1u, F_DONE=2u};
 
@@ -86,19 +97,168 @@ struct Follow { EvData d; u32 event, _a, _b, _c; };	// 48 B
 struct StopLog { EvData d; u32 timestamp, _a, _b, _c; };// 48 B
 struct StagedResult { u32 handle, sord, eord, sseg, spos, eseg, epos, dataRef; };	// 32 B
 
-struct WS		// per-wave state, lives in registers
+// ---------------------------------------------------------------- where the per-document state lives
+// This source is compiled twice:
+//  - SPA_L2_LDS (l2_kernel_lds.hip): the hot state of the document -- rules, triggers, the 16 trigger
+//    buckets, expiry window, free stacks, captured items, follow/dispose lists and the scalar
+//    counters -- is a 40 KB slice of LDS owned by a one-wave workgroup (4 workgroups per CU).  Every
+//    step of the automaton is a chain of dependent accesses to that state, so its speed is the
+//    access latency: LDS answers in ~100 cycles where an L2/HBM round trip costs 500-2000.
+//    Capacities are compile-time constants; a document that outgrows them is queued for
+//  - the global tier (l2_kernel.hip): same code, state in a per-wave arena in HBM whose capacities
+//    grow on demand.
+#define LDSQ __attribute__((address_space(3)))
+#ifdef SPA_L2_LDS
+#define HOT LDSQ
+enum {
+	CAP_RULES=160, CAP_TRIGS=256, CAP_BUCKET=40, CAP_FOLLOW=12, CAP_DISPOSE=160, CAP_HEAP=32,
+	WIN_CHUNK=16, WIN_NCHUNKS=40, CAP_SCRATCH=32, CAP_ITEMS=128, CAP_REFS=128
+};
+#else
+#define HOT
+#define CAP_RULES	(P.arena.maxRules)
+#define CAP_TRIGS	(P.arena.maxTrigs)
+#define CAP_BUCKET	(P.arena.bucketCap)
+#define CAP_FOLLOW	(P.arena.maxFollow)
+#define CAP_DISPOSE	(P.arena.maxDispose)
+#define CAP_HEAP	(P.arena.maxHeap)
+#define WIN_CHUNK	(P.arena.winChunk)
+#define WIN_NCHUNKS	(P.arena.winChunks)
+#define CAP_SCRATCH	(P.arena.scratchCap)
+#define CAP_ITEMS	(P.arena.maxItems)
+#define CAP_REFS	(P.arena.maxRefs)
+#endif
+typedef HOT u32 hu32;
+typedef HOT Rule HRule;
+typedef HOT Trig HTrig;
+typedef HOT Item HItem;
+typedef HOT Follow HFollow;
+typedef HOT EvData HEvData;
+
+// Per-wave scalars: one block at the start of the workgroup's LDS (workgroups are single waves), so
+// every function reaches them with a ds_read at a constant address instead of carrying ~30 live
+// values through calls (which the register allocator would spill to scratch memory: 256 B of
+// memory traffic per access).
+struct WS
 {
-	Rule* rules; Trig* trigs; u32* bEvent; u32* bIdx; u32* bSize; u32* window; u32* winArr; u32* scratch; u32* heap;
-	Follow* follow; u32* dispose; StopLog* stop; Item* items; u32* refs; u32* gstack; StagedResult* staged;
-	u32* ruleFree; u32* trigFree; u32* itemFree; u32* refFree;	// stacks of free record indices
 	u32 curpos, timestamp, nInstalled, nAlt, nSignals, nTrig;
 	u64 open;
 	u32 ruleFreeN, ruleUsed, trigFreeN, trigUsed, itemFreeN, itemUsed, refFreeN, refUsed;
 	u32 heapSize, nFollow, nDispose, nStaged, err;
+	u32 winFreeN, winUsed;
 #if defined(SPA_PROF) || defined(SPA_PROF2)
 	u64 prof[4];
 #endif
 };
+typedef LDSQ WS HWS;
+typedef LDSQ u32 lu32;
+typedef LDSQ u64 lu64;
+// Access to one scalar of the wave state: reads come back through readfirstlane, so the value (and
+// the branches and addresses computed from it) stays in scalar registers.
+struct WSField
+{
+	lu32* p;
+	__device__ __forceinline__ operator u32() const { return __builtin_amdgcn_readfirstlane( *p); }
+	__device__ __forceinline__ u32 operator=( u32 v) const { *p = v; return v; }
+	__device__ __forceinline__ u32 operator=( const WSField& o) const { u32 v = o; *p = v; return v; }
+	__device__ __forceinline__ u32 operator+=( u32 v) const { u32 n = (u32)*this + v; *p = n; return n; }
+	__device__ __forceinline__ u32 operator-=( u32 v) const { u32 n = (u32)*this - v; *p = n; return n; }
+	__device__ __forceinline__ u32 operator++() const { return *this += 1u; }
+	__device__ __forceinline__ u32 operator--() const { return *this -= 1u; }
+	__device__ __forceinline__ u32 operator++( int) const { u32 o = *this; *p = o+1; return o; }
+	__device__ __forceinline__ u32 operator--( int) const { u32 o = *this; *p = o-1; return o; }
+};
+struct WSField64
+{
+	lu64* p;
+	__device__ __forceinline__ operator u64() const { u64 v = *p; return ((u64)__builtin_amdgcn_readfirstlane( (u32)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane( (u32)v); }
+	__device__ __forceinline__ void operator=( u64 v) const { *p = v; }
+	__device__ __forceinline__ void operator+=( u64 v) const { *p = (u64)*this + v; }
+};
+struct WSV		// view of the wave state block at `raw` (one LDS address; everything else folds to constants)
+{
+	HWS* raw;
+	u32* arena;		// the wave's arena in HBM
+	WSField curpos, timestamp, nInstalled, nAlt, nSignals, nTrig;
+	WSField64 open;
+	WSField ruleFreeN, ruleUsed, trigFreeN, trigUsed, itemFreeN, itemUsed, refFreeN, refUsed;
+	WSField heapSize, nFollow, nDispose, nStaged, err;
+	WSField winFreeN, winUsed;
+	__device__ __forceinline__ WSV( HWS* b, u32* a)
+		:raw(b),arena(a),curpos{&b->curpos},timestamp{&b->timestamp},nInstalled{&b->nInstalled},nAlt{&b->nAlt},nSignals{&b->nSignals},nTrig{&b->nTrig}
+		,open{&b->open},ruleFreeN{&b->ruleFreeN},ruleUsed{&b->ruleUsed},trigFreeN{&b->trigFreeN},trigUsed{&b->trigUsed}
+		,itemFreeN{&b->itemFreeN},itemUsed{&b->itemUsed},refFreeN{&b->refFreeN},refUsed{&b->refUsed}
+		,heapSize{&b->heapSize},nFollow{&b->nFollow},nDispose{&b->nDispose},nStaged{&b->nStaged},err{&b->err}
+		,winFreeN{&b->winFreeN},winUsed{&b->winUsed} {}
+};
+typedef const WSV& WSR;
+
+#ifdef SPA_L2_LDS
+// LDS slice layout in words from the wave state block (16-byte aligned where records are moved with b128)
+enum {
+	L_WS=0,				L_BSIZE=L_WS+64,		L_WINDOW=L_BSIZE+16,
+	L_RULES=L_WINDOW+64,		L_TRIGS=L_RULES+CAP_RULES*12,	L_BEVENT=L_TRIGS+CAP_TRIGS*8,
+	L_BIDX=L_BEVENT+16*CAP_BUCKET,	L_WINARR=L_BIDX+16*CAP_BUCKET,	L_WINCHUNK=L_WINARR+WIN_NCHUNKS*WIN_CHUNK,
+	L_WINFREE=L_WINCHUNK+64*8,	L_SCRATCH=L_WINFREE+WIN_NCHUNKS,
+	L_HEAP=L_SCRATCH+16*CAP_SCRATCH,L_FOLLOW=L_HEAP+2*CAP_HEAP,	L_DISPOSE=L_FOLLOW+CAP_FOLLOW*12,
+	L_RULEFREE=L_DISPOSE+CAP_DISPOSE,L_TRIGFREE=L_RULEFREE+CAP_RULES,L_ITEMS=L_TRIGFREE+CAP_TRIGS,
+	L_REFS=L_ITEMS+CAP_ITEMS*12,	L_ITEMFREE=L_REFS+CAP_REFS*2,	L_REFFREE=L_ITEMFREE+CAP_ITEMS,
+	L_TOTAL=L_REFFREE+CAP_REFS
+};
+static_assert( sizeof(WS) <= 64*4, "wave state block");
+static_assert( L_TOTAL*4 <= 40*1024, "LDS slice of one wave: 4 waves per CU share 160 KB");
+static_assert( (L_RULES % 4) == 0 && (L_TRIGS % 4) == 0 && (L_FOLLOW % 4) == 0 && (L_ITEMS % 4) == 0, "b128 alignment");
+#define LDSW( OFS)	((hu32*)w.raw + (OFS))
+#define RULES		((HRule*)LDSW( L_RULES))
+#define TRIGS		((HTrig*)LDSW( L_TRIGS))
+#define BEVENT		LDSW( L_BEVENT)
+#define BIDX		LDSW( L_BIDX)
+#define BSIZE		LDSW( L_BSIZE)
+#define WINDOW		LDSW( L_WINDOW)
+#define WINARR		LDSW( L_WINARR)
+#define WINCHUNK	LDSW( L_WINCHUNK)
+#define WINFREE		LDSW( L_WINFREE)
+#define SCRATCH		LDSW( L_SCRATCH)
+#define HEAP		LDSW( L_HEAP)
+#define FOLLOW		((HFollow*)LDSW( L_FOLLOW))
+#define DISPOSE		LDSW( L_DISPOSE)
+#define RULEFREE	LDSW( L_RULEFREE)
+#define TRIGFREE	LDSW( L_TRIGFREE)
+#define ITEMS		((HItem*)LDSW( L_ITEMS))
+#define REFS		LDSW( L_REFS)
+#define ITEMFREE	LDSW( L_ITEMFREE)
+#define REFFREE		LDSW( L_REFFREE)
+// the rest stays in the wave's arena in HBM: written once per event at most, read at document end
+#define COLD( OFS)	(w.arena + (OFS))
+#define STOP		((StopLog*)COLD( P.arena.oStop))
+#define GSTACK		COLD( P.arena.oGStack)
+#define STAGED		((StagedResult*)COLD( P.arena.oStaged))
+#else
+// the wave's arena in HBM (workgroup = one wave)
+#define ARENA( OFS)	(w.arena + (OFS))
+#define RULES		((Rule*)ARENA( P.arena.oRules))
+#define TRIGS		((Trig*)ARENA( P.arena.oTrigs))
+#define BEVENT		ARENA( P.arena.oBEvent)
+#define BIDX		ARENA( P.arena.oBIdx)
+#define BSIZE		ARENA( P.arena.oBSize)
+#define WINDOW		ARENA( P.arena.oWindow)
+#define WINARR		ARENA( P.arena.oWinArr)
+#define WINCHUNK	ARENA( P.arena.oWinChunk)
+#define WINFREE		ARENA( P.arena.oWinFree)
+#define SCRATCH		ARENA( P.arena.oScratch)
+#define HEAP		ARENA( P.arena.oHeap)
+#define FOLLOW		((Follow*)ARENA( P.arena.oFollow))
+#define DISPOSE		ARENA( P.arena.oDispose)
+#define RULEFREE	ARENA( P.arena.oRuleFree)
+#define TRIGFREE	ARENA( P.arena.oTrigFree)
+#define ITEMS		((Item*)ARENA( P.arena.oItems))
+#define REFS		ARENA( P.arena.oRefs)
+#define ITEMFREE	ARENA( P.arena.oItemFree)
+#define REFFREE		ARENA( P.arena.oRefFree)
+#define STOP		((StopLog*)ARENA( P.arena.oStop))
+#define GSTACK		ARENA( P.arena.oGStack)
+#define STAGED		((StagedResult*)ARENA( P.arena.oStaged))
+#endif
 
 __device__ __forceinline__ u32 evhash( u32 a)		// src/ruleMatcherAutomaton.cpp:34-40
 {
@@ -110,149 +270,165 @@ __device__ __forceinline__ u32 evhash( u32 a)		// src/ruleMatcherAutomaton.cpp:3
 
 __device__ __forceinline__ u32 bcast0( u32 v) { return __builtin_amdgcn_readfirstlane( v); }
 
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
 // Wave-uniform load: every lane reads the same address; the value is moved to a scalar register so
 // that everything computed from it (indices, loop bounds, branch conditions) stays scalar and the
 // control flow of the automaton is made of scalar branches, not exec-masked vector loops.
 __device__ __forceinline__ u32 ldu( const u32* p) { return __builtin_amdgcn_readfirstlane( *p); }
-// 16-byte accesses: one vector-memory instruction moves a quarter/third/half of a record
-__device__ __forceinline__ uint4 ld4( const void* p) { return *(const uint4*)p; }
-__device__ __forceinline__ uint4 ldu4( const void* p)
+// 16-byte accesses: one memory instruction moves a quarter/third/half of a record
+__device__ __forceinline__ uint4 ld4( const void* p) { const u32x4 v = *(const u32x4*)p; return make_uint4( v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st4( void* p, u32 a, u32 b, u32 c, u32 d) { u32x4 v; v.x = a; v.y = b; v.z = c; v.w = d; *(u32x4*)p = v; }
+__device__ __forceinline__ u32* W( void* p) { return (u32*)p; }
+__device__ __forceinline__ const u32* W( const void* p) { return (const u32*)p; }
+__device__ __forceinline__ u32 ldu( const lu32* p) { return __builtin_amdgcn_readfirstlane( *p); }
+__device__ __forceinline__ uint4 ld4( const LDSQ void* p) { const u32x4 v = *(const LDSQ u32x4*)p; return make_uint4( v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st4( LDSQ void* p, u32 a, u32 b, u32 c, u32 d) { u32x4 v; v.x = a; v.y = b; v.z = c; v.w = d; *(LDSQ u32x4*)p = v; }
+__device__ __forceinline__ lu32* W( LDSQ void* p) { return (lu32*)p; }
+__device__ __forceinline__ const lu32* W( const LDSQ void* p) { return (const lu32*)p; }
+template <class PTR>
+__device__ __forceinline__ uint4 ldu4( PTR p)
 {
-	uint4 v = *(const uint4*)p;
+	uint4 v = ld4( p);
 	v.x = __builtin_amdgcn_readfirstlane( v.x); v.y = __builtin_amdgcn_readfirstlane( v.y);
 	v.z = __builtin_amdgcn_readfirstlane( v.z); v.w = __builtin_amdgcn_readfirstlane( v.w);
 	return v;
 }
-__device__ __forceinline__ void st4( void* p, u32 a, u32 b, u32 c, u32 d) { *(uint4*)p = make_uint4( a, b, c, d); }
-
-__device__ __forceinline__ void ldEv( EvData& d, const EvData* p)
+template <class PTR>
+__device__ __forceinline__ void ldEv( EvData& d, PTR p)
 {
-	const uint4 a = ldu4( p), b = ldu4( (const u32*)p + 4);
+	const uint4 a = ldu4( p), b = ldu4( W( p) + 4);
 	d.sseg = a.x; d.eseg = a.y; d.spos = a.z; d.epos = a.w; d.sord = b.x; d.eord = b.y; d.sub = b.z; d.fmt = b.w;
+}
+template <class PTR>
+__device__ __forceinline__ void stEv( PTR p, const EvData& d)
+{
+	st4( p, d.sseg, d.eseg, d.spos, d.epos);
+	st4( W( p) + 4, d.sord, d.eord, d.sub, d.fmt);
 }
 
 // ---------------------------------------------------------------- allocators
 // Which index a new record gets is not observable (only list orders are), so freed indices are
 // kept on plain stacks: a whole batch of lanes can pop its indices with one gather.
-__device__ __forceinline__ u32 allocRule( WS& w, const L2Params& P)
+__device__ __forceinline__ u32 allocRule( WSR w, KP P)
 {
 	u32 r;
-	if (w.ruleFreeN) { r = ldu( &w.ruleFree[ --w.ruleFreeN]); }
-	else if (w.ruleUsed < P.arena.maxRules) { r = w.ruleUsed++; }
-	else { w.err = SPD_ERR_ARENA; r = 0; }
+	if (w.ruleFreeN) { r = ldu( &RULEFREE[ --w.ruleFreeN]); }
+	else if (w.ruleUsed < CAP_RULES) { r = w.ruleUsed++; }
+	else { ARENA_FAIL; r = 0; }
 	return r;
 }
-__device__ __forceinline__ void freeRule( WS& w, u32 r)
+__device__ __forceinline__ void freeRule( WSR w, KP P, u32 r)
 {
-	w.ruleFree[ w.ruleFreeN++] = r;
+	RULEFREE[ w.ruleFreeN++] = r;
 }
-__device__ __forceinline__ u32 allocTrig( WS& w, const L2Params& P)
+__device__ __forceinline__ u32 allocTrig( WSR w, KP P)
 {
 	u32 t;
-	if (w.trigFreeN) { t = ldu( &w.trigFree[ --w.trigFreeN]); }
-	else if (w.trigUsed < P.arena.maxTrigs) { t = w.trigUsed++; }
-	else { w.err = SPD_ERR_ARENA; t = 0; }
+	if (w.trigFreeN) { t = ldu( &TRIGFREE[ --w.trigFreeN]); }
+	else if (w.trigUsed < CAP_TRIGS) { t = w.trigUsed++; }
+	else { ARENA_FAIL; t = 0; }
 	return t;
 }
-__device__ __forceinline__ void freeTrig( WS& w, u32 t)
+__device__ __forceinline__ void freeTrig( WSR w, KP P, u32 t)
 {
-	w.trigFree[ w.trigFreeN++] = t;
+	TRIGFREE[ w.trigFreeN++] = t;
 }
-__device__ __forceinline__ u32 allocItem( WS& w, const L2Params& P)
+__device__ __forceinline__ u32 allocItem( WSR w, KP P)
 {
 	u32 t;
-	if (w.itemFreeN) { t = ldu( &w.itemFree[ --w.itemFreeN]); }
-	else if (w.itemUsed < P.arena.maxItems) { t = w.itemUsed++; }
-	else { w.err = SPD_ERR_ARENA; t = 0; }
+	if (w.itemFreeN) { t = ldu( &ITEMFREE[ --w.itemFreeN]); }
+	else if (w.itemUsed < CAP_ITEMS) { t = w.itemUsed++; }
+	else { ARENA_FAIL; t = 0; }
 	return t;
 }
 // data references: refs[2i] = head of the item list (1-based), refs[2i+1] = reference count
-__device__ __forceinline__ u32 createRef( WS& w, const L2Params& P)	// cpp:750-753
+__device__ __forceinline__ u32 createRef( WSR w, KP P)	// cpp:750-753
 {
 	u32 t;
-	if (w.refFreeN) { t = ldu( &w.refFree[ --w.refFreeN]); }
-	else if (w.refUsed < P.arena.maxRefs) { t = w.refUsed++; }
-	else { w.err = SPD_ERR_ARENA; return 0; }
-	w.refs[ 2*t] = 0; w.refs[ 2*t+1] = 1;
+	if (w.refFreeN) { t = ldu( &REFFREE[ --w.refFreeN]); }
+	else if (w.refUsed < CAP_REFS) { t = w.refUsed++; }
+	else { ARENA_FAIL; return 0; }
+	REFS[ 2*t] = 0; REFS[ 2*t+1] = 1;
 	return t+1;
 }
-__device__ __forceinline__ void addRef( WS& w, u32 ref) { w.refs[ 2*(ref-1)+1] = ldu( &w.refs[ 2*(ref-1)+1]) + 1; }	// cpp:734-738
+__device__ __forceinline__ void addRef( WSR w, KP P, u32 ref) { REFS[ 2*(ref-1)+1] = ldu( &REFS[ 2*(ref-1)+1]) + 1; }	// cpp:734-738
 
-__device__ void disposeRef( WS& w, u32 ref)				// cpp:710-732
+__device__ __forceinline__ void disposeRef( WSR w, KP P, u32 ref)				// cpp:710-732
 {
-	u32 cnt = ldu( &w.refs[ 2*(ref-1)+1]);
-	if (cnt > 1) { w.refs[ 2*(ref-1)+1] = cnt-1; }
+	u32 cnt = ldu( &REFS[ 2*(ref-1)+1]);
+	if (cnt > 1) { REFS[ 2*(ref-1)+1] = cnt-1; }
 	else if (cnt == 1)
 	{
-		u32 it = ldu( &w.refs[ 2*(ref-1)]);
+		u32 it = ldu( &REFS[ 2*(ref-1)]);
 		for (u32 guard=0; it; ++guard)
 		{
 			if (guard > w.itemUsed) { w.err = SPD_ERR_INTERNAL; break; }
-			u32 nx = ldu( &w.items[ it-1].next);
-			w.itemFree[ w.itemFreeN++] = it-1;
+			u32 nx = ldu( &ITEMS[ it-1].next);
+			ITEMFREE[ w.itemFreeN++] = it-1;
 			it = nx;
 		}
-		w.refs[ 2*(ref-1)+1] = 0;
-		w.refFree[ w.refFreeN++] = ref-1;
+		REFS[ 2*(ref-1)+1] = 0;
+		REFFREE[ w.refFreeN++] = ref-1;
 	}
 	else { w.err = SPD_ERR_DATAREF; }
 }
 
-__device__ void appendItem( WS& w, const L2Params& P, u32 ref, u32 variable, const EvData& d)	// cpp:740-748
+__device__ __forceinline__ void appendItem( WSR w, KP P, u32 ref, u32 variable, const EvData& d)	// cpp:740-748
 {
-	if (d.sub) addRef( w, d.sub);
+	if (d.sub) addRef( w, P, d.sub);
 	u32 it = allocItem( w, P);
 	if (w.err) return;
-	Item* I = &w.items[ it];
-	I->variable = variable; I->d = d;
-	I->next = ldu( &w.refs[ 2*(ref-1)]);
-	w.refs[ 2*(ref-1)] = it+1;
+	HItem* I = &ITEMS[ it];
+	I->variable = variable; stEv( &I->d, d);
+	I->next = ldu( &REFS[ 2*(ref-1)]);
+	REFS[ 2*(ref-1)] = it+1;
 }
 
-__device__ void joinItems( WS& w, const L2Params& P, u32 dest, u32 src)	// cpp:755-770
+__device__ __forceinline__ void joinItems( WSR w, KP P, u32 dest, u32 src)	// cpp:755-770
 {
-	u32 it = ldu( &w.refs[ 2*(src-1)]);
+	u32 it = ldu( &REFS[ 2*(src-1)]);
 	for (u32 guard=0; it && !w.err; ++guard)
 	{
-		if (guard > P.arena.maxItems) { w.err = SPD_ERR_INTERNAL; break; }
-		Item* S = &w.items[ it-1];
+		if (guard > CAP_ITEMS) { w.err = SPD_ERR_INTERNAL; break; }
+		HItem* S = &ITEMS[ it-1];
 		u32 variable = ldu( &S->variable); EvData d; ldEv( d, &S->d); it = ldu( &S->next);
 		appendItem( w, P, dest, variable, d);
 	}
 }
 
 // ---------------------------------------------------------------- event trigger table (cpp:114-257)
-__device__ __forceinline__ void addTrigger( WS& w, const L2Params& P, u32 t, u32 event)
+__device__ __forceinline__ void addTrigger( WSR w, KP P, u32 t, u32 event)
 {
 	u32 h = evhash( event) & 15u;
-	u32 pos = ldu( &w.bSize[ h]);
-	if (pos >= P.arena.bucketCap) { w.err = SPD_ERR_ARENA; return; }
-	w.bEvent[ h*P.arena.bucketCap + pos] = event;
-	w.bIdx[ h*P.arena.bucketCap + pos] = t;
-	w.bSize[ h] = pos+1;
-	w.trigs[ t].link = (h << 28) | pos;
+	u32 pos = ldu( &BSIZE[ h]);
+	if (pos >= CAP_BUCKET) { ARENA_FAIL; return; }
+	BEVENT[ h*CAP_BUCKET + pos] = event;
+	BIDX[ h*CAP_BUCKET + pos] = t;
+	BSIZE[ h] = pos+1;
+	TRIGS[ t].link = (h << 28) | pos;
 	w.nTrig += 1;
 }
-__device__ __forceinline__ void removeTrigger( WS& w, const L2Params& P, u32 t)	// swap with last, cpp:133-152
+__device__ __forceinline__ void removeTrigger( WSR w, KP P, u32 t)	// swap with last, cpp:133-152
 {
-	u32 link = ldu( &w.trigs[ t].link);
+	u32 link = ldu( &TRIGS[ t].link);
 	u32 h = link >> 28, pos = link & 0x0FFFFFFFu;
-	u32 last = ldu( &w.bSize[ h])-1;
+	u32 last = ldu( &BSIZE[ h])-1;
 	if (pos != last)
 	{
-		u32 me = ldu( &w.bEvent[ h*P.arena.bucketCap + last]);
-		u32 mi = ldu( &w.bIdx[ h*P.arena.bucketCap + last]);
-		w.bEvent[ h*P.arena.bucketCap + pos] = me;
-		w.bIdx[ h*P.arena.bucketCap + pos] = mi;
-		w.trigs[ mi].link = link;
+		u32 me = ldu( &BEVENT[ h*CAP_BUCKET + last]);
+		u32 mi = ldu( &BIDX[ h*CAP_BUCKET + last]);
+		BEVENT[ h*CAP_BUCKET + pos] = me;
+		BIDX[ h*CAP_BUCKET + pos] = mi;
+		TRIGS[ mi].link = link;
 	}
-	w.bSize[ h] = last;
+	BSIZE[ h] = last;
 	w.nTrig -= 1;
 }
 
-__device__ void deactivateRule( WS& w, const L2Params& P, u32 r)	// cpp:679-702
+__device__ __forceinline__ void deactivateRule( WSR w, KP P, u32 r)	// cpp:679-702
 {
-	Rule* R = &w.rules[ r];
+	HRule* R = &RULES[ r];
 	u32 flags = ldu( &R->flags);
 	if (flags & F_ACTIVE)
 	{
@@ -261,14 +437,14 @@ __device__ void deactivateRule( WS& w, const L2Params& P, u32 r)	// cpp:679-702
 		for (u32 guard=0; t; ++guard)
 		{
 			if (guard > w.trigUsed) { w.err = SPD_ERR_INTERNAL; break; }
-			u32 nx = ldu( &w.trigs[ t-1].next);
+			u32 nx = ldu( &TRIGS[ t-1].next);
 			removeTrigger( w, P, t-1);
-			freeTrig( w, t-1);
+			freeTrig( w, P, t-1);
 			t = nx;
 		}
 		R->trigHead = 0;
 		u32 ref = ldu( &R->dataRef);
-		if (ref) { disposeRef( w, ref); R->dataRef = 0; }
+		if (ref) { disposeRef( w, P, ref); R->dataRef = 0; }
 	}
 }
 
@@ -291,8 +467,9 @@ __device__ __forceinline__ u32 byteField( u32 c0, u32 c1, u32 c2, u32 c3, u32 h)
 // order and is done one rule per lane.
 enum {DEACT_MAXCHAIN=4};
 
-__device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 n, bool reversed, bool freeRules, bool checkDup)
+__device__ __noinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP P, const hu32* list, u32 n, bool reversed, bool freeRules, bool checkDup)
 {
+	const WSV w( wsBlock, wsArena);
 	for (u32 base=0; base<n && !w.err; base+=64)
 	{
 		const u32 nb = (n - base) < 64u ? (n - base) : 64u;
@@ -303,10 +480,10 @@ __device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 
 		u32 head = 0, ref = 0;
 		if (have)
 		{
-			Rule* R = &w.rules[ r];
+			HRule* R = &RULES[ r];
 			u32 flags = R->flags;
 			act = (flags & F_ACTIVE) != 0;
-			if (act) { const uint4 q2 = ld4( (const u32*)R + 8); head = q2.x; ref = q2.y; }
+			if (act) { const uint4 q2 = ld4( W( R) + 8); head = q2.x; ref = q2.y; }
 		}
 		if (checkDup)
 		{
@@ -320,7 +497,7 @@ __device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 
 		}
 		if (act)
 		{
-			Rule* R = &w.rules[ r];
+			HRule* R = &RULES[ r];
 			R->flags = R->flags & ~F_ACTIVE; R->trigHead = 0; R->dataRef = 0;
 		}
 		// trigger chains (short: one per installed template)
@@ -329,26 +506,26 @@ __device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 
 		for (int c=0; c<DEACT_MAXCHAIN; ++c)
 		{
 			t[ c] = 0;
-			if (act && head) { t[ c] = head-1; head = w.trigs[ head-1].next; ++nt; }
+			if (act && head) { t[ c] = head-1; head = TRIGS[ head-1].next; ++nt; }
 		}
 		if (act && head) longChain = true;
 		if (__ballot( longChain))
 		{
 			// rare: finish this block one rule at a time (flags were cleared above: restore, then serial)
-			if (act) { Rule* R = &w.rules[ r]; R->flags = R->flags | F_ACTIVE; R->trigHead = t[0]+1; R->dataRef = ref; }
+			if (act) { HRule* R = &RULES[ r]; R->flags = R->flags | F_ACTIVE; R->trigHead = t[0]+1; R->dataRef = ref; }
 			__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 			for (u32 k=0; k<nb && !w.err; ++k)
 			{
 				u32 rk = (u32)__builtin_amdgcn_readlane( r, k);
 				deactivateRule( w, P, rk);
-				if (freeRules) freeRule( w, rk);
+				if (freeRules) freeRule( w, P, rk);
 			}
 			continue;
 		}
 		// stable partition of the triggers by bucket: scratch[b*cap + rank]
 		u32 hOf[ DEACT_MAXCHAIN];
 #pragma unroll
-		for (int c=0; c<DEACT_MAXCHAIN; ++c) hOf[ c] = ((u32)c < nt) ? (w.trigs[ t[ c]].link >> 28) : 16u;
+		for (int c=0; c<DEACT_MAXCHAIN; ++c) hOf[ c] = ((u32)c < nt) ? (TRIGS[ t[ c]].link >> 28) : 16u;
 		u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
 		for (int c=0; c<DEACT_MAXCHAIN; ++c)
@@ -378,7 +555,7 @@ __device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 
 			return (f & 2u) ? (v >> 16) : (v & 0xFFFFu);
 		};
 		auto own = [&]( u32 h) -> u32 { return byteField( c0, c1, c2, c3, h); };
-		const u32 scap = P.arena.scratchCap;
+		const u32 scap = CAP_SCRATCH;
 		u32 seen0 = 0, seen1 = 0, seen2 = 0, seen3 = 0;	// my own earlier triggers per bucket
 		u32 ntot = 0;
 #pragma unroll
@@ -389,13 +566,13 @@ __device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 
 				const u32 h = hOf[ c];
 				const u32 mineBefore = byteField( seen0, seen1, seen2, seen3, h);
 				const u32 rankInBucket = incl( h) - own( h) + mineBefore;
-				if (rankInBucket < scap) w.scratch[ h*scap + rankInBucket] = t[ c]; else w.err = SPD_ERR_ARENA;
+				if (rankInBucket < scap) SCRATCH[ h*scap + rankInBucket] = t[ c]; else ARENA_FAIL;
 				u32 inc = 1u << ((h & 3u)*8), ws = h >> 2;
 				if (ws == 0) seen0 += inc; else if (ws == 1) seen1 += inc; else if (ws == 2) seen2 += inc; else seen3 += inc;
 				++ntot;
 			}
 		}
-		if (__ballot( w.err != 0)) { w.err = SPD_ERR_ARENA; return; }
+		if (__ballot( w.err != 0)) { ARENA_FAIL; return; }
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		// lane b replays the removals of bucket b (cpp:133-152)
 		{
@@ -419,24 +596,24 @@ __device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 
 			if (myCount)
 			{
 				const u32 b = LANE;
-				u32* be = w.bEvent + b*P.arena.bucketCap;
-				u32* bi = w.bIdx + b*P.arena.bucketCap;
-				u32 size = w.bSize[ b];
+				hu32* be = BEVENT + b*CAP_BUCKET;
+				hu32* bi = BIDX + b*CAP_BUCKET;
+				u32 size = BSIZE[ b];
 				for (u32 k=0; k<myCount; ++k)
 				{
-					const u32 tk = w.scratch[ b*scap + k];
-					const u32 link = w.trigs[ tk].link;
+					const u32 tk = SCRATCH[ b*scap + k];
+					const u32 link = TRIGS[ tk].link;
 					const u32 pos = link & 0x0FFFFFFFu;
 					const u32 last = size-1;
 					if (pos != last)
 					{
 						const u32 me = be[ last], mi = bi[ last];
 						be[ pos] = me; bi[ pos] = mi;
-						w.trigs[ mi].link = link;
+						TRIGS[ mi].link = link;
 					}
 					size = last;
 				}
-				w.bSize[ b] = size;
+				BSIZE[ b] = size;
 			}
 		}
 		// release the trigger records
@@ -446,7 +623,7 @@ __device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 
 			const u32 totalT = (u32)__builtin_amdgcn_readlane( incT, 63);
 			u32 at = w.trigFreeN + incT - ntot;
 #pragma unroll
-			for (int c=0; c<DEACT_MAXCHAIN; ++c) if ((u32)c < nt) w.trigFree[ at++] = t[ c];
+			for (int c=0; c<DEACT_MAXCHAIN; ++c) if ((u32)c < nt) TRIGFREE[ at++] = t[ c];
 			w.trigFreeN += totalT;
 			w.nTrig -= totalT;
 		}
@@ -457,13 +634,13 @@ __device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 
 			u32 nfree = 0; bool freeRef = false;
 			if (act && ref)
 			{
-				u32 cnt = w.refs[ 2*(ref-1)+1];
-				if (cnt > 1) w.refs[ 2*(ref-1)+1] = cnt-1;
+				u32 cnt = REFS[ 2*(ref-1)+1];
+				if (cnt > 1) REFS[ 2*(ref-1)+1] = cnt-1;
 				else if (cnt == 1)
 				{
 					freeRef = true;
-					for (u32 it=w.refs[ 2*(ref-1)], g=0; it; it=w.items[ it-1].next, ++g) { ++nfree; if (g > w.itemUsed) { bad = true; break; } }
-					w.refs[ 2*(ref-1)+1] = 0;
+					for (u32 it=REFS[ 2*(ref-1)], g=0; it; it=ITEMS[ it-1].next, ++g) { ++nfree; if (g > w.itemUsed) { bad = true; break; } }
+					REFS[ 2*(ref-1)+1] = 0;
 				}
 				else bad = true;
 			}
@@ -474,16 +651,16 @@ __device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 
 			if (freeRef)
 			{
 				u32 at = w.itemFreeN + incI - nfree;
-				for (u32 it=w.refs[ 2*(ref-1)]; it; ) { u32 nx = w.items[ it-1].next; w.itemFree[ at++] = it-1; it = nx; }
+				for (u32 it=REFS[ 2*(ref-1)]; it; ) { u32 nx = ITEMS[ it-1].next; ITEMFREE[ at++] = it-1; it = nx; }
 			}
 			const u64 fm = __ballot( freeRef);
-			if (freeRef) w.refFree[ w.refFreeN + (u32)__popcll( fm & lanesBelow())] = ref-1;
+			if (freeRef) REFFREE[ w.refFreeN + (u32)__popcll( fm & lanesBelow())] = ref-1;
 			w.itemFreeN += totalI;
 			w.refFreeN += (u32)__popcll( fm);
 		}
 		if (freeRules)
 		{
-			if (have) w.ruleFree[ w.ruleFreeN + LANE] = r;
+			if (have) RULEFREE[ w.ruleFreeN + LANE] = r;
 			w.ruleFreeN += nb;
 		}
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
@@ -493,75 +670,112 @@ __device__ void deactivateBatch( WS& w, const L2Params& P, const u32* list, u32 
 // ---------------------------------------------------------------- expiry (cpp:1066-1135)
 // far-expiry queue: binary heap on `pos` (min-heap via the inverted comparison of hpp:425-428),
 // sifted exactly like libstdc++'s __push_heap/__adjust_heap so ties come out in the same order.
-__device__ void heapPush( WS& w, const L2Params& P, u32 pos, u32 idx)
+__device__ __forceinline__ void heapPush( WSR w, KP P, u32 pos, u32 idx)
 {
-	if (w.heapSize >= P.arena.maxHeap) { w.err = SPD_ERR_ARENA; return; }
+	if (w.heapSize >= CAP_HEAP) { ARENA_FAIL; return; }
 	u32 hole = w.heapSize++;
 	while (hole > 0)
 	{
 		u32 parent = (hole-1) >> 1;
-		u32 ppos = ldu( &w.heap[ 2*parent]);
+		u32 ppos = ldu( &HEAP[ 2*parent]);
 		if (!(ppos > pos)) break;			// comp(parent, value) == parent.pos > value.pos
-		w.heap[ 2*hole] = ppos; w.heap[ 2*hole+1] = ldu( &w.heap[ 2*parent+1]);
+		HEAP[ 2*hole] = ppos; HEAP[ 2*hole+1] = ldu( &HEAP[ 2*parent+1]);
 		hole = parent;
 	}
-	w.heap[ 2*hole] = pos; w.heap[ 2*hole+1] = idx;
+	HEAP[ 2*hole] = pos; HEAP[ 2*hole+1] = idx;
 }
-__device__ void heapPop( WS& w)
+__device__ __forceinline__ void heapPop( WSR w, KP P)
 {
 	u32 n = w.heapSize;
 	if (n > 1)
 	{
 		u32 len = n-1;
-		u32 vpos = ldu( &w.heap[ 2*len]), vidx = ldu( &w.heap[ 2*len+1]);
+		u32 vpos = ldu( &HEAP[ 2*len]), vidx = ldu( &HEAP[ 2*len+1]);
 		u32 hole = 0, child = 0;
 		while (child < (len-1)/2)
 		{
 			child = 2*(child+1);
-			if (ldu( &w.heap[ 2*child]) > ldu( &w.heap[ 2*(child-1)])) child--;	// comp(first[child], first[child-1])
-			w.heap[ 2*hole] = ldu( &w.heap[ 2*child]); w.heap[ 2*hole+1] = ldu( &w.heap[ 2*child+1]);
+			if (ldu( &HEAP[ 2*child]) > ldu( &HEAP[ 2*(child-1)])) child--;	// comp(first[child], first[child-1])
+			HEAP[ 2*hole] = ldu( &HEAP[ 2*child]); HEAP[ 2*hole+1] = ldu( &HEAP[ 2*child+1]);
 			hole = child;
 		}
 		if ((len & 1) == 0 && child == (len-2)/2)
 		{
 			child = 2*(child+1);
-			w.heap[ 2*hole] = ldu( &w.heap[ 2*(child-1)]); w.heap[ 2*hole+1] = ldu( &w.heap[ 2*(child-1)+1]);
+			HEAP[ 2*hole] = ldu( &HEAP[ 2*(child-1)]); HEAP[ 2*hole+1] = ldu( &HEAP[ 2*(child-1)+1]);
 			hole = child-1;
 		}
 		while (hole > 0)
 		{
 			u32 parent = (hole-1) >> 1;
-			u32 ppos = ldu( &w.heap[ 2*parent]);
+			u32 ppos = ldu( &HEAP[ 2*parent]);
 			if (!(ppos > vpos)) break;
-			w.heap[ 2*hole] = ppos; w.heap[ 2*hole+1] = ldu( &w.heap[ 2*parent+1]);
+			HEAP[ 2*hole] = ppos; HEAP[ 2*hole+1] = ldu( &HEAP[ 2*parent+1]);
 			hole = parent;
 		}
-		w.heap[ 2*hole] = vpos; w.heap[ 2*hole+1] = vidx;
+		HEAP[ 2*hole] = vpos; HEAP[ 2*hole+1] = vidx;
 	}
 	w.heapSize = n-1;
 }
 
-__device__ __forceinline__ void defineDisposeRule( WS& w, const L2Params& P, u32 pos, u32 r)	// cpp:1066-1082
+// ---- expiry window (cpp:1066-1082): the rules that expire at one of the next 64 positions, per
+// position in definition order.  A position's list is a sequence of fixed-size chunks taken from a
+// pool (a rule sits in exactly one list, so the pool is bounded by the number of live rules, while
+// a single position may receive a whole batch of 64 installs at once).
+__device__ __forceinline__ u32 winAllocChunk( WSR w, KP P)
+{
+	if (w.winFreeN) return ldu( &WINFREE[ --w.winFreeN]);
+	if (w.winUsed < WIN_NCHUNKS) return w.winUsed++;
+	ARENA_FAIL;
+	return 0;
+}
+// make room for `n` more entries in the list of `slot` (currently `cnt` entries)
+__device__ __forceinline__ void winReserve( WSR w, KP P, u32 slot, u32 cnt, u32 n)
+{
+	const u32 C = WIN_CHUNK;
+	u32 have = (cnt + C-1) / C;
+	const u32 need = (cnt + n + C-1) / C;
+	if (need > 8u) { ARENA_FAIL; return; }
+	for (; have < need && !w.err; ++have) { const u32 c = winAllocChunk( w, P); WINCHUNK[ slot*8 + have] = c; }
+}
+__device__ __forceinline__ u32 winEntryIndex( WSR w, KP P, u32 slot, u32 i)	// may be called per lane
+{
+	const u32 C = WIN_CHUNK;
+	return WINCHUNK[ slot*8 + i/C]*C + (i % C);
+}
+__device__ __forceinline__ void winAppendOne( WSR w, KP P, u32 slot, u32 r)
+{
+	const u32 cnt = ldu( &WINDOW[ slot]);
+	winReserve( w, P, slot, cnt, 1);
+	if (w.err) return;
+	WINARR[ winEntryIndex( w, P, slot, cnt)] = r;
+	WINDOW[ slot] = cnt+1;
+}
+// copy the list of `slot` to DISPOSE[0..cnt) (free while no transition is running) and release its chunks
+__device__ __forceinline__ void winTake( WSR w, KP P, u32 slot, u32 cnt)
+{
+	if (cnt > CAP_DISPOSE) { ARENA_FAIL; return; }
+	for (u32 i=LANE; i<cnt; i+=64) DISPOSE[ i] = WINARR[ winEntryIndex( w, P, slot, i)];
+	const u32 C = WIN_CHUNK, nc = (cnt + C-1) / C;
+	if (LANE < nc) WINFREE[ w.winFreeN + LANE] = WINCHUNK[ slot*8 + LANE];
+	w.winFreeN += nc;
+	WINDOW[ slot] = 0;
+}
+
+__device__ __forceinline__ void defineDisposeRule( WSR w, KP P, u32 pos, u32 r)	// cpp:1066-1082
 {
 	// pos >= curpos always holds here: installProgram has rejected expired programs
-	if (pos < w.curpos + 64u)
-	{
-		u32 widx = pos & 63u;
-		const u32 cnt = ldu( &w.window[ widx]);
-		if (cnt >= P.arena.winCap) { w.err = SPD_ERR_ARENA; return; }
-		w.winArr[ widx*P.arena.winCap + cnt] = r;
-		w.window[ widx] = cnt+1;
-	}
+	if (pos < w.curpos + 64u) winAppendOne( w, P, pos & 63u, r);
 	else heapPush( w, P, pos, r);
 }
 
-__device__ __forceinline__ void disposeRule( WS& w, const L2Params& P, u32 r)	// cpp:704-708
+__device__ __forceinline__ void disposeRule( WSR w, KP P, u32 r)	// cpp:704-708
 {
 	deactivateRule( w, P, r);
-	freeRule( w, r);
+	freeRule( w, P, r);
 }
 
-__device__ void setCurrentPos( WS& w, const L2Params& P, u32 pos)	// cpp:1084-1135
+__device__ __forceinline__ void setCurrentPos( WSR w, KP P, u32 pos)	// cpp:1084-1135
 {
 	if (w.curpos == pos) return;
 	u32 wcnt = 0;
@@ -570,42 +784,41 @@ __device__ void setCurrentPos( WS& w, const L2Params& P, u32 pos)	// cpp:1084-11
 		u32 widx = w.curpos & 63u;
 		if (widx == 0)
 		{
-			while (w.heapSize && ldu( &w.heap[0]) < w.curpos + 64u)
+			while (w.heapSize && ldu( &HEAP[0]) < w.curpos + 64u)
 			{
 				wcnt = 0;
-				u32 hp = ldu( &w.heap[0]), hr = ldu( &w.heap[1]);
-				const u32 hcnt = ldu( &w.window[ hp & 63u]);
-				if (hcnt >= P.arena.winCap) { w.err = SPD_ERR_ARENA; return; }
-				w.winArr[ (hp & 63u)*P.arena.winCap + hcnt] = hr;
-				w.window[ hp & 63u] = hcnt+1;
-				heapPop( w);
+				u32 hp = ldu( &HEAP[0]), hr = ldu( &HEAP[1]);
+				winAppendOne( w, P, hp & 63u, hr);
+				if (w.err) return;
+				heapPop( w, P);
 			}
 		}
-		const u32 cnt = ldu( &w.window[ widx]);
+		const u32 cnt = ldu( &WINDOW[ widx]);
 		if (cnt)
 		{
 			// the rules of this position, last defined first (the reference's LIFO list order)
-			deactivateBatch( w, P, w.winArr + widx*P.arena.winCap, cnt, true/*reversed*/, true/*free the rules*/, false);
-			w.window[ widx] = 0;
+			winTake( w, P, widx, cnt);
+			if (w.err) return;
+			deactivateBatch( w.raw, w.arena, P, DISPOSE, cnt, true/*reversed*/, true/*free the rules*/, false);
 		}
 	}
 	if (w.curpos < pos)
 	{
 		w.curpos = pos;
-		while (w.heapSize && ldu( &w.heap[0]) < w.curpos)
+		while (w.heapSize && ldu( &HEAP[0]) < w.curpos)
 		{
-			u32 hr = ldu( &w.heap[1]);
-			heapPop( w);
+			u32 hr = ldu( &HEAP[1]);
+			heapPop( w, P);
 			disposeRule( w, P, hr);
 		}
 	}
 }
 
 // ---------------------------------------------------------------- fireSignal (cpp:772-979)
-__device__ void fireSignal( WS& w, const L2Params& P, u32 r, u32 sigtype, u32 sigval, u32 variable, const EvData& d)
+__device__ __forceinline__ void fireSignal( WSR w, KP P, u32 r, u32 sigtype, u32 sigval, u32 variable, const EvData& d)
 {
-	Rule* R = &w.rules[ r];
-	const uint4 q0 = ldu4( R), q1 = ldu4( (const u32*)R + 4);		// {value,count,flags,start_ordpos} {end_ordpos,start_origseg,start_origpos,program}
+	HRule* R = &RULES[ r];
+	const uint4 q0 = ldu4( R), q1 = ldu4( W( R) + 4);		// {value,count,flags,start_ordpos} {end_ordpos,start_origseg,start_origpos,program}
 	u32 value = q0.x, count = q0.y, flags = q0.z, end_ordpos = q1.x;
 	bool match = false, take = false, fin = false;
 	w.nSignals += 1;
@@ -653,7 +866,7 @@ __device__ void fireSignal( WS& w, const L2Params& P, u32 r, u32 sigtype, u32 si
 			break;
 		default: // SIG_DEL
 			R->count = 0; R->value = 0;
-			if (w.nDispose < P.arena.maxDispose) w.dispose[ w.nDispose++] = r; else w.err = SPD_ERR_ARENA;
+			if (w.nDispose < CAP_DISPOSE) DISPOSE[ w.nDispose++] = r; else ARENA_FAIL;
 			return;
 	}
 	u32 start_ordpos = q0.w, start_origseg = q1.y, start_origpos = q1.z;
@@ -688,45 +901,45 @@ __device__ void fireSignal( WS& w, const L2Params& P, u32 r, u32 sigtype, u32 si
 	}
 	const u32 newFlags = (match && !(flags & F_DONE)) ? (flags | F_DONE) : flags;
 	st4( R, value, count, newFlags, start_ordpos);
-	st4( (u32*)R + 4, end_ordpos, start_origseg, start_origpos, q1.w);
+	st4( W( R) + 4, end_ordpos, start_origseg, start_origpos, q1.w);
 	if (match)
 	{
 		if (!(flags & F_DONE))
 		{
-			const uint4 g0 = ldu4( &P.programs[ q1.w]), g1 = ldu4( (const u32*)&P.programs[ q1.w] + 4);	// {initsigval,initcount,event,resultHandle} {formatHandle,..}
+			const uint4 g0 = ldu4( &P.programs[ q1.w]), g1 = ldu4( W( &P.programs[ q1.w]) + 4);	// {initsigval,initcount,event,resultHandle} {formatHandle,..}
 			u32 fevent = g0.z, handle = g0.w, fmt = g1.x;
 			if (fevent)
 			{
-				if (w.nFollow < P.arena.maxFollow)
+				if (w.nFollow < CAP_FOLLOW)
 				{
-					Follow* F = &w.follow[ w.nFollow++];
+					HFollow* F = &FOLLOW[ w.nFollow++];
 					st4( F, start_origseg, d.eseg, start_origpos, d.epos);
-					st4( (u32*)F + 4, start_ordpos, end_ordpos, dataRef, fmt);
+					st4( W( F) + 4, start_ordpos, end_ordpos, dataRef, fmt);
 					F->event = fevent;
-					if (dataRef) addRef( w, dataRef);
+					if (dataRef) addRef( w, P, dataRef);
 				}
-				else w.err = SPD_ERR_ARENA;
+				else ARENA_FAIL;
 			}
 			if (handle)
 			{
 				if (w.nStaged < P.arena.maxStaged)
 				{
-					StagedResult* S = &w.staged[ w.nStaged++];
+					StagedResult* S = &STAGED[ w.nStaged++];
 					st4( S, handle, start_ordpos, end_ordpos, start_origseg);
-					st4( (u32*)S + 4, start_origpos, d.eseg, d.epos, dataRef);
-					if (dataRef) addRef( w, dataRef);
+					st4( W( S) + 4, start_origpos, d.eseg, d.epos, dataRef);
+					if (dataRef) addRef( w, P, dataRef);
 				}
-				else w.err = SPD_ERR_ARENA;
+				else ARENA_FAIL;
 			}
 		}
 		if (fin)
 		{
-			if (w.nDispose < P.arena.maxDispose) w.dispose[ w.nDispose++] = r; else w.err = SPD_ERR_ARENA;
+			if (w.nDispose < CAP_DISPOSE) DISPOSE[ w.nDispose++] = r; else ARENA_FAIL;
 		}
 	}
 }
 
-__device__ __forceinline__ const DevKeyEntry* lookupKey( const L2Params& P, u32 event)
+__device__ __forceinline__ const DevKeyEntry* lookupKey( KP P, u32 event)
 {
 	if (!event) return 0;
 	u32 slot = keyHash( event) & P.keymask;
@@ -741,32 +954,47 @@ __device__ __forceinline__ const DevKeyEntry* lookupKey( const L2Params& P, u32 
 	return 0;
 }
 
+// per-lane variant (divergent probes): stop word log slot of an event, 0 if it has none
+__device__ __forceinline__ u32 stopIdxOfLane( KP P, u32 event)
+{
+	if (!event) return 0;
+	u32 slot = keyHash( event) & P.keymask;
+	for (u32 probes=0; probes<=P.keymask; ++probes)
+	{
+		const uint4 eq = ld4( &P.keytab[ slot]);		// {event, listBegin, listCount, stopIdx}
+		if (eq.x == event) return eq.w;
+		if (eq.x == 0) return 0;
+		slot = (slot+1) & P.keymask;
+	}
+	return 0;
+}
+
 // ---------------------------------------------------------------- replayPastEvent (cpp:1272-1334)
-__device__ void replayPastEvent( WS& w, const L2Params& P, u32 pastEvent, u32 pastStopIdx, u32 r, u32 range)
+__device__ __forceinline__ void replayPastEvent( WSR w, KP P, u32 pastEvent, u32 pastStopIdx, u32 r, u32 range)
 {
 	if (!pastStopIdx) return;
-	const StopLog* L = &w.stop[ pastStopIdx-1];
+	const StopLog* L = &STOP[ pastStopIdx-1];
 	u32 pastStamp = ldu( &L->timestamp);
 	if (!pastStamp) return;
 	EvData ld; ldEv( ld, &L->d);
 	if (ld.sord + range < w.curpos) return;
 
 	u32 nFollow0 = w.nFollow, nDispose0 = w.nDispose;
-	u32 t = ldu( &w.rules[ r].trigHead);
+	u32 t = ldu( &RULES[ r].trigHead);
 	for (u32 guard=0; t && !w.err; ++guard)
 	{
 		if (guard > w.trigUsed) { w.err = SPD_ERR_INTERNAL; break; }
-		Trig* T = &w.trigs[ t-1];
+		HTrig* T = &TRIGS[ t-1];
 		u32 tev = ldu( &T->event), typevar = ldu( &T->typevar), sigval = ldu( &T->sigval);
 		t = ldu( &T->next);
 		if (tev == pastEvent) fireSignal( w, P, r, typevar & 15u, sigval, typevar >> 4, ld);
 	}
 	// a structure delimiter logged after the replayed event cancels the rule (cpp:1306-1321)
-	t = ldu( &w.rules[ r].trigHead);
+	t = ldu( &RULES[ r].trigHead);
 	for (u32 guard=0; t; ++guard)
 	{
 		if (guard > w.trigUsed) { w.err = SPD_ERR_INTERNAL; break; }
-		Trig* T = &w.trigs[ t-1];
+		HTrig* T = &TRIGS[ t-1];
 		u32 tev = ldu( &T->event), typevar = ldu( &T->typevar);
 		t = ldu( &T->next);
 		if ((typevar & 15u) == SIG_DEL)
@@ -775,18 +1003,18 @@ __device__ void replayPastEvent( WS& w, const L2Params& P, u32 pastEvent, u32 pa
 			u32 esi = e ? ldu( &e->stopIdx) : 0;
 			if (esi)
 			{
-				u32 ts = ldu( &w.stop[ esi-1].timestamp);
+				u32 ts = ldu( &STOP[ esi-1].timestamp);
 				if (ts && ts > pastStamp) { deactivateRule( w, P, r); break; }
 			}
 		}
 	}
-	for (u32 di=nDispose0; di<w.nDispose; ++di) deactivateRule( w, P, ldu( &w.dispose[ di]));
+	for (u32 di=nDispose0; di<w.nDispose; ++di) deactivateRule( w, P, ldu( &DISPOSE[ di]));
 	w.nDispose = nDispose0;
 	if (w.nFollow != nFollow0) { w.nFollow = nFollow0; w.err = SPD_ERR_PASTFOLLOW; }
 }
 
 // ---------------------------------------------------------------- installProgram (cpp:1168-1270)
-__device__ void installProgram( WS& w, const L2Params& P, u32 keyevent, const DevKeyRef* K, const EvData& d)
+__device__ __forceinline__ void installProgram( WSR w, KP P, u32 keyevent, const DevKeyRef* K, const EvData& d)
 {
 	u32 program = ldu( &K->program);
 	const DevProgram* G = &P.programs[ program];
@@ -795,7 +1023,7 @@ __device__ void installProgram( WS& w, const L2Params& P, u32 keyevent, const De
 
 	u32 r = allocRule( w, P);
 	if (w.err) return;
-	Rule* R = &w.rules[ r];
+	HRule* R = &RULES[ r];
 	u32 count = ldu( &G->initcount) & 0xFFFFu;		// ActionSlot::count is 16 bit (hpp:98)
 	R->value = ldu( &G->initsigval); R->count = count; R->flags = F_ACTIVE; R->start_ordpos = 0;
 	R->end_ordpos = 0; R->start_origseg = 0; R->start_origpos = 0; R->program = program;
@@ -828,7 +1056,7 @@ __device__ void installProgram( WS& w, const L2Params& P, u32 keyevent, const De
 		{
 			u32 t = allocTrig( w, P);
 			if (w.err) return;
-			Trig* T = &w.trigs[ t];
+			HTrig* T = &TRIGS[ t];
 			T->event = tev; T->rule = r; T->sigval = ldu( &D->sigval); T->typevar = sigtype | (ldu( &D->variable) << 4);
 			T->next = head; head = t+1;
 			addTrigger( w, P, t, tev);
@@ -868,7 +1096,7 @@ __device__ void installProgram( WS& w, const L2Params& P, u32 keyevent, const De
 enum {MAXT=3};
 
 
-__device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u32 lc, const EvData& d)
+__device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb, u32 lc, const EvData& d)
 {
 	for (u32 base=0; base<lc && !w.err; base+=64)
 	{
@@ -880,7 +1108,7 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 		{
 			const uint4 kq = ld4( &P.keylist[ lb + base + LANE]);		// {program, pastEvent, pastStopIdx, -}
 			program = kq.x; pastEvent = kq.y; pastStopIdx = kq.z;
-			const uint4 g0 = ld4( &P.programs[ program]), g1 = ld4( (const u32*)&P.programs[ program] + 4);
+			const uint4 g0 = ld4( &P.programs[ program]), g1 = ld4( W( &P.programs[ program]) + 4);
 			g_initsigval = g0.x; g_count = g0.y & 0xFFFFu; g_event = g0.z; g_handle = g0.w;
 			g_fmt = g1.x; g_range = g1.y; g_tb = g1.z; g_tc = g1.w;
 		}
@@ -921,7 +1149,7 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 		u32 start_ordpos = 0, start_origseg = 0, start_origpos = 0, dataRef = 0;
 		bool match = false, fin = false, del = false, odd = false;
 		u32 nFires = 0;
-		u32 itemVar0 = 0, itemVar1 = 0;		// captured variables: [0] from the replayed event, [1] from the key event
+		u32 itemVar0 = 0;				// captured variable of the replayed event
 		EvData ld; ld.sseg = ld.eseg = ld.spos = ld.epos = ld.sord = ld.eord = ld.sub = ld.fmt = 0;
 		auto fireLocal = [&]( u32 sigtype, u32 sigval, const EvData& e, bool& took) {
 			bool m = false, f = false; took = false;
@@ -979,12 +1207,12 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 			const u32 psi = pastStopIdx;
 			if (psi)
 			{
-				const u32* L = (const u32*)&w.stop[ psi-1];
+				const u32* L = (const u32*)&STOP[ psi-1];
 				const uint4 la = ld4( L), lbq = ld4( L+4), lc4 = ld4( L+8);
 				if (lc4.x /*timestamp*/ && lbq.x /*start_ordpos*/ + g_range >= w.curpos)
 				{
 					ld.sseg = la.x; ld.eseg = la.y; ld.spos = la.z; ld.epos = la.w; ld.sord = lbq.x; ld.eord = lbq.y; ld.sub = lbq.z; ld.fmt = lbq.w;
-					if (hasDel || ld.sub) odd = true;		// cancel check / sub-match data: sequential path
+					if (ld.sub) odd = true;				// sub-match data to join: sequential path
 					u32 replays = 0;
 #pragma unroll
 					for (int j=MAXT-1; j>=0; --j)			// the rule's trigger list: last installed first
@@ -998,21 +1226,49 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 						}
 					}
 					if (replays > 1 || match || del) odd = true;	// a replay that matches or deletes: sequential path
+					// a structure delimiter logged after the replayed event cancels the rule (cpp:1306-1321)
+					if (hasDel)
+					{
+#pragma unroll
+						for (int j=0; j<MAXT; ++j)
+						{
+							if (tInstall[ j] && (tTypevar[ j] & 15u) == SIG_DEL)
+							{
+								const u32 esi = stopIdxOfLane( P, tEvent[ j]);
+								if (esi)
+								{
+									const u32 ts = STOP[ esi-1].timestamp;
+									if (ts && ts > lc4.x) odd = true;		// cancelled: sequential path does the deactivation
+								}
+							}
+						}
+					}
 				}
 			}
 		}
-		bool keyTook = false;
+		u32 keyVar[ MAXT];				// captured variable of key trigger j if it took the event
+		bool matchedBare = false;			// matched while the slot had no captured data yet
 #pragma unroll
 		for (int j=0; j<MAXT; ++j)
 		{
+			keyVar[ j] = 0;
 			if (live && tKey[ j])
 			{
-				bool took;
+				bool took; const bool matchedBefore = match;
+				bool hadItem = itemVar0 != 0;
+#pragma unroll
+				for (int i=0; i<MAXT; ++i) if (i < j && keyVar[ i]) hadItem = true;
 				fireLocal( tTypevar[ j] & 15u, tSigval[ j], d, took);
-				if (took) { if (keyTook) odd = true; keyTook = true; itemVar1 = tTypevar[ j] >> 4; }
+				if (took) keyVar[ j] = tTypevar[ j] >> 4;
+				if (match && !matchedBefore && !hadItem && !keyVar[ j]) matchedBare = true;
 			}
 		}
-		if (nofKey > 1 && del) odd = true;		// several key triggers where one deletes, or two take: sequential path
+		if (nofKey > 1 && del) odd = true;		// several key triggers where one deletes: sequential path
+		if (!P.withItems) { itemVar0 = 0; for (int j=0; j<MAXT; ++j) keyVar[ j] = 0; }
+		u32 nItems = itemVar0 ? 1u : 0u;
+#pragma unroll
+		for (int j=0; j<MAXT; ++j) if (keyVar[ j]) ++nItems;
+		if (matchedBare && nItems) odd = true;		// result staged before the data reference existed: sequential path
 		if (del) { match = false; fin = false; }
 		const bool slowLane = live && (odd || expiry >= w.curpos + 64u || g_tc > (u32)MAXT);
 		const bool liveAll = live;
@@ -1045,8 +1301,8 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 		{
 			const u32 fromStack = w.ruleFreeN < nlive ? w.ruleFreeN : nlive;
 			const u32 bump = nlive - fromStack;
-			if (w.ruleUsed + bump > P.arena.maxRules) { w.err = SPD_ERR_ARENA; return; }
-			if (live) r = rank < fromStack ? w.ruleFree[ w.ruleFreeN - 1 - rank] : w.ruleUsed + (rank - fromStack);
+			if (w.ruleUsed + bump > CAP_RULES) { ARENA_FAIL; return; }
+			if (live) r = rank < fromStack ? RULEFREE[ w.ruleFreeN - 1 - rank] : w.ruleUsed + (rank - fromStack);
 			w.ruleFreeN -= fromStack; w.ruleUsed += bump;
 		}
 		// ---- dispose window (cpp:1072-1076): the rules of one expiry position are kept in definition order
@@ -1060,14 +1316,15 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 				const u32 wsel = (u32)__builtin_amdgcn_readlane( widx, leader);
 				const bool mine = live && widx == wsel;
 				const u64 grp = __ballot( mine);
-				const u32 cnt = ldu( &w.window[ wsel]);
+				const u32 cnt = ldu( &WINDOW[ wsel]);
 				const u32 ng = (u32)__popcll( grp);
-				if (cnt + ng > P.arena.winCap) { full = true; break; }
-				if (mine) w.winArr[ wsel*P.arena.winCap + cnt + (u32)__popcll( grp & lanesBelow())] = r;
-				w.window[ wsel] = cnt + ng;
+				winReserve( w, P, wsel, cnt, ng);
+				if (w.err) { full = true; break; }
+				if (mine) WINARR[ winEntryIndex( w, P, wsel, cnt + (u32)__popcll( grp & lanesBelow()))] = r;
+				WINDOW[ wsel] = cnt + ng;
 				todo &= ~grp;
 			}
-			if (full) { w.err = SPD_ERR_ARENA; return; }
+			if (full) return;
 		}
 		const u32 nextLink = 0;
 		// ---- triggers: bucket positions in (program, template) order
@@ -1096,7 +1353,7 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 		const u32 trigBefore = byteSum( e0 + e1 + e2 + e3);
 		const u32 totalTrig = byteSum( t0 + t1 + t2 + t3);
 		const u32 trigFromStack = w.trigFreeN < totalTrig ? w.trigFreeN : totalTrig;
-		if (w.trigUsed + (totalTrig - trigFromStack) > P.arena.maxTrigs) { w.err = SPD_ERR_ARENA; return; }
+		if (w.trigUsed + (totalTrig - trigFromStack) > CAP_TRIGS) { ARENA_FAIL; return; }
 		u32 head = 0, local = 0;
 		bool overflow = false;
 #pragma unroll
@@ -1108,70 +1365,73 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 				u32 same = 0;
 #pragma unroll
 				for (int jj=0; jj<j; ++jj) if (tInstall[ jj] && hB[ jj] == h) ++same;	// my own earlier templates
-				const u32 pos = w.bSize[ h] + byteField( e0, e1, e2, e3, h) + same;
+				const u32 pos = BSIZE[ h] + byteField( e0, e1, e2, e3, h) + same;
 				const u32 seq = trigBefore + local;
-				const u32 t = seq < trigFromStack ? w.trigFree[ w.trigFreeN - 1 - seq] : w.trigUsed + (seq - trigFromStack);
-				if (pos >= P.arena.bucketCap) overflow = true;
+				const u32 t = seq < trigFromStack ? TRIGFREE[ w.trigFreeN - 1 - seq] : w.trigUsed + (seq - trigFromStack);
+				if (pos >= CAP_BUCKET) overflow = true;
 				else
 				{
-					w.bEvent[ h*P.arena.bucketCap + pos] = tEvent[ j];
-					w.bIdx[ h*P.arena.bucketCap + pos] = t;
-					Trig* T = &w.trigs[ t];
+					BEVENT[ h*CAP_BUCKET + pos] = tEvent[ j];
+					BIDX[ h*CAP_BUCKET + pos] = t;
+					HTrig* T = &TRIGS[ t];
 					st4( T, tEvent[ j], r, tSigval[ j], tTypevar[ j]);
-					st4( (u32*)T + 4, (h << 28) | pos, head, 0, 0);
+					st4( W( T) + 4, (h << 28) | pos, head, 0, 0);
 					head = t+1;
 				}
 				++local;
 			}
 		}
-		if (__ballot( overflow)) { w.err = SPD_ERR_ARENA; return; }
+		if (__ballot( overflow)) { ARENA_FAIL; return; }
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
-		if (LANE < 16) w.bSize[ LANE] += byteField( t0, t1, t2, t3, LANE);
+		if (LANE < 16) BSIZE[ LANE] += byteField( t0, t1, t2, t3, LANE);
 		w.trigFreeN -= trigFromStack; w.trigUsed += totalTrig - trigFromStack;
 		w.nTrig += totalTrig;
 		w.nInstalled += nlive;
 
 		w.nSignals += (u32)__popcll( __ballot( live && (nFires & 1u))) + 2u*(u32)__popcll( __ballot( live && (nFires & 2u))) + 4u*(u32)__popcll( __ballot( live && (nFires & 4u)));
 		w.nAlt += (u32)__popcll( __ballot( live && pastEvent != 0));
-		// captured variables: up to two items per lane (the replayed event's, then the key event's on top: LIFO list)
-		const bool want0 = P.withItems && live && itemVar0 != 0;
-		const bool want1 = P.withItems && live && keyTook && itemVar1 != 0;
+		// captured variables: the replayed event's item first, then the key triggers' in order (LIFO list: last on top)
 		const bool emitFollow = live && match && g_event != 0;
 		const bool emitResult = live && match && g_handle != 0;
 		{
-			const u64 im0 = __ballot( want0), im1 = __ballot( want1), rmk = __ballot( want0 || want1);
+			const u32 myItems = live ? nItems : 0u;
+			const u64 ib0 = __ballot( myItems & 1u), ib1 = __ballot( myItems & 2u), ib2 = __ballot( myItems & 4u), rmk = __ballot( myItems != 0);
 			if (rmk)
 			{
-				const u32 ni = (u32)__popcll( im0) + (u32)__popcll( im1), nr = (u32)__popcll( rmk);
-				const u32 ri = (u32)__popcll( im0 & lanesBelow()) + (u32)__popcll( im1 & lanesBelow());
+				const u32 ni = (u32)__popcll( ib0) + 2u*(u32)__popcll( ib1) + 4u*(u32)__popcll( ib2), nr = (u32)__popcll( rmk);
+				const u32 ri = (u32)__popcll( ib0 & lanesBelow()) + 2u*(u32)__popcll( ib1 & lanesBelow()) + 4u*(u32)__popcll( ib2 & lanesBelow());
 				const u32 rr = (u32)__popcll( rmk & lanesBelow());
 				const u32 itemFromStack = w.itemFreeN < ni ? w.itemFreeN : ni;
 				const u32 refFromStack = w.refFreeN < nr ? w.refFreeN : nr;
-				if (w.itemUsed + (ni - itemFromStack) > P.arena.maxItems || w.refUsed + (nr - refFromStack) > P.arena.maxRefs) { w.err = SPD_ERR_ARENA; return; }
-				if (want0 || want1)
+				if (w.itemUsed + (ni - itemFromStack) > CAP_ITEMS || w.refUsed + (nr - refFromStack) > CAP_REFS) { ARENA_FAIL; return; }
+				if (myItems)
 				{
 					u32 seq = ri, below = 0;
-					if (want0)
+					if (itemVar0)
 					{
-						const u32 it = seq < itemFromStack ? w.itemFree[ w.itemFreeN - 1 - seq] : w.itemUsed + (seq - itemFromStack);
-						Item* I = &w.items[ it];
+						const u32 it = seq < itemFromStack ? ITEMFREE[ w.itemFreeN - 1 - seq] : w.itemUsed + (seq - itemFromStack);
+						HItem* I = &ITEMS[ it];
 						st4( I, itemVar0, 0, 0, 0);
-						st4( (u32*)I + 4, ld.sseg, ld.eseg, ld.spos, ld.epos);
-						st4( (u32*)I + 8, ld.sord, ld.eord, ld.sub, ld.fmt);
+						st4( W( I) + 4, ld.sseg, ld.eseg, ld.spos, ld.epos);
+						st4( W( I) + 8, ld.sord, ld.eord, ld.sub, ld.fmt);
 						below = it+1; ++seq;
 					}
-					if (want1)
+#pragma unroll
+					for (int j=0; j<MAXT; ++j)
 					{
-						const u32 it = seq < itemFromStack ? w.itemFree[ w.itemFreeN - 1 - seq] : w.itemUsed + (seq - itemFromStack);
-						Item* I = &w.items[ it];
-						st4( I, itemVar1, below, 0, 0);
-						st4( (u32*)I + 4, d.sseg, d.eseg, d.spos, d.epos);
-						st4( (u32*)I + 8, d.sord, d.eord, d.sub, d.fmt);
-						below = it+1;
+						if (keyVar[ j])
+						{
+							const u32 it = seq < itemFromStack ? ITEMFREE[ w.itemFreeN - 1 - seq] : w.itemUsed + (seq - itemFromStack);
+							HItem* I = &ITEMS[ it];
+							st4( I, keyVar[ j], below, 0, 0);
+							st4( W( I) + 4, d.sseg, d.eseg, d.spos, d.epos);
+							st4( W( I) + 8, d.sord, d.eord, d.sub, d.fmt);
+							below = it+1; ++seq;
+						}
 					}
-					const u32 rf = rr < refFromStack ? w.refFree[ w.refFreeN - 1 - rr] : w.refUsed + (rr - refFromStack);
-					w.refs[ 2*rf] = below;
-					w.refs[ 2*rf+1] = 1u + (emitFollow ? 1u : 0u) + (emitResult ? 1u : 0u);	// rule + follow + result (cpp:941-953)
+					const u32 rf = rr < refFromStack ? REFFREE[ w.refFreeN - 1 - rr] : w.refUsed + (rr - refFromStack);
+					REFS[ 2*rf] = below;
+					REFS[ 2*rf+1] = 1u + (emitFollow ? 1u : 0u) + (emitResult ? 1u : 0u);	// rule + follow + result (cpp:941-953)
 					dataRef = rf+1;
 				}
 				w.itemFreeN -= itemFromStack; w.itemUsed += ni - itemFromStack;
@@ -1184,12 +1444,12 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 			if (fm)
 			{
 				const u32 nf = (u32)__popcll( fm);
-				if (w.nFollow + nf > P.arena.maxFollow) { w.err = SPD_ERR_ARENA; return; }
+				if (w.nFollow + nf > CAP_FOLLOW) { ARENA_FAIL; return; }
 				if (emitFollow)
 				{
-					Follow* F = &w.follow[ w.nFollow + (u32)__popcll( fm & lanesBelow())];
+					HFollow* F = &FOLLOW[ w.nFollow + (u32)__popcll( fm & lanesBelow())];
 					st4( F, start_origseg, d.eseg, start_origpos, d.epos);
-					st4( (u32*)F + 4, start_ordpos, end_ordpos, dataRef, g_fmt);
+					st4( W( F) + 4, start_ordpos, end_ordpos, dataRef, g_fmt);
 					F->event = g_event;
 				}
 				w.nFollow += nf;
@@ -1198,12 +1458,12 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 			if (rm)
 			{
 				const u32 nr = (u32)__popcll( rm);
-				if (w.nStaged + nr > P.arena.maxStaged) { w.err = SPD_ERR_ARENA; return; }
+				if (w.nStaged + nr > P.arena.maxStaged) { ARENA_FAIL; return; }
 				if (emitResult)
 				{
-					StagedResult* S = &w.staged[ w.nStaged + (u32)__popcll( rm & lanesBelow())];
+					StagedResult* S = &STAGED[ w.nStaged + (u32)__popcll( rm & lanesBelow())];
 					st4( S, g_handle, start_ordpos, end_ordpos, start_origseg);
-					st4( (u32*)S + 4, start_origpos, d.eseg, d.epos, dataRef);
+					st4( W( S) + 4, start_origpos, d.eseg, d.epos, dataRef);
 				}
 				w.nStaged += nr;
 			}
@@ -1212,17 +1472,17 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 			if (dm)
 			{
 				const u32 nd = (u32)__popcll( dm);
-				if (w.nDispose + nd > P.arena.maxDispose) { w.err = SPD_ERR_ARENA; return; }
-				if (wantDispose) w.dispose[ w.nDispose + (u32)__popcll( dm & lanesBelow())] = r;
+				if (w.nDispose + nd > CAP_DISPOSE) { ARENA_FAIL; return; }
+				if (wantDispose) DISPOSE[ w.nDispose + (u32)__popcll( dm & lanesBelow())] = r;
 				w.nDispose += nd;
 			}
 		}
 		if (live)
 		{
-			Rule* R = &w.rules[ r];
+			HRule* R = &RULES[ r];
 			st4( R, value, count, flags, start_ordpos);
-			st4( (u32*)R + 4, end_ordpos, start_origseg, start_origpos, program);
-			st4( (u32*)R + 8, head, dataRef, nextLink, expiry);
+			st4( W( R) + 4, end_ordpos, start_origseg, start_origpos, program);
+			st4( W( R) + 8, head, dataRef, nextLink, expiry);
 		}
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		} // segments
@@ -1230,16 +1490,17 @@ __device__ void installBatch( WS& w, const L2Params& P, u32 keyevent, u32 lb, u3
 }
 
 // ---------------------------------------------------------------- doTransition (cpp:981-1064)
-__device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData& data)
+__device__ __noinline__ void doTransition( HWS* wsBlock, u32* wsArena, KP P, u32 event, const EvData data)
 {
+	const WSV w( wsBlock, wsArena);
 	w.open += w.nTrig;
 	w.nFollow = 1;
-	w.follow[0].d = data; w.follow[0].event = event;
+	stEv( &FOLLOW[0].d, data); FOLLOW[0].event = event;
 
 	for (u32 fi=0; fi<w.nFollow && !w.err; ++fi)
 	{
-		EvData d; ldEv( d, &w.follow[ fi].d);
-		u32 ev = ldu( &w.follow[ fi].event);
+		EvData d; ldEv( d, &FOLLOW[ fi].d);
+		u32 ev = ldu( &FOLLOW[ fi].event);
 		w.nDispose = 0;
 		TRACE2( 6, fi); TRACE2( 7, ev);
 
@@ -1248,9 +1509,9 @@ __device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData&
 		if (ev)
 		{
 			u32 h = evhash( ev) & 15u;
-			u32 n = ldu( &w.bSize[ h]);
-			const u32* be = w.bEvent + h*P.arena.bucketCap;
-			const u32* bi = w.bIdx + h*P.arena.bucketCap;
+			u32 n = ldu( &BSIZE[ h]);
+			const hu32* be = BEVENT + h*CAP_BUCKET;
+			const hu32* bi = BIDX + h*CAP_BUCKET;
 			for (u32 base=0; base<n && !w.err; base+=64)
 			{
 				u32 i = base + LANE;
@@ -1259,7 +1520,7 @@ __device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData&
 				{
 					u32 p = (u32)__builtin_ctzll( m);
 					m &= m-1;
-					const uint4 tq = ldu4( &w.trigs[ ldu( &bi[ base+p])]);	// {event, rule, sigval, typevar}
+					const uint4 tq = ldu4( &TRIGS[ ldu( &bi[ base+p])]);	// {event, rule, sigval, typevar}
 					u32 tr = tq.y, typevar = tq.w, sigval = tq.z;
 					fireSignal( w, P, tr, typevar & 15u, sigval, typevar >> 4, d);
 				}
@@ -1283,18 +1544,18 @@ __device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData&
 		TRACE2( 9, 3);
 		PROF_ADD( 1);
 		// deactivate rules that finished or were deleted
-		if (w.nDispose >= 3) deactivateBatch( w, P, w.dispose, w.nDispose, false, false, true);
-		else for (u32 di=0; di<w.nDispose; ++di) deactivateRule( w, P, ldu( &w.dispose[ di]));
+		if (w.nDispose >= 3) deactivateBatch( w.raw, w.arena, P, DISPOSE, w.nDispose, false, false, true);
+		else for (u32 di=0; di<w.nDispose; ++di) deactivateRule( w, P, ldu( &DISPOSE[ di]));
 		PROF_ADD( 2);
 
 		if (stopIdx)
 		{
-			StopLog* L = &w.stop[ stopIdx-1];
-			L->d = d; L->timestamp = ++w.timestamp;
+			StopLog* L = &STOP[ stopIdx-1];
+			stEv( &L->d, d); L->timestamp = ++w.timestamp;
 		}
 		else if (d.sub && P.withItems)
 		{
-			disposeRef( w, d.sub);
+			disposeRef( w, P, d.sub);
 		}
 	}
 }
@@ -1302,20 +1563,20 @@ __device__ void doTransition( WS& w, const L2Params& P, u32 event, const EvData&
 // ---------------------------------------------------------------- result items (patternMatcher.cpp:164-190)
 // depth-first walk of an item list; items with sub-lists (and no format) are followed by their
 // sub-items.  emit==0 counts only.
-__device__ u32 walkItems( WS& w, const L2Params& P, u32 ref, u32* out)
+__device__ __forceinline__ u32 walkItems( WSR w, KP P, u32 ref, u32* out)
 {
 	u32 n = 0, sp = 0;
-	u32 cur = ldu( &w.refs[ 2*(ref-1)]);
+	u32 cur = ldu( &REFS[ 2*(ref-1)]);
 	for (u32 guard=0;; ++guard)
 	{
 		if (guard > (1u<<22)) { w.err = SPD_ERR_INTERNAL; break; }
 		if (!cur)
 		{
 			if (!sp) break;
-			cur = ldu( &w.gstack[ --sp]);
+			cur = ldu( &GSTACK[ --sp]);
 			continue;
 		}
-		const Item* I = &w.items[ cur-1];
+		const HItem* I = &ITEMS[ cur-1];
 		EvData d; ldEv( d, &I->d);
 		if (out)
 		{
@@ -1326,9 +1587,9 @@ __device__ u32 walkItems( WS& w, const L2Params& P, u32 ref, u32* out)
 		cur = ldu( &I->next);
 		if (d.sub && !d.fmt)
 		{
-			if (sp >= P.arena.maxGStack) { w.err = SPD_ERR_ARENA; break; }
-			w.gstack[ sp++] = cur;
-			cur = ldu( &w.refs[ 2*(d.sub-1)]);
+			if (sp >= P.arena.maxGStack) { ARENA_FAIL; break; }
+			GSTACK[ sp++] = cur;
+			cur = ldu( &REFS[ 2*(d.sub-1)]);
 		}
 	}
 	return n;
@@ -1337,38 +1598,46 @@ __device__ u32 walkItems( WS& w, const L2Params& P, u32 ref, u32* out)
 } // anonymous namespace
 
 // ================================================================== kernel
-extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPA_L2_WAVES_PER_EU, 8)))
-void spa_l2_match_kernel( L2Params P)
+#ifdef SPA_L2_LDS
+extern "C" __global__ __launch_bounds__(64)
+void spa_l2_match_kernel_lds( L2Params kernelArgs)
 {
-	const u32 waveSlot = bcast0( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-	u32* A = P.arenaBase + (u64)waveSlot * P.arena.totalWords;
-
-	WS w;
-	w.rules = (Rule*)(A + P.arena.oRules);	w.trigs = (Trig*)(A + P.arena.oTrigs);
-	w.bEvent = A + P.arena.oBEvent;		w.bIdx = A + P.arena.oBIdx;
-	w.bSize = A + P.arena.oBSize;		w.window = A + P.arena.oWindow;
-	w.winArr = A + P.arena.oWinArr;		w.scratch = A + P.arena.oScratch;
-	w.heap = A + P.arena.oHeap;		w.follow = (Follow*)(A + P.arena.oFollow);
-	w.dispose = A + P.arena.oDispose;	w.stop = (StopLog*)(A + P.arena.oStop);
-	w.items = (Item*)(A + P.arena.oItems);	w.refs = A + P.arena.oRefs;
-	w.gstack = A + P.arena.oGStack;		w.staged = (StagedResult*)(A + P.arena.oStaged);
-	w.ruleFree = A + P.arena.oRuleFree;	w.trigFree = A + P.arena.oTrigFree;
-	w.itemFree = A + P.arena.oItemFree;	w.refFree = A + P.arena.oRefFree;
+	KP P = kernelParams();
+	__shared__ __attribute__((aligned(16))) u32 ldsSlice[ L_TOTAL];
+	const WSV w( (HWS*)ldsSlice, P.arenaBase + (u64)blockIdx.x * P.arena.totalWords);
+	const u32 ndocs = P.ndocs;
+#else
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPA_L2_WAVES_PER_EU, 8)))
+void spa_l2_match_kernel( L2Params kernelArgs)
+{
+	KP P = kernelParams();
+	__shared__ __attribute__((aligned(16))) u32 ldsSlice[ 64];
+	const WSV w( (HWS*)ldsSlice, P.arenaBase + (u64)blockIdx.x * P.arena.totalWords);
+	// second tier: only the documents the LDS tier has queued (count known on the device only)
+	const u32 ndocs = P.docListCount ? ldu( P.docListCount) : P.ndocs;
+#endif
+	const u32 waveSlot = blockIdx.x;
+	const u32 nWaveSlots = gridDim.x;
 
 	// documents are dealt round-robin to the resident waves (document d -> wave d mod nwaves)
-	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
-	for (u32 doc=waveSlot; doc<P.ndocs; doc+=nWaveSlots)
+	for (u32 di=waveSlot; di<ndocs; di+=nWaveSlots)
 	{
+#ifdef SPA_L2_LDS
+		const u32 doc = di;
+#else
+		const u32 doc = P.docList ? ldu( &P.docList[ di]) : di;
+#endif
 		TRACE( 1, doc);
 		// per-document reset (lane-parallel)
-		if (LANE < 16) w.bSize[ LANE] = 0;
-		w.window[ LANE] = 0;
-		for (u32 s=LANE; s<P.nofStopWords; s+=64) w.stop[ s].timestamp = 0;
+		if (LANE < 16) BSIZE[ LANE] = 0;
+		WINDOW[ LANE] = 0;
+		for (u32 s=LANE; s<P.nofStopWords; s+=64) STOP[ s].timestamp = 0;
 		w.curpos = 0; w.timestamp = 0; w.nInstalled = 0; w.nAlt = 0; w.nSignals = 0; w.nTrig = 0; w.open = 0;
 		w.ruleFreeN = 0; w.ruleUsed = 0; w.trigFreeN = 0; w.trigUsed = 0; w.itemFreeN = 0; w.itemUsed = 0;
 #if defined(SPA_PROF) || defined(SPA_PROF2)
-		w.prof[0] = w.prof[1] = w.prof[2] = w.prof[3] = 0;
+		w.raw->prof[0] = w.raw->prof[1] = w.raw->prof[2] = w.raw->prof[3] = 0;
 #endif
+		w.winFreeN = 0; w.winUsed = 0;
 		w.refFreeN = 0; w.refUsed = 0; w.heapSize = 0; w.nFollow = 0; w.nDispose = 0; w.nStaged = 0; w.err = 0;
 
 		u64 lbeg, lend;
@@ -1408,7 +1677,7 @@ void spa_l2_match_kernel( L2Params P)
 				d.sseg = origseg; d.eseg = origseg; d.spos = origpos; d.epos = origpos + origsize;
 				d.sord = ordpos; d.eord = ordpos+1; d.sub = 0; d.fmt = 0;
 				TRACE2( 2, nEvents); TRACE2( 3, id); TRACE2( 4, ordpos);
-				doTransition( w, P, id /*TermEvent: type bits 0*/, d);
+				doTransition( w.raw, w.arena, P, id /*TermEvent: type bits 0*/, d);
 				TRACE2( 5, nEvents);
 				++nEvents;
 			}
@@ -1423,7 +1692,7 @@ void spa_l2_match_kernel( L2Params P)
 			u32 total = 0;
 			for (u32 ri=0; ri<nres && !w.err; ++ri)
 			{
-				u32 ref = ldu( &w.staged[ ri].dataRef);
+				u32 ref = ldu( &STAGED[ ri].dataRef);
 				if (ref) total += walkItems( w, P, ref, 0);
 			}
 			if (w.err) nres = 0;
@@ -1451,7 +1720,7 @@ void spa_l2_match_kernel( L2Params P)
 				// item lists are pointer chains: walked serially, result records patched with (begin,count)
 				for (u32 ri=0; ri<nres; ++ri)
 				{
-					u32 ref = ldu( &w.staged[ ri].dataRef);
+					u32 ref = ldu( &STAGED[ ri].dataRef);
 					u32 n = ref ? walkItems( w, P, ref, P.items + ip*7) : 0;
 					u32* o = P.results + (resBase + ri)*9;
 					o[7] = (u32)ip; o[8] = n;
@@ -1461,22 +1730,37 @@ void spa_l2_match_kernel( L2Params P)
 			// the 7-tuples: one result per lane, 36-byte records
 			for (u32 ri=LANE; ri<nres; ri+=64)
 			{
-				const StagedResult* S = &w.staged[ ri];
+				const StagedResult* S = &STAGED[ ri];
 				u32* o = P.results + (resBase + ri)*9;
 				o[0] = S->handle; o[1] = S->sord; o[2] = S->eord; o[3] = S->sseg; o[4] = S->spos; o[5] = S->eseg; o[6] = S->epos;
 				if (!P.withItems) { o[7] = 0; o[8] = 0; }
 			}
 		}
+#ifdef SPA_L2_LDS
+		if (w.err == SPD_ERR_ARENA && P.retryList)
+		{
+			// the document outgrew the LDS slice: the global tier runs it again from the start
+			if (LANE == 0) P.retryList[ atomicAdd( P.retryCount, 1u)] = doc;
+			continue;
+		}
+#endif
 		if (LANE == 0)
 		{
 			P.docRange[ 2*(u64)doc] = resBase; P.docRange[ 2*(u64)doc+1] = nres;
 			u64* st = P.docStats + 4*(u64)doc;
 			st[0] = w.nInstalled; st[1] = w.nAlt; st[2] = w.nSignals; st[3] = w.open;
+#ifdef SPA_PROF2
+#ifdef SPA_L2_LDS
+			if (w.err == SPD_ERR_ARENA) { st[0] = w.raw->prof[3]; st[1] = w.ruleUsed; st[2] = w.trigUsed; st[3] = w.itemUsed; }
+#else
+			st[0] = w.refUsed; st[1] = w.ruleUsed; st[2] = w.trigUsed; st[3] = w.itemUsed;	// high-water marks
+#endif
+#endif
 			P.docStatus[ doc] = (int32_t)w.err;
 			atomicAdd( (unsigned long long*)&P.counters[ SPC_EVENTS], (unsigned long long)nEvents);
 			if (w.err) atomicAdd( (unsigned long long*)&P.counters[ SPC_FAILED], 1ull);
 #if defined(SPA_PROF) || defined(SPA_PROF2)
-			for (int pi=0; pi<4; ++pi) atomicAdd( (unsigned long long*)&P.counters[ 4+pi], (unsigned long long)w.prof[ pi]);
+			for (int pi=0; pi<4; ++pi) atomicAdd( (unsigned long long*)&P.counters[ 4+pi], (unsigned long long)w.raw->prof[ pi]);
 #endif
 		}
 	}
@@ -1484,9 +1768,17 @@ void spa_l2_match_kernel( L2Params P)
 
 // host-side launcher (called from capi.cpp, same translation unit family compiled by hipcc)
 namespace spa {
-hipError_t launchL2Match( const L2Params& P, unsigned nblocks, hipStream_t stream)
+#ifdef SPA_L2_LDS
+hipError_t launchL2MatchLds( const L2Params& P, unsigned nwaves, hipStream_t stream)
 {
-	hipLaunchKernelGGL( spa_l2_match_kernel, dim3( nblocks), dim3( 256), 0, stream, P);
+	hipLaunchKernelGGL( spa_l2_match_kernel_lds, dim3( nwaves), dim3( 64), 0, stream, P);
 	return hipGetLastError();
 }
+#else
+hipError_t launchL2Match( const L2Params& P, unsigned nblocks /*= waves*/, hipStream_t stream)
+{
+	hipLaunchKernelGGL( spa_l2_match_kernel, dim3( nblocks), dim3( 64), 0, stream, P);
+	return hipGetLastError();
+}
+#endif
 }
