@@ -100,7 +100,7 @@ struct sp_matcher_ctx
 	hipStream_t lastStream;
 	bool withItems;
 	bool ldsOnly;			// diagnostics (SPA_L2_TIER=ldsonly): no second tier, overflowing documents fail
-	bool ldsTier;			// first tier: document state in LDS (SPA_L2_TIER=global switches it off)
+	bool ldsTier;			// optional first tier with the document state in LDS (SPA_L2_TIER=lds): measured slower than 8 HBM-arena waves per CU, kept for experiments
 	unsigned numCUs;
 	// single-document mode
 	std::vector<sp_lexem_t> curLexems;
@@ -108,7 +108,7 @@ struct sp_matcher_ctx
 	sp_matcher_stats_t lastStats;
 
 	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),arenaWaves(0),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
-		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),ldsOnly(false),ldsTier(true),numCUs(256),curHasSeg(false)
+		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),ldsOnly(false),ldsTier(false),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
 		std::memset( &lastStats, 0, sizeof(lastStats));
@@ -204,7 +204,7 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 		c->nofStopWords = ft.nofStopWords;
 		c->arena.nStop = ft.nofStopWords;
 		c->dCursor.alloc( 64);
-		{ const char* tier = getenv( "SPA_L2_TIER"); if (tier && std::strcmp( tier, "global") == 0) c->ldsTier = false; if (tier && std::strcmp( tier, "ldsonly") == 0) c->ldsOnly = true; }
+		{ const char* tier = getenv( "SPA_L2_TIER"); if (tier && std::strcmp( tier, "lds") == 0) c->ldsTier = true; if (tier && std::strcmp( tier, "ldsonly") == 0) { c->ldsTier = true; c->ldsOnly = true; } }
 		c->dCounters.alloc( SPC_COUNT*sizeof(uint64_t));
 		HIP_CHECK( hipEventCreate( &c->evStart));
 		HIP_CHECK( hipEventCreate( &c->evStop));
@@ -416,12 +416,12 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
 	if (c->ldsTier)
 	{
-		// tier 1: one-wave workgroups with the document state in LDS (4 per CU); documents that outgrow
+		// tier 1: one-wave workgroups with the document state in LDS (2 per CU); documents that outgrow
 		// the slice are queued on the device.  tier 2: the global-arena kernel takes the queue (usually
 		// empty: its waves read the count and leave).  No host round trip in between.
 		c->dRetry.reserve( (ndocs+1)*sizeof(uint32_t));
 		P.retryList = c->ldsOnly ? 0 : (uint32_t*)c->dRetry.ptr; P.retryCount = (uint32_t*)c->dCursor.ptr;
-		unsigned ldsWaves = (unsigned)((ndocs < (size_t)c->numCUs*4) ? ndocs : (size_t)c->numCUs*4);
+		unsigned ldsWaves = (unsigned)((ndocs < (size_t)c->numCUs*2) ? ndocs : (size_t)c->numCUs*2);
 		if (ldsWaves > c->arenaWaves) ldsWaves = c->arenaWaves;
 		if (ldsWaves == 0) ldsWaves = 1;
 		HIP_CHECK( launchL2MatchLds( P, ldsWaves, stream));

@@ -101,7 +101,7 @@ struct StagedResult { u32 handle, sord, eord, sseg, spos, eseg, epos, dataRef; }
 // This source is compiled twice:
 //  - SPA_L2_LDS (l2_kernel_lds.hip): the hot state of the document -- rules, triggers, the 16 trigger
 //    buckets, expiry window, free stacks, captured items, follow/dispose lists and the scalar
-//    counters -- is a 40 KB slice of LDS owned by a one-wave workgroup (4 workgroups per CU).  Every
+//    counters -- is a 77 KB slice of LDS owned by a one-wave workgroup (2 workgroups per CU).  Every
 //    step of the automaton is a chain of dependent accesses to that state, so its speed is the
 //    access latency: LDS answers in ~100 cycles where an L2/HBM round trip costs 500-2000.
 //    Capacities are compile-time constants; a document that outgrows them is queued for
@@ -111,8 +111,8 @@ struct StagedResult { u32 handle, sord, eord, sseg, spos, eseg, epos, dataRef; }
 #ifdef SPA_L2_LDS
 #define HOT LDSQ
 enum {
-	CAP_RULES=160, CAP_TRIGS=256, CAP_BUCKET=40, CAP_FOLLOW=12, CAP_DISPOSE=160, CAP_HEAP=32,
-	WIN_CHUNK=16, WIN_NCHUNKS=40, CAP_SCRATCH=32, CAP_ITEMS=128, CAP_REFS=128
+	CAP_RULES=576, CAP_TRIGS=576, CAP_BUCKET=80, CAP_FOLLOW=16, CAP_DISPOSE=576, CAP_HEAP=64,
+	WIN_CHUNK=16, WIN_NCHUNKS=100, CAP_SCRATCH=48
 };
 #else
 #define HOT
@@ -125,13 +125,13 @@ enum {
 #define WIN_CHUNK	(P.arena.winChunk)
 #define WIN_NCHUNKS	(P.arena.winChunks)
 #define CAP_SCRATCH	(P.arena.scratchCap)
+#endif
 #define CAP_ITEMS	(P.arena.maxItems)
 #define CAP_REFS	(P.arena.maxRefs)
-#endif
 typedef HOT u32 hu32;
 typedef HOT Rule HRule;
 typedef HOT Trig HTrig;
-typedef HOT Item HItem;
+typedef Item HItem;		// captured items and data references stay in HBM in both tiers: results keep them alive until the document ends
 typedef HOT Follow HFollow;
 typedef HOT EvData HEvData;
 
@@ -201,13 +201,11 @@ enum {
 	L_BIDX=L_BEVENT+16*CAP_BUCKET,	L_WINARR=L_BIDX+16*CAP_BUCKET,	L_WINCHUNK=L_WINARR+WIN_NCHUNKS*WIN_CHUNK,
 	L_WINFREE=L_WINCHUNK+64*8,	L_SCRATCH=L_WINFREE+WIN_NCHUNKS,
 	L_HEAP=L_SCRATCH+16*CAP_SCRATCH,L_FOLLOW=L_HEAP+2*CAP_HEAP,	L_DISPOSE=L_FOLLOW+CAP_FOLLOW*12,
-	L_RULEFREE=L_DISPOSE+CAP_DISPOSE,L_TRIGFREE=L_RULEFREE+CAP_RULES,L_ITEMS=L_TRIGFREE+CAP_TRIGS,
-	L_REFS=L_ITEMS+CAP_ITEMS*12,	L_ITEMFREE=L_REFS+CAP_REFS*2,	L_REFFREE=L_ITEMFREE+CAP_ITEMS,
-	L_TOTAL=L_REFFREE+CAP_REFS
+	L_RULEFREE=L_DISPOSE+CAP_DISPOSE,L_TRIGFREE=L_RULEFREE+CAP_RULES,L_TOTAL=L_TRIGFREE+CAP_TRIGS
 };
 static_assert( sizeof(WS) <= 64*4, "wave state block");
-static_assert( L_TOTAL*4 <= 40*1024, "LDS slice of one wave: 4 waves per CU share 160 KB");
-static_assert( (L_RULES % 4) == 0 && (L_TRIGS % 4) == 0 && (L_FOLLOW % 4) == 0 && (L_ITEMS % 4) == 0, "b128 alignment");
+static_assert( L_TOTAL*4 <= 80*1024, "LDS slice of one wave: 2 waves per CU share 160 KB");
+static_assert( (L_RULES % 4) == 0 && (L_TRIGS % 4) == 0 && (L_FOLLOW % 4) == 0, "b128 alignment");
 #define LDSW( OFS)	((hu32*)w.raw + (OFS))
 #define RULES		((HRule*)LDSW( L_RULES))
 #define TRIGS		((HTrig*)LDSW( L_TRIGS))
@@ -224,15 +222,15 @@ static_assert( (L_RULES % 4) == 0 && (L_TRIGS % 4) == 0 && (L_FOLLOW % 4) == 0 &
 #define DISPOSE		LDSW( L_DISPOSE)
 #define RULEFREE	LDSW( L_RULEFREE)
 #define TRIGFREE	LDSW( L_TRIGFREE)
-#define ITEMS		((HItem*)LDSW( L_ITEMS))
-#define REFS		LDSW( L_REFS)
-#define ITEMFREE	LDSW( L_ITEMFREE)
-#define REFFREE		LDSW( L_REFFREE)
 // the rest stays in the wave's arena in HBM: written once per event at most, read at document end
 #define COLD( OFS)	(w.arena + (OFS))
 #define STOP		((StopLog*)COLD( P.arena.oStop))
 #define GSTACK		COLD( P.arena.oGStack)
 #define STAGED		((StagedResult*)COLD( P.arena.oStaged))
+#define ITEMS		((Item*)COLD( P.arena.oItems))
+#define REFS		COLD( P.arena.oRefs)
+#define ITEMFREE	COLD( P.arena.oItemFree)
+#define REFFREE		COLD( P.arena.oRefFree)
 #else
 // the wave's arena in HBM (workgroup = one wave)
 #define ARENA( OFS)	(w.arena + (OFS))
