@@ -318,6 +318,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 #pragma unroll
 	for (int p=0; p<PASSES; ++p) state[ p] = 0;
 	const u32 len = w.docLen;
+	const u32 nofPasses = uni( P.nofPasses);
 	const u32 drainAt = P.queueCap > P.nofPatterns + 64 ? P.queueCap - P.nofPatterns - 64 : 0;
 	int prevctx = CTX_EDGE;
 	bool inWord = false; u32 runStart = 0, runHash = 0;		// token hash of the current run of word characters
@@ -358,15 +359,22 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 #pragma unroll
 			for (int p=0; p<PASSES; ++p)
 			{
-				accRow[ p] = T.at( T.oAccept + (p*CTX_COUNT + ctx)*64 + LANE);
-				cmRow[ p] = T.at( (p*P.nofClasses + cls)*64 + LANE);
-				stRow[ p] = T.at( T.oStart + (p*CTX_COUNT + prevctx)*64 + LANE);
+				// the kernel is instantiated for 1,2,4,8,.. passes: the tables end at nofPasses
+				accRow[ p] = 0; cmRow[ p] = 0; stRow[ p] = 0;
+				if ((u32)p < nofPasses)
+				{
+					accRow[ p] = T.at( T.oAccept + (p*CTX_COUNT + ctx)*64 + LANE);
+					cmRow[ p] = T.at( (p*P.nofClasses + cls)*64 + LANE);
+					stRow[ p] = T.at( T.oStart + (p*CTX_COUNT + prevctx)*64 + LANE);
+				}
 			}
 			u64 acc[ PASSES];
 			u64 anyAcc = 0;
 #pragma unroll
 			for (int p=0; p<PASSES; ++p)
 			{
+				acc[ p] = 0;
+				if ((u32)p >= nofPasses) continue;
 				const u64 st = state[ p];
 				acc[ p] = st & accRow[ p];			// matches ending before byte i
 				anyAcc |= acc[ p];
