@@ -16,7 +16,6 @@
 
 namespace spa {
 hipError_t launchL2Match( const L2Params& P, unsigned nblocks, hipStream_t stream);
-hipError_t launchL2MatchLds( const L2Params& P, unsigned nwaves, hipStream_t stream);
 }
 
 using namespace spa;
@@ -49,10 +48,9 @@ uint32_t alignUp( uint32_t v, uint32_t a) { return (v + a-1) / a * a; }
 void layoutArena( ArenaLayout& L)
 {
 	uint32_t o = 0;
-	L.oRules = o;	o += alignUp( L.maxRules*12, 4);
-	L.oTrigs = o;	o += alignUp( L.maxTrigs*8, 4);
-	L.oBEvent = o;	o += alignUp( 16*L.bucketCap, 16);
-	L.oBIdx = o;	o += alignUp( 16*L.bucketCap, 16);
+	L.oRules = o;	o += L.maxRules*32;			// 128-byte blocks: rule + its 4 trigger slots
+	L.oTrigs = 0; L.oBIdx = 0; L.oTrigFree = 0;		// (unused: triggers live in the rule blocks)
+	L.oBEvent = o;	o += alignUp( 2*16*L.bucketCap, 32);	// {event, trigger id} pairs
 	L.oBSize = o;	o += 16;
 	L.oWindow = o;	o += 64;
 	L.oHeap = o;	o += alignUp( L.maxHeap*2, 4);
@@ -64,7 +62,6 @@ void layoutArena( ArenaLayout& L)
 	L.oGStack = o;	o += alignUp( L.maxGStack, 4);
 	L.oStaged = o;	o += alignUp( L.maxStaged*8, 4);
 	L.oRuleFree = o; o += alignUp( L.maxRules, 4);
-	L.oTrigFree = o; o += alignUp( L.maxTrigs, 4);
 	L.oItemFree = o; o += alignUp( L.maxItems, 4);
 	L.oRefFree = o;	o += alignUp( L.maxRefs, 4);
 	// expiry window: lists of up to 8 chunks per position; the pool covers every live rule plus one
@@ -91,7 +88,7 @@ struct sp_matcher_ctx
 	// working memory
 	ArenaLayout arena;
 	DeviceBuffer dArena; unsigned arenaWaves;
-	DeviceBuffer dCursor, dCounters, dRetry;
+	DeviceBuffer dCursor, dCounters;
 	// batch buffers (grown on demand)
 	DeviceBuffer dLexems, dOrigseg, dDocOffsets, dResults, dItems, dDocRange, dDocStats, dDocStatus;
 	uint64_t resultCapacity, itemCapacity, minResultCapacity, minItemCapacity;
@@ -99,8 +96,6 @@ struct sp_matcher_ctx
 	hipEvent_t evStart, evStop; bool evValid;
 	hipStream_t lastStream;
 	bool withItems;
-	bool ldsOnly;			// diagnostics (SPA_L2_TIER=ldsonly): no second tier, overflowing documents fail
-	bool ldsTier;			// optional first tier with the document state in LDS (SPA_L2_TIER=lds): measured slower than 8 HBM-arena waves per CU, kept for experiments
 	unsigned numCUs;
 	// single-document mode
 	std::vector<sp_lexem_t> curLexems;
@@ -108,7 +103,7 @@ struct sp_matcher_ctx
 	sp_matcher_stats_t lastStats;
 
 	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),arenaWaves(0),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
-		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),ldsOnly(false),ldsTier(false),numCUs(256),curHasSeg(false)
+		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
 		std::memset( &lastStats, 0, sizeof(lastStats));
@@ -204,7 +199,6 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 		c->nofStopWords = ft.nofStopWords;
 		c->arena.nStop = ft.nofStopWords;
 		c->dCursor.alloc( 64);
-		{ const char* tier = getenv( "SPA_L2_TIER"); if (tier && std::strcmp( tier, "lds") == 0) c->ldsTier = true; if (tier && std::strcmp( tier, "ldsonly") == 0) { c->ldsTier = true; c->ldsOnly = true; } }
 		c->dCounters.alloc( SPC_COUNT*sizeof(uint64_t));
 		HIP_CHECK( hipEventCreate( &c->evStart));
 		HIP_CHECK( hipEventCreate( &c->evStop));
@@ -414,20 +408,6 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	P.trace = (uint32_t*)traceDev;
 #endif
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
-	if (c->ldsTier)
-	{
-		// tier 1: one-wave workgroups with the document state in LDS (2 per CU); documents that outgrow
-		// the slice are queued on the device.  tier 2: the global-arena kernel takes the queue (usually
-		// empty: its waves read the count and leave).  No host round trip in between.
-		c->dRetry.reserve( (ndocs+1)*sizeof(uint32_t));
-		P.retryList = c->ldsOnly ? 0 : (uint32_t*)c->dRetry.ptr; P.retryCount = (uint32_t*)c->dCursor.ptr;
-		unsigned ldsWaves = (unsigned)((ndocs < (size_t)c->numCUs*2) ? ndocs : (size_t)c->numCUs*2);
-		if (ldsWaves > c->arenaWaves) ldsWaves = c->arenaWaves;
-		if (ldsWaves == 0) ldsWaves = 1;
-		HIP_CHECK( launchL2MatchLds( P, ldsWaves, stream));
-		P.retryList = 0; P.retryCount = 0;
-		P.docList = (const uint32_t*)c->dRetry.ptr; P.docListCount = (const uint32_t*)c->dCursor.ptr;
-	}
 	HIP_CHECK( launchL2Match( P, nblocks, stream));
 	HIP_CHECK( hipEventRecord( c->evStop, stream));
 #if defined(SPA_TRACE) || defined(SPA_POLL)
@@ -493,12 +473,6 @@ int sp_matcher_ctx_batch_counters( sp_matcher_ctx_t* c, uint64_t counters[8])
 		HIP_CHECK( hipSetDevice( c->device));
 		HIP_CHECK( hipStreamSynchronize( c->lastStream));
 		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, SPC_COUNT*sizeof(uint64_t), hipMemcpyDeviceToHost));
-#if !defined(SPA_PROF) && !defined(SPA_PROF2)
-		// diagnostic: how many documents went to the second tier
-		uint32_t retried = 0;
-		if (c->ldsTier) HIP_CHECK( hipMemcpy( &retried, c->dCursor.ptr, sizeof(retried), hipMemcpyDeviceToHost));
-		counters[ 7] = retried;
-#endif
 	});
 }
 

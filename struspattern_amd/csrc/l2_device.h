@@ -41,12 +41,6 @@ struct L2Params
 	uint32_t* arenaBase;
 	ArenaLayout arena;
 	uint32_t* docCursor;
-	// two tiers: the LDS kernel appends the documents that outgrow its slice to retryList; the
-	// global-arena kernel then takes its documents from docList/docListCount (same buffers)
-	uint32_t* retryList;
-	uint32_t* retryCount;
-	const uint32_t* docList;
-	const uint32_t* docListCount;
 	// output
 	uint64_t* counters;		// SPC_*
 	uint32_t* results;		// sp_result_t[resultCapacity] (9 words each)

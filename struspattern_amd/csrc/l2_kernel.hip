@@ -77,20 +77,25 @@ typedef uint64_t u64;
 typedef const __attribute__((address_space(4))) L2Params& KP;
 __device__ __forceinline__ KP kernelParams() { return *(const __attribute__((address_space(4))) L2Params*)__builtin_amdgcn_kernarg_segment_ptr(); }
 
-enum {F_ACTIVE=1u, F_DONE=2u};
+enum {F_ACTIVE=1u, F_DONE=2u, F_EXT=4u};
 
 struct EvData { u32 sseg, eseg, spos, epos, sord, eord, sub, fmt; };		// src/ruleMatcherAutomaton.hpp:200-218
 
-struct Rule		// rule instance + its action slot (hpp:87-104, :171-186), 48 B
+// A rule instance and the triggers it has installed share one 128-byte block (one L2 cache line):
+// installing, firing and deactivating a rule each touch that line and the bucket lines, nothing else.
+// The per-document state of all resident waves is far larger than the L2, so the number of distinct
+// lines an operation touches is what the kernel pays for.
+struct Trig		// installed trigger (hpp:45-74, :118-127), 16 B
+{
+	u32 event, sigval, typevar, link;	// typevar = sigtype | variable<<4 ; link = bucket<<28 | position in the bucket
+};
+struct Rule		// rule instance + its action slot (hpp:87-104, :171-186) + 4 trigger slots, 128 B
 {
 	u32 value, count, flags, start_ordpos;
 	u32 end_ordpos, start_origseg, start_origpos, program;
-	u32 trigHead, dataRef, next, expiry;
-};
-struct Trig		// installed trigger (hpp:45-74, :118-127), 32 B
-{
-	u32 event, rule, sigval, typevar;	// typevar = sigtype | variable<<4
-	u32 link, next, _a, _b;			// link = bucket<<28 | position ; next = next trigger of the same rule (1-based)
+	u32 trigMask, dataRef, ext, owner;	// trigMask: occupied slots; ext: continuation block+1 (programs with more than 4 triggers); owner: rule of a continuation block
+	u32 _pad[4];
+	Trig trig[4];				// trigger id = 4*block + slot, filled in installation order
 };
 struct Item { u32 variable, next, _a, _b; EvData d; };	// captured variable (hpp:262-271), 48 B
 struct Follow { EvData d; u32 event, _a, _b, _c; };	// 48 B
@@ -98,26 +103,12 @@ struct StopLog { EvData d; u32 timestamp, _a, _b, _c; };// 48 B
 struct StagedResult { u32 handle, sord, eord, sseg, spos, eseg, epos, dataRef; };	// 32 B
 
 // ---------------------------------------------------------------- where the per-document state lives
-// This source is compiled twice:
-//  - SPA_L2_LDS (l2_kernel_lds.hip): the hot state of the document -- rules, triggers, the 16 trigger
-//    buckets, expiry window, free stacks, captured items, follow/dispose lists and the scalar
-//    counters -- is a 77 KB slice of LDS owned by a one-wave workgroup (2 workgroups per CU).  Every
-//    step of the automaton is a chain of dependent accesses to that state, so its speed is the
-//    access latency: LDS answers in ~100 cycles where an L2/HBM round trip costs 500-2000.
-//    Capacities are compile-time constants; a document that outgrows them is queued for
-//  - the global tier (l2_kernel.hip): same code, state in a per-wave arena in HBM whose capacities
-//    grow on demand.
+// Records and lists: a per-wave arena in HBM whose capacities grow on demand (layout: ArenaLayout).
+// Scalars: a block of LDS per wave (struct WS).  A variant that kept rules, triggers and buckets in a
+// 77 KB LDS slice (2 waves per CU) was measured slower than 8 arena waves per CU and was removed.
 #define LDSQ __attribute__((address_space(3)))
-#ifdef SPA_L2_LDS
-#define HOT LDSQ
-enum {
-	CAP_RULES=576, CAP_TRIGS=576, CAP_BUCKET=80, CAP_FOLLOW=16, CAP_DISPOSE=576, CAP_HEAP=64,
-	WIN_CHUNK=16, WIN_NCHUNKS=100, CAP_SCRATCH=48
-};
-#else
 #define HOT
 #define CAP_RULES	(P.arena.maxRules)
-#define CAP_TRIGS	(P.arena.maxTrigs)
 #define CAP_BUCKET	(P.arena.bucketCap)
 #define CAP_FOLLOW	(P.arena.maxFollow)
 #define CAP_DISPOSE	(P.arena.maxDispose)
@@ -125,12 +116,11 @@ enum {
 #define WIN_CHUNK	(P.arena.winChunk)
 #define WIN_NCHUNKS	(P.arena.winChunks)
 #define CAP_SCRATCH	(P.arena.scratchCap)
-#endif
 #define CAP_ITEMS	(P.arena.maxItems)
 #define CAP_REFS	(P.arena.maxRefs)
 typedef HOT u32 hu32;
 typedef HOT Rule HRule;
-typedef HOT Trig HTrig;
+typedef Trig HTrig;
 typedef Item HItem;		// captured items and data references stay in HBM in both tiers: results keep them alive until the document ends
 typedef HOT Follow HFollow;
 typedef HOT EvData HEvData;
@@ -143,7 +133,7 @@ struct WS
 {
 	u32 curpos, timestamp, nInstalled, nAlt, nSignals, nTrig;
 	u64 open;
-	u32 ruleFreeN, ruleUsed, trigFreeN, trigUsed, itemFreeN, itemUsed, refFreeN, refUsed;
+	u32 ruleFreeN, ruleUsed, itemFreeN, itemUsed, refFreeN, refUsed;
 	u32 heapSize, nFollow, nDispose, nStaged, err;
 	u32 winFreeN, winUsed;
 #if defined(SPA_PROF) || defined(SPA_PROF2)
@@ -181,63 +171,23 @@ struct WSV		// view of the wave state block at `raw` (one LDS address; everythin
 	u32* arena;		// the wave's arena in HBM
 	WSField curpos, timestamp, nInstalled, nAlt, nSignals, nTrig;
 	WSField64 open;
-	WSField ruleFreeN, ruleUsed, trigFreeN, trigUsed, itemFreeN, itemUsed, refFreeN, refUsed;
+	WSField ruleFreeN, ruleUsed, itemFreeN, itemUsed, refFreeN, refUsed;
 	WSField heapSize, nFollow, nDispose, nStaged, err;
 	WSField winFreeN, winUsed;
 	__device__ __forceinline__ WSV( HWS* b, u32* a)
 		:raw(b),arena(a),curpos{&b->curpos},timestamp{&b->timestamp},nInstalled{&b->nInstalled},nAlt{&b->nAlt},nSignals{&b->nSignals},nTrig{&b->nTrig}
-		,open{&b->open},ruleFreeN{&b->ruleFreeN},ruleUsed{&b->ruleUsed},trigFreeN{&b->trigFreeN},trigUsed{&b->trigUsed}
+		,open{&b->open},ruleFreeN{&b->ruleFreeN},ruleUsed{&b->ruleUsed}
 		,itemFreeN{&b->itemFreeN},itemUsed{&b->itemUsed},refFreeN{&b->refFreeN},refUsed{&b->refUsed}
 		,heapSize{&b->heapSize},nFollow{&b->nFollow},nDispose{&b->nDispose},nStaged{&b->nStaged},err{&b->err}
 		,winFreeN{&b->winFreeN},winUsed{&b->winUsed} {}
 };
 typedef const WSV& WSR;
 
-#ifdef SPA_L2_LDS
-// LDS slice layout in words from the wave state block (16-byte aligned where records are moved with b128)
-enum {
-	L_WS=0,				L_BSIZE=L_WS+64,		L_WINDOW=L_BSIZE+16,
-	L_RULES=L_WINDOW+64,		L_TRIGS=L_RULES+CAP_RULES*12,	L_BEVENT=L_TRIGS+CAP_TRIGS*8,
-	L_BIDX=L_BEVENT+16*CAP_BUCKET,	L_WINARR=L_BIDX+16*CAP_BUCKET,	L_WINCHUNK=L_WINARR+WIN_NCHUNKS*WIN_CHUNK,
-	L_WINFREE=L_WINCHUNK+64*8,	L_SCRATCH=L_WINFREE+WIN_NCHUNKS,
-	L_HEAP=L_SCRATCH+16*CAP_SCRATCH,L_FOLLOW=L_HEAP+2*CAP_HEAP,	L_DISPOSE=L_FOLLOW+CAP_FOLLOW*12,
-	L_RULEFREE=L_DISPOSE+CAP_DISPOSE,L_TRIGFREE=L_RULEFREE+CAP_RULES,L_TOTAL=L_TRIGFREE+CAP_TRIGS
-};
-static_assert( sizeof(WS) <= 64*4, "wave state block");
-static_assert( L_TOTAL*4 <= 80*1024, "LDS slice of one wave: 2 waves per CU share 160 KB");
-static_assert( (L_RULES % 4) == 0 && (L_TRIGS % 4) == 0 && (L_FOLLOW % 4) == 0, "b128 alignment");
-#define LDSW( OFS)	((hu32*)w.raw + (OFS))
-#define RULES		((HRule*)LDSW( L_RULES))
-#define TRIGS		((HTrig*)LDSW( L_TRIGS))
-#define BEVENT		LDSW( L_BEVENT)
-#define BIDX		LDSW( L_BIDX)
-#define BSIZE		LDSW( L_BSIZE)
-#define WINDOW		LDSW( L_WINDOW)
-#define WINARR		LDSW( L_WINARR)
-#define WINCHUNK	LDSW( L_WINCHUNK)
-#define WINFREE		LDSW( L_WINFREE)
-#define SCRATCH		LDSW( L_SCRATCH)
-#define HEAP		LDSW( L_HEAP)
-#define FOLLOW		((HFollow*)LDSW( L_FOLLOW))
-#define DISPOSE		LDSW( L_DISPOSE)
-#define RULEFREE	LDSW( L_RULEFREE)
-#define TRIGFREE	LDSW( L_TRIGFREE)
-// the rest stays in the wave's arena in HBM: written once per event at most, read at document end
-#define COLD( OFS)	(w.arena + (OFS))
-#define STOP		((StopLog*)COLD( P.arena.oStop))
-#define GSTACK		COLD( P.arena.oGStack)
-#define STAGED		((StagedResult*)COLD( P.arena.oStaged))
-#define ITEMS		((Item*)COLD( P.arena.oItems))
-#define REFS		COLD( P.arena.oRefs)
-#define ITEMFREE	COLD( P.arena.oItemFree)
-#define REFFREE		COLD( P.arena.oRefFree)
-#else
 // the wave's arena in HBM (workgroup = one wave)
 #define ARENA( OFS)	(w.arena + (OFS))
 #define RULES		((Rule*)ARENA( P.arena.oRules))
-#define TRIGS		((Trig*)ARENA( P.arena.oTrigs))
-#define BEVENT		ARENA( P.arena.oBEvent)
-#define BIDX		ARENA( P.arena.oBIdx)
+#define TRIG( T)	(&RULES[ (T) >> 2].trig[ (T) & 3u])
+#define BKT		ARENA( P.arena.oBEvent)		/* 16 buckets x bucketCap x {event, trigger id} */
 #define BSIZE		ARENA( P.arena.oBSize)
 #define WINDOW		ARENA( P.arena.oWindow)
 #define WINARR		ARENA( P.arena.oWinArr)
@@ -248,7 +198,6 @@ static_assert( (L_RULES % 4) == 0 && (L_TRIGS % 4) == 0 && (L_FOLLOW % 4) == 0, 
 #define FOLLOW		((Follow*)ARENA( P.arena.oFollow))
 #define DISPOSE		ARENA( P.arena.oDispose)
 #define RULEFREE	ARENA( P.arena.oRuleFree)
-#define TRIGFREE	ARENA( P.arena.oTrigFree)
 #define ITEMS		((Item*)ARENA( P.arena.oItems))
 #define REFS		ARENA( P.arena.oRefs)
 #define ITEMFREE	ARENA( P.arena.oItemFree)
@@ -256,7 +205,6 @@ static_assert( (L_RULES % 4) == 0 && (L_TRIGS % 4) == 0 && (L_FOLLOW % 4) == 0, 
 #define STOP		((StopLog*)ARENA( P.arena.oStop))
 #define GSTACK		ARENA( P.arena.oGStack)
 #define STAGED		((StagedResult*)ARENA( P.arena.oStaged))
-#endif
 
 __device__ __forceinline__ u32 evhash( u32 a)		// src/ruleMatcherAutomaton.cpp:34-40
 {
@@ -319,18 +267,6 @@ __device__ __forceinline__ u32 allocRule( WSR w, KP P)
 __device__ __forceinline__ void freeRule( WSR w, KP P, u32 r)
 {
 	RULEFREE[ w.ruleFreeN++] = r;
-}
-__device__ __forceinline__ u32 allocTrig( WSR w, KP P)
-{
-	u32 t;
-	if (w.trigFreeN) { t = ldu( &TRIGFREE[ --w.trigFreeN]); }
-	else if (w.trigUsed < CAP_TRIGS) { t = w.trigUsed++; }
-	else { ARENA_FAIL; t = 0; }
-	return t;
-}
-__device__ __forceinline__ void freeTrig( WSR w, KP P, u32 t)
-{
-	TRIGFREE[ w.trigFreeN++] = t;
 }
 __device__ __forceinline__ u32 allocItem( WSR w, KP P)
 {
@@ -401,27 +337,44 @@ __device__ __forceinline__ void addTrigger( WSR w, KP P, u32 t, u32 event)
 	u32 h = evhash( event) & 15u;
 	u32 pos = ldu( &BSIZE[ h]);
 	if (pos >= CAP_BUCKET) { ARENA_FAIL; return; }
-	BEVENT[ h*CAP_BUCKET + pos] = event;
-	BIDX[ h*CAP_BUCKET + pos] = t;
+	*(uint2*)&BKT[ 2*(h*CAP_BUCKET + pos)] = make_uint2( event, t);
 	BSIZE[ h] = pos+1;
-	TRIGS[ t].link = (h << 28) | pos;
+	TRIG( t)->link = (h << 28) | pos;
 	w.nTrig += 1;
 }
 __device__ __forceinline__ void removeTrigger( WSR w, KP P, u32 t)	// swap with last, cpp:133-152
 {
-	u32 link = ldu( &TRIGS[ t].link);
+	u32 link = ldu( &TRIG( t)->link);
 	u32 h = link >> 28, pos = link & 0x0FFFFFFFu;
 	u32 last = ldu( &BSIZE[ h])-1;
 	if (pos != last)
 	{
-		u32 me = ldu( &BEVENT[ h*CAP_BUCKET + last]);
-		u32 mi = ldu( &BIDX[ h*CAP_BUCKET + last]);
-		BEVENT[ h*CAP_BUCKET + pos] = me;
-		BIDX[ h*CAP_BUCKET + pos] = mi;
-		TRIGS[ mi].link = link;
+		u32 me = ldu( &BKT[ 2*(h*CAP_BUCKET + last)]);
+		u32 mi = ldu( &BKT[ 2*(h*CAP_BUCKET + last)+1]);
+		*(uint2*)&BKT[ 2*(h*CAP_BUCKET + pos)] = make_uint2( me, mi);
+		TRIG( mi)->link = link;
 	}
 	BSIZE[ h] = last;
 	w.nTrig -= 1;
+}
+
+// The triggers of a rule, last installed first (the order of the reference's per-rule trigger list):
+// continuation blocks from the deepest one back, then the slots 3..0 of the rule's own block.
+template <class VISIT>
+__device__ __forceinline__ void forEachTriggerLastFirst( WSR w, KP P, u32 r, VISIT visit)
+{
+	u32 depth = 0;
+	for (u32 b=ldu( &RULES[ r].ext); b; b=ldu( &RULES[ b-1].ext))
+	{
+		if (++depth > CAP_RULES) { w.err = SPD_ERR_INTERNAL; return; }
+	}
+	for (u32 k=depth+1; k>0; --k)
+	{
+		u32 b = r;
+		for (u32 i=1; i<k; ++i) b = ldu( &RULES[ b].ext)-1;
+		const u32 mask = ldu( &RULES[ b].trigMask);
+		for (int j=3; j>=0; --j) if ((mask >> j) & 1u) visit( 4*b + (u32)j);
+	}
 }
 
 __device__ __forceinline__ void deactivateRule( WSR w, KP P, u32 r)	// cpp:679-702
@@ -431,16 +384,15 @@ __device__ __forceinline__ void deactivateRule( WSR w, KP P, u32 r)	// cpp:679-7
 	if (flags & F_ACTIVE)
 	{
 		R->flags = flags & ~F_ACTIVE;
-		u32 t = ldu( &R->trigHead);
-		for (u32 guard=0; t; ++guard)
+		forEachTriggerLastFirst( w, P, r, [&]( u32 t) { removeTrigger( w, P, t); });
+		for (u32 b=ldu( &R->ext); b; )			// release the continuation blocks
 		{
-			if (guard > w.trigUsed) { w.err = SPD_ERR_INTERNAL; break; }
-			u32 nx = ldu( &TRIGS[ t-1].next);
-			removeTrigger( w, P, t-1);
-			freeTrig( w, P, t-1);
-			t = nx;
+			u32 nx = ldu( &RULES[ b-1].ext);
+			RULES[ b-1].trigMask = 0; RULES[ b-1].ext = 0;
+			RULEFREE[ w.ruleFreeN++] = b-1;
+			b = nx;
 		}
-		R->trigHead = 0;
+		R->trigMask = 0; R->ext = 0;
 		u32 ref = ldu( &R->dataRef);
 		if (ref) { disposeRef( w, P, ref); R->dataRef = 0; }
 	}
@@ -475,13 +427,13 @@ __device__ __noinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP P, 
 		u32 r = 0;
 		if (have) r = reversed ? list[ n - 1 - (base + LANE)] : list[ base + LANE];
 		bool act = false;
-		u32 head = 0, ref = 0;
+		u32 mask = 0, ref = 0, ext = 0;
 		if (have)
 		{
 			HRule* R = &RULES[ r];
 			u32 flags = R->flags;
 			act = (flags & F_ACTIVE) != 0;
-			if (act) { const uint4 q2 = ld4( W( R) + 8); head = q2.x; ref = q2.y; }
+			if (act) { const uint4 q2 = ld4( W( R) + 8); mask = q2.x; ref = q2.y; ext = q2.z; }	// {trigMask, dataRef, ext, owner}
 		}
 		if (checkDup)
 		{
@@ -496,21 +448,24 @@ __device__ __noinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP P, 
 		if (act)
 		{
 			HRule* R = &RULES[ r];
-			R->flags = R->flags & ~F_ACTIVE; R->trigHead = 0; R->dataRef = 0;
+			R->flags = R->flags & ~F_ACTIVE; R->trigMask = 0; R->dataRef = 0;
 		}
-		// trigger chains (short: one per installed template)
-		u32 t[ DEACT_MAXCHAIN]; u32 nt = 0; bool longChain = false;
-#pragma unroll
-		for (int c=0; c<DEACT_MAXCHAIN; ++c)
+		// my triggers, last installed first: the occupied slots of my block from the top
+		u32 t[ DEACT_MAXCHAIN]; u32 nt = 0;
+		const bool longChain = act && ext != 0;		// continuation blocks (more than 4 triggers): rare
 		{
-			t[ c] = 0;
-			if (act && head) { t[ c] = head-1; head = TRIGS[ head-1].next; ++nt; }
+			u32 rem = act ? mask : 0u;
+#pragma unroll
+			for (int c=0; c<DEACT_MAXCHAIN; ++c)
+			{
+				t[ c] = 0;
+				if (rem) { const u32 j = 31u - (u32)__builtin_clz( rem); rem &= ~(1u << j); t[ c] = 4*r + j; ++nt; }
+			}
 		}
-		if (act && head) longChain = true;
 		if (__ballot( longChain))
 		{
 			// rare: finish this block one rule at a time (flags were cleared above: restore, then serial)
-			if (act) { HRule* R = &RULES[ r]; R->flags = R->flags | F_ACTIVE; R->trigHead = t[0]+1; R->dataRef = ref; }
+			if (act) { HRule* R = &RULES[ r]; R->flags = R->flags | F_ACTIVE; R->trigMask = mask; R->dataRef = ref; }
 			__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 			for (u32 k=0; k<nb && !w.err; ++k)
 			{
@@ -523,7 +478,7 @@ __device__ __noinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP P, 
 		// stable partition of the triggers by bucket: scratch[b*cap + rank]
 		u32 hOf[ DEACT_MAXCHAIN];
 #pragma unroll
-		for (int c=0; c<DEACT_MAXCHAIN; ++c) hOf[ c] = ((u32)c < nt) ? (TRIGS[ t[ c]].link >> 28) : 16u;
+		for (int c=0; c<DEACT_MAXCHAIN; ++c) hOf[ c] = ((u32)c < nt) ? (TRIG( t[ c])->link >> 28) : 16u;
 		u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
 		for (int c=0; c<DEACT_MAXCHAIN; ++c)
@@ -594,37 +549,27 @@ __device__ __noinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP P, 
 			if (myCount)
 			{
 				const u32 b = LANE;
-				hu32* be = BEVENT + b*CAP_BUCKET;
-				hu32* bi = BIDX + b*CAP_BUCKET;
+				uint2* bk = (uint2*)BKT + b*CAP_BUCKET;		// {event, trigger id}
 				u32 size = BSIZE[ b];
 				for (u32 k=0; k<myCount; ++k)
 				{
 					const u32 tk = SCRATCH[ b*scap + k];
-					const u32 link = TRIGS[ tk].link;
+					const u32 link = TRIG( tk)->link;
 					const u32 pos = link & 0x0FFFFFFFu;
 					const u32 last = size-1;
 					if (pos != last)
 					{
-						const u32 me = be[ last], mi = bi[ last];
-						be[ pos] = me; bi[ pos] = mi;
-						TRIGS[ mi].link = link;
+						const uint2 moved = bk[ last];
+						bk[ pos] = moved;
+						TRIG( moved.y)->link = link;
 					}
 					size = last;
 				}
 				BSIZE[ b] = size;
 			}
 		}
-		// release the trigger records
-		{
-			u32 incT = ntot;
-			for (int dd=1; dd<64; dd<<=1) { u32 up = __shfl_up( incT, dd); if ((int)LANE >= dd) incT += up; }
-			const u32 totalT = (u32)__builtin_amdgcn_readlane( incT, 63);
-			u32 at = w.trigFreeN + incT - ntot;
-#pragma unroll
-			for (int c=0; c<DEACT_MAXCHAIN; ++c) if ((u32)c < nt) TRIGFREE[ at++] = t[ c];
-			w.trigFreeN += totalT;
-			w.nTrig -= totalT;
-		}
+		// the trigger slots go with their rule blocks: only the count of installed triggers changes
+		w.nTrig -= (u32)__popcll( __ballot( ntot & 1u)) + 2u*(u32)__popcll( __ballot( ntot & 2u)) + 4u*(u32)__popcll( __ballot( ntot & 4u));
 		// release the data references (cpp:696-700 -> :710-732): one rule per lane
 		if (P.withItems)
 		{
@@ -816,7 +761,13 @@ __device__ __forceinline__ void setCurrentPos( WSR w, KP P, u32 pos)	// cpp:1084
 __device__ __forceinline__ void fireSignal( WSR w, KP P, u32 r, u32 sigtype, u32 sigval, u32 variable, const EvData& d)
 {
 	HRule* R = &RULES[ r];
-	const uint4 q0 = ldu4( R), q1 = ldu4( W( R) + 4);		// {value,count,flags,start_ordpos} {end_ordpos,start_origseg,start_origpos,program}
+	uint4 q0 = ldu4( R), q1 = ldu4( W( R) + 4);		// {value,count,flags,start_ordpos} {end_ordpos,start_origseg,start_origpos,program}
+	if (q0.z & F_EXT)
+	{
+		// trigger slot in a continuation block: the state is in the owner's block
+		r = ldu( &R->owner); R = &RULES[ r];
+		q0 = ldu4( R); q1 = ldu4( W( R) + 4);
+	}
 	u32 value = q0.x, count = q0.y, flags = q0.z, end_ordpos = q1.x;
 	bool match = false, take = false, fin = false;
 	w.nSignals += 1;
@@ -978,34 +929,28 @@ __device__ __forceinline__ void replayPastEvent( WSR w, KP P, u32 pastEvent, u32
 	if (ld.sord + range < w.curpos) return;
 
 	u32 nFollow0 = w.nFollow, nDispose0 = w.nDispose;
-	u32 t = ldu( &RULES[ r].trigHead);
-	for (u32 guard=0; t && !w.err; ++guard)
-	{
-		if (guard > w.trigUsed) { w.err = SPD_ERR_INTERNAL; break; }
-		HTrig* T = &TRIGS[ t-1];
-		u32 tev = ldu( &T->event), typevar = ldu( &T->typevar), sigval = ldu( &T->sigval);
-		t = ldu( &T->next);
-		if (tev == pastEvent) fireSignal( w, P, r, typevar & 15u, sigval, typevar >> 4, ld);
-	}
+	forEachTriggerLastFirst( w, P, r, [&]( u32 t) {
+		if (w.err) return;
+		const uint4 tq = ldu4( TRIG( t));		// {event, sigval, typevar, link}
+		if (tq.x == pastEvent) fireSignal( w, P, r, tq.z & 15u, tq.y, tq.z >> 4, ld);
+	});
 	// a structure delimiter logged after the replayed event cancels the rule (cpp:1306-1321)
-	t = ldu( &RULES[ r].trigHead);
-	for (u32 guard=0; t; ++guard)
-	{
-		if (guard > w.trigUsed) { w.err = SPD_ERR_INTERNAL; break; }
-		HTrig* T = &TRIGS[ t-1];
-		u32 tev = ldu( &T->event), typevar = ldu( &T->typevar);
-		t = ldu( &T->next);
-		if ((typevar & 15u) == SIG_DEL)
+	bool cancelled = false;
+	forEachTriggerLastFirst( w, P, r, [&]( u32 t) {
+		if (cancelled) return;
+		const uint4 tq = ldu4( TRIG( t));
+		if ((tq.z & 15u) == SIG_DEL)
 		{
-			const DevKeyEntry* e = lookupKey( P, tev);
+			const DevKeyEntry* e = lookupKey( P, tq.x);
 			u32 esi = e ? ldu( &e->stopIdx) : 0;
 			if (esi)
 			{
 				u32 ts = ldu( &STOP[ esi-1].timestamp);
-				if (ts && ts > pastStamp) { deactivateRule( w, P, r); break; }
+				if (ts && ts > pastStamp) cancelled = true;
 			}
 		}
-	}
+	});
+	if (cancelled) deactivateRule( w, P, r);
 	for (u32 di=nDispose0; di<w.nDispose; ++di) deactivateRule( w, P, ldu( &DISPOSE[ di]));
 	w.nDispose = nDispose0;
 	if (w.nFollow != nFollow0) { w.nFollow = nFollow0; w.err = SPD_ERR_PASTFOLLOW; }
@@ -1025,7 +970,7 @@ __device__ __forceinline__ void installProgram( WSR w, KP P, u32 keyevent, const
 	u32 count = ldu( &G->initcount) & 0xFFFFu;		// ActionSlot::count is 16 bit (hpp:98)
 	R->value = ldu( &G->initsigval); R->count = count; R->flags = F_ACTIVE; R->start_ordpos = 0;
 	R->end_ordpos = 0; R->start_origseg = 0; R->start_origpos = 0; R->program = program;
-	R->trigHead = 0; R->dataRef = 0; R->expiry = d.sord + range;
+	R->trigMask = 0; R->dataRef = 0; R->ext = 0; R->owner = 0;
 	defineDisposeRule( w, P, d.sord + range, r);
 	if (w.err) return;
 
@@ -1033,7 +978,7 @@ __device__ __forceinline__ void installProgram( WSR w, KP P, u32 keyevent, const
 	u64 keymaskbits = 0;
 	u32 nofKey = 0;
 	bool hasKey = false;
-	u32 head = 0;
+	u32 blk = r, slot = 0, blkMask = 0;		// trigger slots are filled in installation order, 4 per block
 	for (u32 j=0; j<tc; ++j)
 	{
 		const DevTrigDef* D = &P.trigdefs[ tb+j];
@@ -1052,16 +997,26 @@ __device__ __forceinline__ void installProgram( WSR w, KP P, u32 keyevent, const
 		else doInstall = true;
 		if (doInstall)
 		{
-			u32 t = allocTrig( w, P);
-			if (w.err) return;
-			HTrig* T = &TRIGS[ t];
-			T->event = tev; T->rule = r; T->sigval = ldu( &D->sigval); T->typevar = sigtype | (ldu( &D->variable) << 4);
-			T->next = head; head = t+1;
+			if (slot == 4)
+			{
+				// more than 4 triggers: continue in another block chained to this one
+				u32 nb = allocRule( w, P);
+				if (w.err) return;
+				HRule* X = &RULES[ nb];
+				X->value = 0; X->count = 0; X->flags = F_EXT; X->start_ordpos = 0;
+				X->trigMask = 0; X->dataRef = 0; X->ext = 0; X->owner = r;
+				RULES[ blk].trigMask = blkMask; RULES[ blk].ext = nb+1;
+				blk = nb; slot = 0; blkMask = 0;
+			}
+			const u32 t = 4*blk + slot;
+			HTrig* T = TRIG( t);
+			T->event = tev; T->sigval = ldu( &D->sigval); T->typevar = sigtype | (ldu( &D->variable) << 4);
 			addTrigger( w, P, t, tev);
 			if (w.err) return;
+			blkMask |= 1u << slot; ++slot;
 		}
 	}
-	R->trigHead = head;
+	RULES[ blk].trigMask = blkMask;
 	w.nInstalled += 1;
 
 	u32 pastEvent = ldu( &K->pastEvent);
@@ -1324,7 +1279,6 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 			}
 			if (full) return;
 		}
-		const u32 nextLink = 0;
 		// ---- triggers: bucket positions in (program, template) order
 		u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;		// my installs per bucket, 16 x 8 bit
 		u32 hB[ MAXT];
@@ -1348,11 +1302,8 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 		const u32 e0 = i0 - c0, e1 = i1 - c1, e2 = i2 - c2, e3 = i3 - c3;
 		const u32 t0 = (u32)__builtin_amdgcn_readlane( i0, 63), t1 = (u32)__builtin_amdgcn_readlane( i1, 63);
 		const u32 t2 = (u32)__builtin_amdgcn_readlane( i2, 63), t3 = (u32)__builtin_amdgcn_readlane( i3, 63);
-		const u32 trigBefore = byteSum( e0 + e1 + e2 + e3);
 		const u32 totalTrig = byteSum( t0 + t1 + t2 + t3);
-		const u32 trigFromStack = w.trigFreeN < totalTrig ? w.trigFreeN : totalTrig;
-		if (w.trigUsed + (totalTrig - trigFromStack) > CAP_TRIGS) { ARENA_FAIL; return; }
-		u32 head = 0, local = 0;
+		u32 head = 0, local = 0;		// head: occupied trigger slots of my block
 		bool overflow = false;
 #pragma unroll
 		for (int j=0; j<MAXT; ++j)
@@ -1364,17 +1315,13 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 #pragma unroll
 				for (int jj=0; jj<j; ++jj) if (tInstall[ jj] && hB[ jj] == h) ++same;	// my own earlier templates
 				const u32 pos = BSIZE[ h] + byteField( e0, e1, e2, e3, h) + same;
-				const u32 seq = trigBefore + local;
-				const u32 t = seq < trigFromStack ? TRIGFREE[ w.trigFreeN - 1 - seq] : w.trigUsed + (seq - trigFromStack);
+				const u32 t = 4*r + local;		// slots in installation order (MAXT <= 4)
 				if (pos >= CAP_BUCKET) overflow = true;
 				else
 				{
-					BEVENT[ h*CAP_BUCKET + pos] = tEvent[ j];
-					BIDX[ h*CAP_BUCKET + pos] = t;
-					HTrig* T = &TRIGS[ t];
-					st4( T, tEvent[ j], r, tSigval[ j], tTypevar[ j]);
-					st4( W( T) + 4, (h << 28) | pos, head, 0, 0);
-					head = t+1;
+					*(uint2*)&BKT[ 2*(h*CAP_BUCKET + pos)] = make_uint2( tEvent[ j], t);
+					st4( TRIG( t), tEvent[ j], tSigval[ j], tTypevar[ j], (h << 28) | pos);
+					head |= 1u << local;
 				}
 				++local;
 			}
@@ -1382,7 +1329,6 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 		if (__ballot( overflow)) { ARENA_FAIL; return; }
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		if (LANE < 16) BSIZE[ LANE] += byteField( t0, t1, t2, t3, LANE);
-		w.trigFreeN -= trigFromStack; w.trigUsed += totalTrig - trigFromStack;
 		w.nTrig += totalTrig;
 		w.nInstalled += nlive;
 
@@ -1480,7 +1426,7 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 			HRule* R = &RULES[ r];
 			st4( R, value, count, flags, start_ordpos);
 			st4( W( R) + 4, end_ordpos, start_origseg, start_origpos, program);
-			st4( W( R) + 8, head, dataRef, nextLink, expiry);
+			st4( W( R) + 8, head, dataRef, 0, 0);		// {trigMask, dataRef, ext, owner}
 		}
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		} // segments
@@ -1508,19 +1454,20 @@ __device__ __noinline__ void doTransition( HWS* wsBlock, u32* wsArena, KP P, u32
 		{
 			u32 h = evhash( ev) & 15u;
 			u32 n = ldu( &BSIZE[ h]);
-			const hu32* be = BEVENT + h*CAP_BUCKET;
-			const hu32* bi = BIDX + h*CAP_BUCKET;
+			const uint2* bk = (const uint2*)BKT + h*CAP_BUCKET;	// {event, trigger id}
 			for (u32 base=0; base<n && !w.err; base+=64)
 			{
 				u32 i = base + LANE;
-				u64 m = __ballot( i < n && be[ i] == ev);
+				uint2 entry = make_uint2( 0, 0);
+				if (i < n) entry = bk[ i];
+				u64 m = __ballot( i < n && entry.x == ev);
 				while (m && !w.err)
 				{
 					u32 p = (u32)__builtin_ctzll( m);
 					m &= m-1;
-					const uint4 tq = ldu4( &TRIGS[ ldu( &bi[ base+p])]);	// {event, rule, sigval, typevar}
-					u32 tr = tq.y, typevar = tq.w, sigval = tq.z;
-					fireSignal( w, P, tr, typevar & 15u, sigval, typevar >> 4, d);
+					const u32 t = (u32)__builtin_amdgcn_readlane( entry.y, p);
+					const uint4 tq = ldu4( TRIG( t));	// {event, sigval, typevar, link}; the rule is the block the slot sits in
+					fireSignal( w, P, t >> 2, tq.z & 15u, tq.y, tq.z >> 4, d);
 				}
 			}
 		}
@@ -1596,42 +1543,27 @@ __device__ __forceinline__ u32 walkItems( WSR w, KP P, u32 ref, u32* out)
 } // anonymous namespace
 
 // ================================================================== kernel
-#ifdef SPA_L2_LDS
-extern "C" __global__ __launch_bounds__(64)
-void spa_l2_match_kernel_lds( L2Params kernelArgs)
-{
-	KP P = kernelParams();
-	__shared__ __attribute__((aligned(16))) u32 ldsSlice[ L_TOTAL];
-	const WSV w( (HWS*)ldsSlice, P.arenaBase + (u64)blockIdx.x * P.arena.totalWords);
-	const u32 ndocs = P.ndocs;
-#else
 extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPA_L2_WAVES_PER_EU, 8)))
 void spa_l2_match_kernel( L2Params kernelArgs)
 {
 	KP P = kernelParams();
 	__shared__ __attribute__((aligned(16))) u32 ldsSlice[ 64];
 	const WSV w( (HWS*)ldsSlice, P.arenaBase + (u64)blockIdx.x * P.arena.totalWords);
-	// second tier: only the documents the LDS tier has queued (count known on the device only)
-	const u32 ndocs = P.docListCount ? ldu( P.docListCount) : P.ndocs;
-#endif
+	const u32 ndocs = P.ndocs;
 	const u32 waveSlot = blockIdx.x;
 	const u32 nWaveSlots = gridDim.x;
 
 	// documents are dealt round-robin to the resident waves (document d -> wave d mod nwaves)
 	for (u32 di=waveSlot; di<ndocs; di+=nWaveSlots)
 	{
-#ifdef SPA_L2_LDS
 		const u32 doc = di;
-#else
-		const u32 doc = P.docList ? ldu( &P.docList[ di]) : di;
-#endif
 		TRACE( 1, doc);
 		// per-document reset (lane-parallel)
 		if (LANE < 16) BSIZE[ LANE] = 0;
 		WINDOW[ LANE] = 0;
 		for (u32 s=LANE; s<P.nofStopWords; s+=64) STOP[ s].timestamp = 0;
 		w.curpos = 0; w.timestamp = 0; w.nInstalled = 0; w.nAlt = 0; w.nSignals = 0; w.nTrig = 0; w.open = 0;
-		w.ruleFreeN = 0; w.ruleUsed = 0; w.trigFreeN = 0; w.trigUsed = 0; w.itemFreeN = 0; w.itemUsed = 0;
+		w.ruleFreeN = 0; w.ruleUsed = 0; w.itemFreeN = 0; w.itemUsed = 0;
 #if defined(SPA_PROF) || defined(SPA_PROF2)
 		w.raw->prof[0] = w.raw->prof[1] = w.raw->prof[2] = w.raw->prof[3] = 0;
 #endif
@@ -1734,25 +1666,13 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 				if (!P.withItems) { o[7] = 0; o[8] = 0; }
 			}
 		}
-#ifdef SPA_L2_LDS
-		if (w.err == SPD_ERR_ARENA && P.retryList)
-		{
-			// the document outgrew the LDS slice: the global tier runs it again from the start
-			if (LANE == 0) P.retryList[ atomicAdd( P.retryCount, 1u)] = doc;
-			continue;
-		}
-#endif
 		if (LANE == 0)
 		{
 			P.docRange[ 2*(u64)doc] = resBase; P.docRange[ 2*(u64)doc+1] = nres;
 			u64* st = P.docStats + 4*(u64)doc;
 			st[0] = w.nInstalled; st[1] = w.nAlt; st[2] = w.nSignals; st[3] = w.open;
 #ifdef SPA_PROF2
-#ifdef SPA_L2_LDS
-			if (w.err == SPD_ERR_ARENA) { st[0] = w.raw->prof[3]; st[1] = w.ruleUsed; st[2] = w.trigUsed; st[3] = w.itemUsed; }
-#else
-			st[0] = w.refUsed; st[1] = w.ruleUsed; st[2] = w.trigUsed; st[3] = w.itemUsed;	// high-water marks
-#endif
+			st[0] = w.refUsed; st[1] = w.ruleUsed; st[2] = w.nTrig; st[3] = w.itemUsed;	// high-water marks
 #endif
 			P.docStatus[ doc] = (int32_t)w.err;
 			atomicAdd( (unsigned long long*)&P.counters[ SPC_EVENTS], (unsigned long long)nEvents);
@@ -1766,17 +1686,9 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 
 // host-side launcher (called from capi.cpp, same translation unit family compiled by hipcc)
 namespace spa {
-#ifdef SPA_L2_LDS
-hipError_t launchL2MatchLds( const L2Params& P, unsigned nwaves, hipStream_t stream)
-{
-	hipLaunchKernelGGL( spa_l2_match_kernel_lds, dim3( nwaves), dim3( 64), 0, stream, P);
-	return hipGetLastError();
-}
-#else
 hipError_t launchL2Match( const L2Params& P, unsigned nblocks /*= waves*/, hipStream_t stream)
 {
 	hipLaunchKernelGGL( spa_l2_match_kernel, dim3( nblocks), dim3( 64), 0, stream, P);
 	return hipGetLastError();
 }
-#endif
 }

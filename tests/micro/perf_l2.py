@@ -19,4 +19,4 @@ for op in (None, "sequence"):
             if 2 in codes: ctx.growArena()
             continue
         ms = ctx.lastKernelMs(); best = ms if best is None else min(best, ms)
-    print("op=%s docs=%d: %.1f ms, %d events -> %.2f M ev/s, %.1f M matches/s" % (op, nd, best, c["events"], c["events"]/best/1e3, c["results"]/best/1e3), "second tier docs:", c["prof"][3], flush=True)
+    print("op=%s docs=%d: %.1f ms, %d events -> %.2f M ev/s, %.1f M matches/s" % (op, nd, best, c["events"], c["events"]/best/1e3, c["results"]/best/1e3), flush=True)

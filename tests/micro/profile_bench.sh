@@ -1,0 +1,33 @@
+#!/bin/bash
+# rocprofv3 evidence for the default bench command (run on the GPU box from the repo root):
+#  pass 1: --kernel-trace --stats (per-kernel durations), pass 2/3: FETCH_SIZE / WRITE_SIZE in their own runs.
+set -e
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+OUT=gpurun_out/prof_bench
+rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/write.log 2>&1
+python3 - <<'PY'
+import csv, glob, json, collections
+out = {"command": "python3 bench.py --no-cpu-baseline", "note": "FETCH_SIZE/WRITE_SIZE in KB as reported by rocprofv3; hbm_read_bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction of MI355X_MICROARCH.md, HBM section)", "kernels": {}}
+for f in glob.glob("gpurun_out/prof_bench/stats/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Name"].startswith("spa_"):
+            out["kernels"].setdefault(r["Name"], {}).update({"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6, "total_ms": float(r["TotalDurationNs"]) / 1e6})
+for name, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    acc = collections.defaultdict(list)
+    for f in glob.glob("gpurun_out/prof_bench/%s/**/*counter_collection.csv" % name, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"].startswith("spa_") and r["Counter_Name"] == key:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        v = sorted(v)[len(v) // 2:]          # the sizing passes at the start are shorter: use the upper half (steady state)
+        out["kernels"].setdefault(k, {})[key + "_KB_per_launch"] = sum(v) / len(v)
+for k, d in out["kernels"].items():
+    if "FETCH_SIZE_KB_per_launch" in d: d["hbm_read_bytes_per_launch"] = 2 * 1024 * d["FETCH_SIZE_KB_per_launch"]
+    if "WRITE_SIZE_KB_per_launch" in d: d["hbm_write_bytes_per_launch"] = 1024 * d["WRITE_SIZE_KB_per_launch"]
+json.dump(out, open("gpurun_out/prof_bench/summary.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+tail -1 $OUT/stats.log
