@@ -417,7 +417,7 @@ __device__ __forceinline__ u32 byteField( u32 c0, u32 c1, u32 c2, u32 c3, u32 h)
 // order and is done one rule per lane.
 enum {DEACT_MAXCHAIN=4};
 
-__device__ __noinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP P, const hu32* list, u32 n, bool reversed, bool freeRules, bool checkDup)
+__device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP P, const hu32* list, u32 n, bool reversed, bool freeRules, bool checkDup)
 {
 	const WSV w( wsBlock, wsArena);
 	for (u32 base=0; base<n && !w.err; base+=64)
@@ -1434,7 +1434,7 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 }
 
 // ---------------------------------------------------------------- doTransition (cpp:981-1064)
-__device__ __noinline__ void doTransition( HWS* wsBlock, u32* wsArena, KP P, u32 event, const EvData data)
+__device__ __forceinline__ void doTransition( HWS* wsBlock, u32* wsArena, KP P, u32 event, const EvData data)
 {
 	const WSV w( wsBlock, wsArena);
 	w.open += w.nTrig;
