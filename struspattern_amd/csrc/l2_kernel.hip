@@ -33,7 +33,7 @@ typedef uint64_t u64;
 
 #define LANE ((u32)(threadIdx.x & 63u))
 #ifndef SPA_L2_WAVES_PER_EU
-#define SPA_L2_WAVES_PER_EU 2
+#define SPA_L2_WAVES_PER_EU 3
 #endif
 
 // Debug build only (make TRACE=1): progress words written to host-mapped memory by wave 0 so a
