@@ -188,10 +188,11 @@ typedef const WSV& WSR;
 #define RULES		((Rule*)ARENA( P.arena.oRules))
 #define TRIG( T)	(&RULES[ (T) >> 2].trig[ (T) & 3u])
 #define BKT		ARENA( P.arena.oBEvent)		/* 16 buckets x bucketCap x {event, trigger id} */
-#define BSIZE		ARENA( P.arena.oBSize)
-#define WINDOW		ARENA( P.arena.oWindow)
+// small, touched by every step: in LDS behind the wave state block
+#define BSIZE		((lu32*)w.raw + 64)		/* 16 bucket sizes */
+#define WINDOW		((lu32*)w.raw + 80)		/* 64 expiry list lengths */
+#define WINCHUNK	((lu32*)w.raw + 144)		/* 64 x 8 chunk ids */
 #define WINARR		ARENA( P.arena.oWinArr)
-#define WINCHUNK	ARENA( P.arena.oWinChunk)
 #define WINFREE		ARENA( P.arena.oWinFree)
 #define SCRATCH		ARENA( P.arena.oScratch)
 #define HEAP		ARENA( P.arena.oHeap)
@@ -1547,7 +1548,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
 void spa_l2_match_kernel( L2Params kernelArgs)
 {
 	KP P = kernelParams();
-	__shared__ __attribute__((aligned(16))) u32 ldsSlice[ 64];
+	__shared__ __attribute__((aligned(16))) u32 ldsSlice[ 64 + 16 + 64 + 512];
 	const WSV w( (HWS*)ldsSlice, P.arenaBase + (u64)blockIdx.x * P.arena.totalWords);
 	const u32 ndocs = P.ndocs;
 	const u32 waveSlot = blockIdx.x;
