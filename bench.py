@@ -203,13 +203,33 @@ def main():
             "lexems_per_s": glexems * args.steps / dt,
             "kernel_ms": {"spa_l1_lex_kernel": l1_ms, "spa_l2_match_kernel": l2_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname, "kernel_ms": kms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kname, wl, args), "kernel": kname, "kernel_ms": kms,
+                         "algorithmic_bytes_per_launch": kbytes},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, wl, pats, rules, text, offs, lex, value, unit)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, wl, args):
+    """HBM-side bytes per launch of `kernel` (read + write) from the committed rocprofv3 PMC passes of
+    this same command (tests/micro/profile_bench.sh -> profiles/r01_bench_pmc_summary.json; FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself,
+    so the figure is only reported for the default workload and configuration it was collected on."""
+    if wl != "pipeline" or args.docs or args.regexes:
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")
+    try:
+        with open(path) as f:
+            summ = json.load(f)
+        for name, k in summ["kernels"].items():
+            if name.startswith(kernel):
+                return float(k["hbm_read_bytes_per_launch"]) + float(k["hbm_write_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(args, wl, pats, rules, text, offs, lex, gpu_value, unit):

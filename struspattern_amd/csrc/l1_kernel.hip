@@ -593,29 +593,46 @@ __device__ void lexDocuments( const L1Params& P)
 
 } // anonymous namespace
 
-#define SPA_L1_KERNEL( N, T) \
-extern "C" __global__ __launch_bounds__(T) void spa_l1_lex_kernel_p##N( L1Params P) { if (P.ldsWords) lexDocuments<N,true>( P); else lexDocuments<N,false>( P); }
-SPA_L1_KERNEL( 1, 1024)
-SPA_L1_KERNEL( 2, 1024)
-SPA_L1_KERNEL( 4, 1024)
-SPA_L1_KERNEL( 8, 1024)
-SPA_L1_KERNEL( 16, 256)
-SPA_L1_KERNEL( 32, 256)
+// One instance per pass count (the per-pass rows of a byte step live in registers, so the count is a
+// template parameter: an instance for 8 passes running a 6-pass table would spill three times as many
+// registers).  Up to 5 passes fit the 128 registers of a 1024-thread workgroup without spills; 6..8
+// spill 22..96 of them, which was measured faster than halving the waves (512-thread groups).
+#define SPA_L1_KERNEL( NAME, N, T) \
+extern "C" __global__ __launch_bounds__(T) void spa_l1_lex_kernel_##NAME( L1Params P) { if (P.ldsWords) lexDocuments<N,true>( P); else lexDocuments<N,false>( P); }
+SPA_L1_KERNEL( p1, 1, 1024)
+SPA_L1_KERNEL( p2, 2, 1024)
+SPA_L1_KERNEL( p3, 3, 1024)
+SPA_L1_KERNEL( p4, 4, 1024)
+SPA_L1_KERNEL( p5, 5, 1024)
+SPA_L1_KERNEL( p6, 6, 1024)
+SPA_L1_KERNEL( p7, 7, 1024)
+SPA_L1_KERNEL( p8, 8, 1024)
+SPA_L1_KERNEL( p16, 16, 256)
+SPA_L1_KERNEL( p32, 32, 256)
 
 namespace spa {
 hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, hipStream_t stream)
 {
 	const size_t lds = (size_t)P.ldsWords * 8;
 #define SPA_L1_LAUNCH( N) do { \
-	if (lds > 65536) { hipError_t e = hipFuncSetAttribute( (const void*)spa_l1_lex_kernel_p##N, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
-	hipLaunchKernelGGL( spa_l1_lex_kernel_p##N, dim3( nblocks), dim3( nthreads), lds, stream, P); } while (0)
-	if (P.nofPasses <= 1) SPA_L1_LAUNCH( 1);
-	else if (P.nofPasses <= 2) SPA_L1_LAUNCH( 2);
-	else if (P.nofPasses <= 4) SPA_L1_LAUNCH( 4);
-	else if (P.nofPasses <= 8) SPA_L1_LAUNCH( 8);
-	else if (P.nofPasses <= 16) SPA_L1_LAUNCH( 16);
-	else if (P.nofPasses <= 32) SPA_L1_LAUNCH( 32);
-	else return hipErrorInvalidValue;
+	if (lds > 65536) { hipError_t e = hipFuncSetAttribute( (const void*)spa_l1_lex_kernel_##N, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
+	hipLaunchKernelGGL( spa_l1_lex_kernel_##N, dim3( nblocks), dim3( nthreads), lds, stream, P); } while (0)
+	switch (P.nofPasses)
+	{
+		case 1: SPA_L1_LAUNCH( p1); break;
+		case 2: SPA_L1_LAUNCH( p2); break;
+		case 3: SPA_L1_LAUNCH( p3); break;
+		case 4: SPA_L1_LAUNCH( p4); break;
+		case 5: SPA_L1_LAUNCH( p5); break;
+		case 6: SPA_L1_LAUNCH( p6); break;
+		case 7: SPA_L1_LAUNCH( p7); break;
+		case 8: SPA_L1_LAUNCH( p8); break;
+		default:
+			if (P.nofPasses <= 16) SPA_L1_LAUNCH( p16);
+			else if (P.nofPasses <= 32) SPA_L1_LAUNCH( p32);
+			else return hipErrorInvalidValue;
+	}
 	return hipGetLastError();
 }
 }
+
