@@ -192,6 +192,8 @@ typedef const WSV& WSR;
 #define BSIZE		((lu32*)w.raw + 64)		/* 16 bucket sizes */
 #define WINDOW		((lu32*)w.raw + 80)		/* 64 expiry list lengths */
 #define WINCHUNK	((lu32*)w.raw + 144)		/* 64 x 8 chunk ids */
+#define SCRLDS		((lu32*)w.raw + 656)		/* 16 x SCRLDS_CAP: bucket partition of a deactivation batch */
+#define EXPLIST		((lu32*)w.raw + 912)		/* EXPLIST_CAP: the rules expiring at the current position */
 #define WINARR		ARENA( P.arena.oWinArr)
 #define WINFREE		ARENA( P.arena.oWinFree)
 #define SCRATCH		ARENA( P.arena.oScratch)
@@ -416,9 +418,10 @@ __device__ __forceinline__ u32 byteField( u32 c0, u32 c1, u32 c2, u32 c3, u32 h)
 // removals in their original order while the other 15 buckets advance in the other lanes.
 // Everything else (clearing the rule, releasing trigger / item / reference records) has no observable
 // order and is done one rule per lane.
-enum {DEACT_MAXCHAIN=4};
+enum {DEACT_MAXCHAIN=4, SCRLDS_CAP=16, EXPLIST_CAP=128};
 
-__device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP P, const hu32* list, u32 n, bool reversed, bool freeRules, bool checkDup)
+template <class LISTPTR>
+__device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP P, LISTPTR list, u32 n, bool reversed, bool freeRules, bool checkDup)
 {
 	const WSV w( wsBlock, wsArena);
 	for (u32 base=0; base<n && !w.err; base+=64)
@@ -509,32 +512,9 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 			return (f & 2u) ? (v >> 16) : (v & 0xFFFFu);
 		};
 		auto own = [&]( u32 h) -> u32 { return byteField( c0, c1, c2, c3, h); };
-		const u32 scap = CAP_SCRATCH;
-		u32 seen0 = 0, seen1 = 0, seen2 = 0, seen3 = 0;	// my own earlier triggers per bucket
-		u32 ntot = 0;
-#pragma unroll
-		for (int c=0; c<DEACT_MAXCHAIN; ++c)
+		// totals per bucket = inclusive values of lane 63; lane b < 16 owns bucket b
+		u32 myCount = 0;
 		{
-			if (hOf[ c] < 16u)
-			{
-				const u32 h = hOf[ c];
-				const u32 mineBefore = byteField( seen0, seen1, seen2, seen3, h);
-				const u32 rankInBucket = incl( h) - own( h) + mineBefore;
-				if (rankInBucket < scap) SCRATCH[ h*scap + rankInBucket] = t[ c]; else ARENA_FAIL;
-				u32 inc = 1u << ((h & 3u)*8), ws = h >> 2;
-				if (ws == 0) seen0 += inc; else if (ws == 1) seen1 += inc; else if (ws == 2) seen2 += inc; else seen3 += inc;
-				++ntot;
-			}
-		}
-		if (__ballot( w.err != 0)) { ARENA_FAIL; return; }
-		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
-		// lane b replays the removals of bucket b (cpp:133-152)
-		{
-			u32 myCount = 0;
-			if (LANE < 16u)
-			{
-				// totals = inclusive value of lane 63
-			}
 			const u32 tl0 = (u32)__builtin_amdgcn_readlane( lo0, 63), th0 = (u32)__builtin_amdgcn_readlane( hi0, 63);
 			const u32 tl1 = (u32)__builtin_amdgcn_readlane( lo1, 63), th1 = (u32)__builtin_amdgcn_readlane( hi1, 63);
 			const u32 tl2 = (u32)__builtin_amdgcn_readlane( lo2, 63), th2 = (u32)__builtin_amdgcn_readlane( hi2, 63);
@@ -547,6 +527,31 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 				const u32 v = (f & 1u) ? hi : lo;
 				myCount = (f & 2u) ? (v >> 16) : (v & 0xFFFFu);
 			}
+		}
+		// the partition lives in LDS when every bucket's share fits (the usual case), else in the arena
+		const bool scrInLds = !__ballot( myCount > (u32)SCRLDS_CAP);
+		const u32 scap = CAP_SCRATCH;
+		u32 seen0 = 0, seen1 = 0, seen2 = 0, seen3 = 0;	// my own earlier triggers per bucket
+		u32 ntot = 0;
+#pragma unroll
+		for (int c=0; c<DEACT_MAXCHAIN; ++c)
+		{
+			if (hOf[ c] < 16u)
+			{
+				const u32 h = hOf[ c];
+				const u32 mineBefore = byteField( seen0, seen1, seen2, seen3, h);
+				const u32 rankInBucket = incl( h) - own( h) + mineBefore;
+				if (scrInLds) SCRLDS[ h*SCRLDS_CAP + rankInBucket] = t[ c];
+				else if (rankInBucket < scap) SCRATCH[ h*scap + rankInBucket] = t[ c]; else ARENA_FAIL;
+				u32 inc = 1u << ((h & 3u)*8), ws = h >> 2;
+				if (ws == 0) seen0 += inc; else if (ws == 1) seen1 += inc; else if (ws == 2) seen2 += inc; else seen3 += inc;
+				++ntot;
+			}
+		}
+		if (__ballot( w.err != 0)) { ARENA_FAIL; return; }
+		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+		// lane b replays the removals of bucket b (cpp:133-152)
+		{
 			if (myCount)
 			{
 				const u32 b = LANE;
@@ -554,13 +559,13 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 				u32 size = BSIZE[ b];
 				for (u32 k=0; k<myCount; ++k)
 				{
-					const u32 tk = SCRATCH[ b*scap + k];
+					const u32 tk = scrInLds ? SCRLDS[ b*SCRLDS_CAP + k] : SCRATCH[ b*scap + k];
+					const u32 last = size-1;
+					const uint2 moved = bk[ last];			// independent of the link: both loads in flight together
 					const u32 link = TRIG( tk)->link;
 					const u32 pos = link & 0x0FFFFFFFu;
-					const u32 last = size-1;
 					if (pos != last)
 					{
-						const uint2 moved = bk[ last];
 						bk[ pos] = moved;
 						TRIG( moved.y)->link = link;
 					}
@@ -695,11 +700,19 @@ __device__ __forceinline__ void winAppendOne( WSR w, KP P, u32 slot, u32 r)
 	WINARR[ winEntryIndex( w, P, slot, cnt)] = r;
 	WINDOW[ slot] = cnt+1;
 }
-// copy the list of `slot` to DISPOSE[0..cnt) (free while no transition is running) and release its chunks
+// copy the list of `slot` to EXPLIST (LDS) or, when it is longer, to DISPOSE[0..cnt) (free while no
+// transition is running) and release its chunks
 __device__ __forceinline__ void winTake( WSR w, KP P, u32 slot, u32 cnt)
 {
-	if (cnt > CAP_DISPOSE) { ARENA_FAIL; return; }
-	for (u32 i=LANE; i<cnt; i+=64) DISPOSE[ i] = WINARR[ winEntryIndex( w, P, slot, i)];
+	if (cnt <= (u32)EXPLIST_CAP)
+	{
+		for (u32 i=LANE; i<cnt; i+=64) EXPLIST[ i] = WINARR[ winEntryIndex( w, P, slot, i)];
+	}
+	else
+	{
+		if (cnt > CAP_DISPOSE) { ARENA_FAIL; return; }
+		for (u32 i=LANE; i<cnt; i+=64) DISPOSE[ i] = WINARR[ winEntryIndex( w, P, slot, i)];
+	}
 	const u32 C = WIN_CHUNK, nc = (cnt + C-1) / C;
 	if (LANE < nc) WINFREE[ w.winFreeN + LANE] = WINCHUNK[ slot*8 + LANE];
 	w.winFreeN += nc;
@@ -743,7 +756,8 @@ __device__ __forceinline__ void setCurrentPos( WSR w, KP P, u32 pos)	// cpp:1084
 			// the rules of this position, last defined first (the reference's LIFO list order)
 			winTake( w, P, widx, cnt);
 			if (w.err) return;
-			deactivateBatch( w.raw, w.arena, P, DISPOSE, cnt, true/*reversed*/, true/*free the rules*/, false);
+			if (cnt <= (u32)EXPLIST_CAP) deactivateBatch( w.raw, w.arena, P, EXPLIST, cnt, true/*reversed*/, true/*free the rules*/, false);
+			else deactivateBatch( w.raw, w.arena, P, DISPOSE, cnt, true/*reversed*/, true/*free the rules*/, false);
 		}
 	}
 	if (w.curpos < pos)
@@ -1548,7 +1562,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S
 void spa_l2_match_kernel( L2Params kernelArgs)
 {
 	KP P = kernelParams();
-	__shared__ __attribute__((aligned(16))) u32 ldsSlice[ 64 + 16 + 64 + 512];
+	__shared__ __attribute__((aligned(16))) u32 ldsSlice[ 64 + 16 + 64 + 512 + 16*SCRLDS_CAP + EXPLIST_CAP];
 	const WSV w( (HWS*)ldsSlice, P.arenaBase + (u64)blockIdx.x * P.arena.totalWords);
 	const u32 ndocs = P.ndocs;
 	const u32 waveSlot = blockIdx.x;
