@@ -439,6 +439,9 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 			act = (flags & F_ACTIVE) != 0;
 			if (act) { const uint4 q2 = ld4( W( R) + 8); mask = q2.x; ref = q2.y; ext = q2.z; }	// {trigMask, dataRef, ext, owner}
 		}
+		// the data reference of my rule {list head, count}: requested now, used after the trigger work
+		uint2 refRec = make_uint2( 0, 0);
+		if (P.withItems && act && ref) refRec = *(const uint2*)&REFS[ 2*(ref-1)];
 		if (checkDup)
 		{
 			// the same rule may be listed twice (deleted and finished in one step): only its first entry acts
@@ -581,14 +584,18 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 		{
 			bool bad = false;
 			u32 nfree = 0; bool freeRef = false;
+			u32 itq[ 4] = {0,0,0,0};		// the first items of my list (usually all of them)
 			if (act && ref)
 			{
-				u32 cnt = REFS[ 2*(ref-1)+1];
+				const u32 cnt = refRec.y;
 				if (cnt > 1) REFS[ 2*(ref-1)+1] = cnt-1;
 				else if (cnt == 1)
 				{
 					freeRef = true;
-					for (u32 it=REFS[ 2*(ref-1)], g=0; it; it=ITEMS[ it-1].next, ++g) { ++nfree; if (g > w.itemUsed) { bad = true; break; } }
+					u32 it = refRec.x;
+#pragma unroll
+					for (int q=0; q<4; ++q) { if (it) { itq[ q] = it; it = ITEMS[ it-1].next; ++nfree; } }
+					for (u32 g=0; it; it=ITEMS[ it-1].next, ++g) { ++nfree; if (g > w.itemUsed) { bad = true; break; } }
 					REFS[ 2*(ref-1)+1] = 0;
 				}
 				else bad = true;
@@ -600,7 +607,9 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 			if (freeRef)
 			{
 				u32 at = w.itemFreeN + incI - nfree;
-				for (u32 it=REFS[ 2*(ref-1)]; it; ) { u32 nx = ITEMS[ it-1].next; ITEMFREE[ at++] = it-1; it = nx; }
+#pragma unroll
+				for (int q=0; q<4; ++q) if (itq[ q]) ITEMFREE[ at++] = itq[ q]-1;
+				if (nfree > 4) for (u32 it=ITEMS[ itq[ 3]-1].next; it; ) { u32 nx = ITEMS[ it-1].next; ITEMFREE[ at++] = it-1; it = nx; }
 			}
 			const u64 fm = __ballot( freeRef);
 			if (freeRef) REFFREE[ w.refFreeN + (u32)__popcll( fm & lanesBelow())] = ref-1;
