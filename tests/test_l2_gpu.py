@@ -116,6 +116,61 @@ def test_origseg_and_position_gaps():
     _compare(gpu, ref, ndocs)
 
 
+def _apply_wide_rules(m, rules, nested):
+    """rules with many terms: more than 4 installed triggers per rule instance (continuation blocks of
+    the kernel's rule records) and more than 3 trigger templates (sequential install path)."""
+    for name, op, rg, card, params in rules:
+        n = len(params)
+        if op in ("sequence_struct", "within_struct"):
+            m.pushTerm(synth.DELIM)
+            n += 1
+        for pi, t in enumerate(params):
+            m.pushTerm(t)
+            if pi % 2 == 0:
+                m.attachVariable("V%d" % pi)
+        m.pushExpression(op, n, rg, card)
+        m.definePattern(name, "", True)
+    for name, inner, t in nested:
+        # a pattern reference inside a wide expression: follow events + joined item lists
+        m.pushPattern(inner)
+        m.attachVariable("sub")
+        m.pushTerm(t)
+        m.pushExpression("sequence", 2, 12, 0)
+        m.definePattern(name, "", True)
+    m.compile()
+
+
+@pytest.mark.parametrize("seed", [51, 52])
+def test_rules_with_many_triggers(seed):
+    rng = np.random.default_rng(seed)
+    nfeat = 9
+    ops = ["sequence", "within", "any", "sequence_struct", "within_struct", "and"]
+    rules = []
+    for ni in range(160):
+        op = ops[ni % len(ops)]
+        nterms = int(rng.integers(5, 10))
+        params = [int(x) for x in rng.integers(1, nfeat + 1, size=nterms)]
+        rg = int(rng.integers(6, 40))
+        card = 0
+        if op in ("any", "and") and rng.random() < 0.5:
+            card = int(rng.integers(2, 4))
+        rules.append(("w%s_%d" % (op, ni), op, rg, card, params))
+    nested = [("n_%d" % i, rules[i][0], int(rng.integers(1, nfeat + 1))) for i in range(0, 40, 3)]
+    ndocs, n = 24, 300
+    lex = np.zeros((ndocs * n, 4), np.uint32)
+    offs = np.arange(ndocs + 1, dtype=np.uint64) * n
+    for d in range(ndocs):
+        ids = rng.integers(1, nfeat + 1, size=n)
+        ids[rng.random(n) < 0.04] = synth.DELIM
+        lex[d * n:(d + 1) * n, 0] = ids
+        lex[d * n:(d + 1) * n, 1] = np.cumsum(rng.choice([1, 1, 1, 2], size=n))
+        lex[d * n:(d + 1) * n, 2] = np.arange(n) * 4
+        lex[d * n:(d + 1) * n, 3] = 3
+    gpu, ref, m, o = _run_both(lambda x: _apply_wide_rules(x, rules, nested), lex, offs)
+    assert len(ref.results) > 100
+    _compare(gpu, ref, ndocs)
+
+
 def test_not_ascending_positions_is_an_error():
     m = spa.PatternMatcherInstance()
     m.pushTerm(1)
