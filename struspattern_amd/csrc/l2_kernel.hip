@@ -435,13 +435,14 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 		u32 r = 0;
 		if (have) r = reversed ? list[ n - 1 - (base + LANE)] : list[ base + LANE];
 		bool act = false;
-		u32 mask = 0, ref = 0, ext = 0;
+		u32 mask = 0, ref = 0, ext = 0, flags = 0;
 		if (have)
 		{
 			HRule* R = &RULES[ r];
-			u32 flags = R->flags;
+			flags = R->flags;
+			const uint4 q2 = ld4( W( R) + 8);	// {trigMask, dataRef, ext, owner}: same line, requested together with the flags
 			act = (flags & F_ACTIVE) != 0;
-			if (act) { const uint4 q2 = ld4( W( R) + 8); mask = q2.x; ref = q2.y; ext = q2.z; }	// {trigMask, dataRef, ext, owner}
+			if (act) { mask = q2.x; ref = q2.y; ext = q2.z; }
 		}
 		// the data reference of my rule {list head, count}: requested now, used after the trigger work
 		uint2 refRec = make_uint2( 0, 0);
@@ -456,10 +457,11 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 			}
 			// ... and entries of earlier 64-blocks have already cleared F_ACTIVE in memory
 		}
-		if (act)
+		if (act && !freeRules)		// (a block that is released below is dead: nothing reads it before its next installation rewrites it)
 		{
 			HRule* R = &RULES[ r];
-			R->flags = R->flags & ~F_ACTIVE; R->trigMask = 0; R->dataRef = 0;
+			R->flags = flags & ~F_ACTIVE;
+			*(uint2*)&R->trigMask = make_uint2( 0, 0);	// trigMask, dataRef
 		}
 		// my triggers, last installed first: the occupied slots of my block from the top
 		u32 t[ DEACT_MAXCHAIN]; u32 nt = 0;
@@ -476,7 +478,7 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 		if (__ballot( longChain))
 		{
 			// rare: finish this block one rule at a time (flags were cleared above: restore, then serial)
-			if (act) { HRule* R = &RULES[ r]; R->flags = R->flags | F_ACTIVE; R->trigMask = mask; R->dataRef = ref; }
+			if (act && !freeRules) { HRule* R = &RULES[ r]; R->flags = flags; R->trigMask = mask; R->dataRef = ref; }
 			__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 			for (u32 k=0; k<nb && !w.err; ++k)
 			{
