@@ -197,7 +197,7 @@ typedef const WSV& WSR;
 #define WINDOW		((lu32*)w.raw + 80)		/* 64 expiry list lengths */
 #define WINCHUNK	((lu32*)w.raw + 144)		/* 64 x 8 chunk ids */
 #define SCRLDS		((lu32*)w.raw + 656)		/* 16 x SCRLDS_CAP: bucket partition of a deactivation batch */
-#define EXPLIST		((lu32*)w.raw + 912)		/* EXPLIST_CAP: the rules expiring at the current position */
+#define EXPLIST		((lu32*)w.raw + 1168)		/* EXPLIST_CAP: the rules expiring at the current position */
 #define WINARR		ARENA( P.arena.oWinArr)
 #define WINFREE		ARENA( P.arena.oWinFree)
 #define SCRATCH		ARENA( P.arena.oScratch)
@@ -422,7 +422,7 @@ __device__ __forceinline__ u32 byteField( u32 c0, u32 c1, u32 c2, u32 c3, u32 h)
 // removals in their original order while the other 15 buckets advance in the other lanes.
 // Everything else (clearing the rule, releasing trigger / item / reference records) has no observable
 // order and is done one rule per lane.
-enum {DEACT_MAXCHAIN=4, SCRLDS_CAP=16, EXPLIST_CAP=128};
+enum {DEACT_MAXCHAIN=4, SCRLDS_CAP=32, EXPLIST_CAP=128, REPLAY_MAX=8};
 
 template <class LISTPTR>
 __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP P, LISTPTR list, u32 n, bool reversed, bool freeRules, bool checkDup)
@@ -430,6 +430,7 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 	const WSV w( wsBlock, wsArena);
 	for (u32 base=0; base<n && !w.err; base+=64)
 	{
+		P2_DECL;
 		const u32 nb = (n - base) < 64u ? (n - base) : 64u;
 		const bool have = LANE < nb;
 		u32 r = 0;
@@ -492,6 +493,8 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 		u32 hOf[ DEACT_MAXCHAIN];
 #pragma unroll
 		for (int c=0; c<DEACT_MAXCHAIN; ++c) hOf[ c] = ((u32)c < nt) ? (TRIG( t[ c])->link >> 28) : 16u;
+		if (__ballot( hOf[ 0] == 77u)) return;	// (forces the loads above to complete here when timing)
+		P2_ADD( 0);
 		u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
 		for (int c=0; c<DEACT_MAXCHAIN; ++c)
@@ -559,30 +562,76 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 		}
 		if (__ballot( w.err != 0)) { ARENA_FAIL; return; }
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
-		// lane b replays the removals of bucket b (cpp:133-152)
+		P2_ADD( 1);
+		// lane b replays the removals of bucket b (cpp:133-152): each removal moves the bucket's current
+		// last entry into the hole.  Only the last m entries can ever move, so for m <= REPLAY_MAX the lane
+		// fetches them and the m links once (all loads in flight together) and plays the sequence in
+		// registers: no memory round trip per removal.  Entries that end up below the new size are
+		// stored (with the link of the moved trigger); everything at or above it is dead.
 		{
 			if (myCount)
 			{
 				const u32 b = LANE;
 				uint2* bk = (uint2*)BKT + b*CAP_BUCKET;		// {event, trigger id}
-				u32 size = BSIZE[ b];
-				for (u32 k=0; k<myCount; ++k)
+				u32 n = BSIZE[ b];
+				for (u32 done=0; done<myCount; done+=REPLAY_MAX)	// REPLAY_MAX removals per round of loads
 				{
-					const u32 tk = scrInLds ? SCRLDS[ b*SCRLDS_CAP + k] : SCRATCH[ b*scap + k];
-					const u32 last = size-1;
-					const uint2 moved = bk[ last];			// independent of the link: both loads in flight together
-					const u32 link = TRIG( tk)->link;
-					const u32 pos = link & 0x0FFFFFFFu;
-					if (pos != last)
+					const u32 m = (myCount - done) < (u32)REPLAY_MAX ? (myCount - done) : (u32)REPLAY_MAX;
+					u32 tk[ REPLAY_MAX], lk[ REPLAY_MAX], ce[ REPLAY_MAX], ct[ REPLAY_MAX], mt[ REPLAY_MAX], mp[ REPLAY_MAX];
+#pragma unroll
+					for (int k=0; k<REPLAY_MAX; ++k)
 					{
-						bk[ pos] = moved;
-						TRIG( moved.y)->link = link;
+						tk[ k] = 0xFFFFFFFFu;
+						if ((u32)k < m) tk[ k] = scrInLds ? SCRLDS[ b*SCRLDS_CAP + done + k] : SCRATCH[ b*scap + done + k];
 					}
-					size = last;
+#pragma unroll
+					for (int k=0; k<REPLAY_MAX; ++k)
+					{
+						lk[ k] = 0; ce[ k] = 0; ct[ k] = 0xFFFFFFFEu; mt[ k] = 0xFFFFFFFDu; mp[ k] = 0;
+						if ((u32)k < m)
+						{
+							lk[ k] = TRIG( tk[ k])->link & 0x0FFFFFFFu;
+							const uint2 e = bk[ n-1-(u32)k];	// the entry at position n-1-k
+							ce[ k] = e.x; ct[ k] = e.y;
+						}
+					}
+#pragma unroll
+					for (int k=0; k<REPLAY_MAX; ++k)
+					{
+						if ((u32)k < m)
+						{
+							// where is trigger tk[k] now?  its stored link, unless this round has moved it
+							u32 pos = lk[ k];
+#pragma unroll
+							for (int i=0; i<k; ++i) if (mt[ i] == tk[ k]) pos = mp[ i];			// moved below the tail
+#pragma unroll
+							for (int j=k; j<REPLAY_MAX; ++j) if (ct[ j] == tk[ k]) pos = n-1-(u32)j;	// sits in the tail
+							const u32 last = n-1-(u32)k;
+							if (pos != last)
+							{
+								const u32 me = ce[ k], mi = ct[ k];		// the entry at `last` moves into the hole
+								if (pos >= n-m)
+								{
+									const u32 jj = n-1-pos;			// a hole inside the tail: stays in registers
+#pragma unroll
+									for (int j=k+1; j<REPLAY_MAX; ++j) if ((u32)j == jj) { ce[ j] = me; ct[ j] = mi; }
+								}
+								else
+								{
+									bk[ pos] = make_uint2( me, mi);
+									TRIG( mi)->link = (b << 28) | pos;
+									mt[ k] = mi; mp[ k] = pos;
+								}
+							}
+						}
+					}
+					n -= m;
 				}
-				BSIZE[ b] = size;
+				BSIZE[ b] = n;
 			}
 		}
+		if (__ballot( BSIZE[ LANE & 15u] == 0x7FFFFFFFu)) return;
+		P2_ADD( 3);
 		// the trigger slots go with their rule blocks: only the count of installed triggers changes
 		w.nTrig -= (u32)__popcll( __ballot( ntot & 1u)) + 2u*(u32)__popcll( __ballot( ntot & 2u)) + 4u*(u32)__popcll( __ballot( ntot & 4u));
 		// release the data references (cpp:696-700 -> :710-732): one rule per lane
@@ -622,6 +671,7 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 			w.itemFreeN += totalI;
 			w.refFreeN += (u32)__popcll( fm);
 		}
+		P2_ADD( 2);
 		if (freeRules)
 		{
 			if (have) RULEFREE[ w.ruleFreeN + LANE] = r;
@@ -1256,9 +1306,6 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 		const bool slowLane = live && (odd || expiry >= w.curpos + 64u || g_tc > (u32)MAXT);
 		const bool liveAll = live;
 		const u64 slowMask = __ballot( slowLane);
-		P2C( 0, __popcll( __ballot( live && odd)));
-		P2C( 1, __popcll( __ballot( live && expiry >= w.curpos + 64u)));
-		P2C( 3, __popcll( __ballot( live && g_tc > (u32)MAXT)));
 		// the batch is cut into runs of ordinary programs (handled by all lanes at once) separated by
 		// the rare programs that take the sequential path; runs and singles are processed in list order
 		for (u32 segStart=0; segStart<nb && !w.err; )
@@ -1267,7 +1314,6 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 		const u32 cut = slowAhead ? (u32)__builtin_ctzll( slowAhead) : nb;
 		if (cut == segStart)
 		{
-			P2C( 2, 1);
 			installProgram( w, P, keyevent, &P.keylist[ lb+base+cut], d);
 			segStart = cut+1;
 			continue;
