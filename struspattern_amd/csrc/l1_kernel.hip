@@ -318,7 +318,8 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 #pragma unroll
 	for (int p=0; p<PASSES; ++p) state[ p] = 0;
 	const u32 len = w.docLen;
-	const u32 nofPasses = uni( P.nofPasses);
+	// instances for 1..8 passes run tables of exactly that many passes; the 16 / 32 instances run anything up to it
+	const u32 nofPasses = (PASSES <= 8) ? (u32)PASSES : uni( P.nofPasses);
 	const u32 drainAt = P.queueCap > P.nofPatterns + 64 ? P.queueCap - P.nofPatterns - 64 : 0;
 	int prevctx = CTX_EDGE;
 	bool inWord = false; u32 runStart = 0, runHash = 0;		// token hash of the current run of word characters
@@ -335,7 +336,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 #pragma unroll
 	for (int p=0; p<PASSES; ++p)
 	{
-		const bool on = (u32)p < P.nofPasses;
+		const bool on = (u32)p < nofPasses;
 		shiftDst[ p] = on ? T.at( T.oShift + p*64 + LANE) : 0; selfLoop[ p] = on ? T.at( T.oSelf + p*64 + LANE) : 0;
 		nExOf[ p] = on ? uni( P.exCount[ p]) : 0;
 	}
@@ -359,7 +360,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 #pragma unroll
 			for (int p=0; p<PASSES; ++p)
 			{
-				// the kernel is instantiated for 1,2,4,8,.. passes: the tables end at nofPasses
+				// the tables end at nofPasses
 				accRow[ p] = 0; cmRow[ p] = 0; stRow[ p] = 0;
 				if ((u32)p < nofPasses)
 				{
