@@ -89,7 +89,9 @@ def main():
     nbytes = 0
     if wl in ("pipeline", "lexer"):
         nreg = args.regexes or (10000 if wl == "pipeline" else 256)
-        ndocs = args.docs or (4096 if wl == "pipeline" else 8192)
+        # documents per step: a multiple of the resident waves of both kernels (4096 lexer / 3072 automaton
+        # wave slots on 256 CUs), so that the static one-wave-per-document assignment runs full rounds
+        ndocs = args.docs or (12288 if wl == "pipeline" else 8192)
         vocab = synth.vocabulary(30000, 1)
         if wl == "pipeline":
             pats, rules = synth.pipeline_workload(nreg, args.rules, vocab, seed=4)
