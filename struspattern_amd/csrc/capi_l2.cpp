@@ -327,12 +327,8 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 {
 	HIP_CHECK( hipSetDevice( c->device));
 	// geometry: one wave per workgroup; as many as keep every CU busy, never more waves than documents
-	// documents are dealt round-robin: use the smallest number of waves that needs the same number of
-	// rounds (4096 documents on 3072 wave slots take two rounds either way; 2048 waves run them with
-	// less memory contention)
 	size_t waveSlots = (size_t)c->numCUs*SPA_L2_WAVES_PER_CU;
-	size_t rounds = ndocs ? (ndocs + waveSlots-1) / waveSlots : 1;
-	unsigned wavesWanted = (unsigned)(ndocs ? (ndocs + rounds-1) / rounds : 1);
+	unsigned wavesWanted = (unsigned)(ndocs < waveSlots ? ndocs : waveSlots);
 	unsigned nblocks = wavesWanted;		// workgroups are single waves
 	if (nblocks == 0) nblocks = 1;
 	unsigned nwaves = nblocks;

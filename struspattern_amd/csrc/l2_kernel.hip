@@ -6,7 +6,7 @@
 //
 // Execution model: a document is inherently sequential (every event mutates the rule state the
 // next event sees), so the unit of parallelism is the document: each 64-lane wavefront (= one
-// workgroup) owns one document at a time; documents are dealt round-robin to the launched waves.
+// workgroup) owns one document at a time and fetches the next from a device-side cursor when done.
 // Inside a document the control flow is wave-uniform (all lanes follow the same path on the same
 // values, so branches are scalar and table/state reads are single-address broadcasts); the lanes are
 // data-parallel workers where the algorithm has width: scanning a trigger bucket for an event id (the
@@ -1629,10 +1629,19 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 	const u32 waveSlot = blockIdx.x;
 	const u32 nWaveSlots = gridDim.x;
 
-	// documents are dealt round-robin to the resident waves (document d -> wave d mod nwaves)
-	for (u32 di=waveSlot; di<ndocs; di+=nWaveSlots)
+	// every wave starts with document `waveSlot` and takes its next ones from a device-side cursor
+	// (documents are long sequential jobs of very different length in real corpora); the loop is
+	// bounded so that it ends whatever the cursor holds
+	for (u32 round=0; round<=ndocs; ++round)
 	{
-		const u32 doc = di;
+		u32 doc = waveSlot;
+		if (round)
+		{
+			u32 nx = 0;
+			if (LANE == 0) nx = atomicAdd( P.docCursor, 1u);
+			doc = nWaveSlots + bcast0( nx);
+		}
+		if (doc >= ndocs) break;
 		TRACE( 1, doc);
 		// per-document reset (lane-parallel)
 		if (LANE < 16) BSIZE[ LANE] = 0;
