@@ -179,7 +179,7 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 			}
 			else { c->ldsWords = 0; c->blockThreads = 256; }
 		}
-		c->dCounters.alloc( L1C_COUNT*sizeof(uint64_t));
+		c->dCounters.alloc( L1C_ALLOC*sizeof(uint64_t));
 		uint32_t npat = (uint32_t)T.patterns.size();
 		c->queueCap = 4096 > 2*npat+256 ? 4096 : 2*npat+256;
 		HIP_CHECK( hipEventCreate( &c->evStart));
@@ -247,7 +247,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	if (c->lexemCapacity < want) { c->dLexems.alloc( want*sizeof(sp_lexem_t)); c->lexemCapacity = want; }
 	c->dDocRange.reserve( (ndocs+1)*2*sizeof(uint64_t));
 	c->dDocStatus.reserve( (ndocs+1)*sizeof(int32_t));
-	HIP_CHECK( hipMemsetAsync( c->dCounters.ptr, 0, L1C_COUNT*sizeof(uint64_t), stream));
+	HIP_CHECK( hipMemsetAsync( c->dCounters.ptr, 0, L1C_ALLOC*sizeof(uint64_t), stream));
 
 	L1Params P;
 	std::memset( &P, 0, sizeof(P));

@@ -6,7 +6,7 @@
 
 namespace spa {
 
-enum {L1C_LEXEMS=0, L1C_BYTES=1, L1C_RAW=2, L1C_FAILED=3, L1C_COUNT=8};
+enum {L1C_LEXEMS=0, L1C_BYTES=1, L1C_RAW=2, L1C_FAILED=3, L1C_COUNT=8, L1C_CURSOR=8 /*document cursor, behind the counters*/, L1C_ALLOC=9};
 
 struct L1Params
 {

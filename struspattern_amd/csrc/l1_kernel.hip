@@ -567,8 +567,18 @@ __device__ void lexDocuments( const L1Params& P)
 	LexWave w;
 	w.queue = A;
 	w.events = (Event*)(A + 4*(u64)P.queueCap);
-	for (u32 doc=waveSlot; doc<P.ndocs; doc+=nWaveSlots)
+	// every wave starts with document `waveSlot` and takes its next ones from a device-side cursor;
+	// the loop is bounded so that it ends whatever the cursor holds
+	for (u32 round=0; round<=P.ndocs; ++round)
 	{
+		u32 doc = waveSlot;
+		if (round)
+		{
+			u32 nx = 0;
+			if (LANE == 0) nx = atomicAdd( (u32*)&P.counters[ L1C_CURSOR], 1u);
+			doc = nWaveSlots + uni( nx);
+		}
+		if (doc >= P.ndocs) break;
 		const u64 beg = ((u64)ldu( (const u32*)&P.docOffsets[ doc]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc]);
 		const u64 end = ((u64)ldu( (const u32*)&P.docOffsets[ doc+1]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc+1]);
 		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
