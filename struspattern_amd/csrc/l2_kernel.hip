@@ -1550,12 +1550,23 @@ __device__ __forceinline__ void doTransition( HWS* wsBlock, u32* wsArena, KP P, 
 		PROF_ADD( 0);
 		// install the programs keyed by this event
 		TRACE2( 9, 1);
-		const DevKeyEntry* e = lookupKey( P, ev);
+		uint4 eq = make_uint4( 0, 0, 0, 0);			// {event, listBegin, listCount, stopIdx}
+		bool e = false;
+		if (ev)
+		{
+			u32 slot = keyHash( ev) & P.keymask;
+			for (u32 probes=0; probes<=P.keymask; ++probes)
+			{
+				eq = ldu4( &P.keytab[ slot]);		// the whole entry with the probe
+				if (eq.x == ev) { e = true; break; }
+				if (eq.x == 0) break;
+				slot = (slot+1) & P.keymask;
+			}
+		}
 		TRACE2( 9, 2);
 		u32 stopIdx = 0;
 		if (e)
 		{
-			const uint4 eq = ldu4( e);				// {event, listBegin, listCount, stopIdx}
 			stopIdx = eq.w;
 			u32 lb = eq.y, lc = eq.z;
 			TRACE2( 10, lc);
