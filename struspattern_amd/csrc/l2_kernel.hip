@@ -1627,6 +1627,43 @@ __device__ __forceinline__ u32 walkItems( WSR w, KP P, u32 ref, u32* out)
 	return n;
 }
 
+// the same walk done by one lane for its own result (independent loads per lane); sub-lists nest
+// rarely and shallowly: a lane that would need more than 4 levels reports `deep` and the document's
+// items are written by the sequential walk instead
+__device__ __forceinline__ u32 walkItemsLane( WSR w, KP P, u32 ref, u32* out, bool& deep)
+{
+	u32 n = 0, sp = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+	u32 cur = REFS[ 2*(ref-1)];
+	for (u32 guard=0;; ++guard)
+	{
+		if (guard > (1u<<22)) { deep = true; break; }
+		if (!cur)
+		{
+			if (!sp) break;
+			--sp;
+			cur = sp == 0 ? s0 : sp == 1 ? s1 : sp == 2 ? s2 : s3;
+			continue;
+		}
+		const Item* I = &ITEMS[ cur-1];
+		const uint4 a = ld4( I), b = ld4( W( I) + 4), c = ld4( W( I) + 8);	// {variable,next,-,-} {sseg,eseg,spos,epos} {sord,eord,sub,fmt}
+		if (out)
+		{
+			u32* o = out + (u64)n*7;
+			o[0] = a.x; o[1] = c.x; o[2] = c.y; o[3] = b.x; o[4] = b.z; o[5] = b.y; o[6] = b.w;
+		}
+		++n;
+		cur = a.y;
+		if (c.z && !c.w)
+		{
+			if (sp >= 4) { deep = true; break; }
+			if (sp == 0) s0 = cur; else if (sp == 1) s1 = cur; else if (sp == 2) s2 = cur; else s3 = cur;
+			++sp;
+			cur = REFS[ 2*(c.z-1)];
+		}
+	}
+	return n;
+}
+
 } // anonymous namespace
 
 // ================================================================== kernel
@@ -1709,27 +1746,10 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 			}
 		}
 
-		// fetchResults: items first (one reservation per document), then the results themselves
+		// fetchResults: the results are reserved first (their records double as the place where the item
+		// counts wait), then the items (one reservation per document)
 		TRACE2( 12, w.nStaged); TRACE2( 13, w.err);
 		u32 nres = w.err ? 0 : w.nStaged;
-		u64 itemBase = 0;
-		if (P.withItems && nres)
-		{
-			u32 total = 0;
-			for (u32 ri=0; ri<nres && !w.err; ++ri)
-			{
-				u32 ref = ldu( &STAGED[ ri].dataRef);
-				if (ref) total += walkItems( w, P, ref, 0);
-			}
-			if (w.err) nres = 0;
-			else if (total)
-			{
-				u64 b = 0;
-				if (LANE == 0) b = atomicAdd( (unsigned long long*)&P.counters[ SPC_ITEMS], (unsigned long long)total);
-				itemBase = ((u64)bcast0( (u32)(b >> 32)) << 32) | bcast0( (u32)b);
-				if (itemBase + total > P.itemCapacity) { w.err = SPD_ERR_OUTPUT; nres = 0; }
-			}
-		}
 		u64 resBase = 0;
 		if (nres)
 		{
@@ -1738,12 +1758,48 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 			resBase = ((u64)bcast0( (u32)(b >> 32)) << 32) | bcast0( (u32)b);
 			if (resBase + nres > P.resultCapacity) { w.err = SPD_ERR_OUTPUT; nres = 0; }
 		}
-		if (nres)
+		if (P.withItems && nres)
 		{
-			u64 ip = itemBase;
-			if (P.withItems)
+			// pass 1: every lane walks the item list of its own result and counts
+			u32 total = 0;
+			bool sequential = false;
+			for (u32 base=0; base<nres; base+=64)
 			{
-				// item lists are pointer chains: walked serially, result records patched with (begin,count)
+				const u32 ri = base + LANE;
+				u32 n = 0; bool deep = false;
+				if (ri < nres)
+				{
+					const u32 ref = STAGED[ ri].dataRef;
+					if (ref) n = walkItemsLane( w, P, ref, 0, deep);
+					P.results[ (resBase + ri)*9 + 8] = n;
+				}
+				if (__ballot( deep)) { sequential = true; break; }
+				u32 incl = n;
+				for (int dd=1; dd<64; dd<<=1) { u32 up = __shfl_up( incl, dd); if ((int)LANE >= dd) incl += up; }
+				total += (u32)__builtin_amdgcn_readlane( incl, 63);
+			}
+			if (sequential)
+			{
+				total = 0;
+				for (u32 ri=0; ri<nres && !w.err; ++ri)
+				{
+					u32 ref = ldu( &STAGED[ ri].dataRef);
+					if (ref) total += walkItems( w, P, ref, 0);
+				}
+			}
+			u64 itemBase = 0;
+			if (w.err) nres = 0;
+			else if (total)
+			{
+				u64 b = 0;
+				if (LANE == 0) b = atomicAdd( (unsigned long long*)&P.counters[ SPC_ITEMS], (unsigned long long)total);
+				itemBase = ((u64)bcast0( (u32)(b >> 32)) << 32) | bcast0( (u32)b);
+				if (itemBase + total > P.itemCapacity) { w.err = SPD_ERR_OUTPUT; nres = 0; }
+			}
+			if (nres && sequential)
+			{
+				// deeply nested item lists: walked one result after the other
+				u64 ip = itemBase;
 				for (u32 ri=0; ri<nres; ++ri)
 				{
 					u32 ref = ldu( &STAGED[ ri].dataRef);
@@ -1753,6 +1809,31 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 					ip += n;
 				}
 			}
+			else if (nres)
+			{
+				// pass 2: positions by prefix sum of the counts, every lane copies its own list
+				u64 ip = itemBase;
+				for (u32 base=0; base<nres; base+=64)
+				{
+					const u32 ri = base + LANE;
+					u32 n = 0;
+					if (ri < nres) n = P.results[ (resBase + ri)*9 + 8];
+					u32 incl = n;
+					for (int dd=1; dd<64; dd<<=1) { u32 up = __shfl_up( incl, dd); if ((int)LANE >= dd) incl += up; }
+					if (ri < nres)
+					{
+						const u64 mine = ip + (incl - n);
+						P.results[ (resBase + ri)*9 + 7] = (u32)mine;
+						const u32 ref = STAGED[ ri].dataRef;
+						bool deep = false;
+						if (ref) (void)walkItemsLane( w, P, ref, P.items + mine*7, deep);
+					}
+					ip += (u32)__builtin_amdgcn_readlane( incl, 63);
+				}
+			}
+		}
+		if (nres)
+		{
 			// the 7-tuples: one result per lane, 36-byte records
 			for (u32 ri=LANE; ri<nres; ri+=64)
 			{
