@@ -36,6 +36,12 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #define LANE ((u32)(threadIdx.x & 63u))
+#ifndef SPA_L2_BATCH_MIN
+#define SPA_L2_BATCH_MIN 1	/* key lists of at least this many programs are installed lane-parallel */
+#endif
+#ifndef SPA_L2_DEACT_MIN
+#define SPA_L2_DEACT_MIN 2	/* dispose lists of at least this many rules are deactivated lane-parallel */
+#endif
 #ifndef SPA_L2_WAVES_PER_EU
 #define SPA_L2_WAVES_PER_EU 3
 #endif
@@ -1570,13 +1576,13 @@ __device__ __forceinline__ void doTransition( HWS* wsBlock, u32* wsArena, KP P, 
 			stopIdx = eq.w;
 			u32 lb = eq.y, lc = eq.z;
 			TRACE2( 10, lc);
-			if (lc >= 4 && !(P.withItems && d.sub)) installBatch( w, P, ev, lb, lc, d);
+			if (lc >= SPA_L2_BATCH_MIN && !(P.withItems && d.sub)) installBatch( w, P, ev, lb, lc, d);
 			else for (u32 k=0; k<lc && !w.err; ++k) { TRACE2( 11, k); installProgram( w, P, ev, &P.keylist[ lb+k], d); }
 		}
 		TRACE2( 9, 3);
 		PROF_ADD( 1);
 		// deactivate rules that finished or were deleted
-		if (w.nDispose >= 3) deactivateBatch( w.raw, w.arena, P, DISPOSE, w.nDispose, false, false, true);
+		if (w.nDispose >= SPA_L2_DEACT_MIN) deactivateBatch( w.raw, w.arena, P, DISPOSE, w.nDispose, false, false, true);
 		else for (u32 di=0; di<w.nDispose; ++di) deactivateRule( w, P, ldu( &DISPOSE[ di]));
 		PROF_ADD( 2);
 
