@@ -483,64 +483,96 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 }
 
 // ---------------------------------------------------------------- stage 4: ordinal positions + output (:893-945)
+// The reference walks the sorted event array once with a little state machine (patternLexer.cpp:893-945):
+// up to the first content/unique event only successor-bound events are kept (position 1); from there on
+// the ordinal position advances whenever a content/unique event starts to the right of all earlier
+// ones, a unique event directly after a unique event is dropped, successor-bound events get position+1.
+// Every piece of that state is a prefix quantity, so 64 events are handled per step: one coalesced
+// load, a max-scan (start of the rightmost counted event so far), two sum-scans (ordinal position,
+// output index), one coalesced store.  Pass A counts (the output is reserved once per document),
+// pass B writes.
+__device__ __forceinline__ u32 scanAdd( u32 v)
+{
+	for (int d=1; d<64; d<<=1) { u32 up = __shfl_up( v, d); if ((int)LANE >= d) v += up; }
+	return v;
+}
+__device__ __forceinline__ u32 scanMax( u32 v)
+{
+	for (int d=1; d<64; d<<=1) { u32 up = __shfl_up( v, d); if ((int)LANE >= d && up > v) v = up; }
+	return v;
+}
 __device__ void emitLexems( LexWave& w, const L1Params& P, u32 doc)
 {
 	enum {BIND_CONTENT=0, BIND_SUCCESSOR=1, BIND_PREDECESSOR=2, BIND_UNIQUE=3};
-	// pass A counts, pass B writes; both walk the event array with the reference's state machine
+	const u32 n = w.nEvents;
+	// the first content/unique event
+	u32 first = n;
+	for (u32 base=0; base<n && first==n; base+=64)
+	{
+		const u32 i = base + LANE;
+		u32 bind = 0xFFu;
+		if (i < n) bind = (w.events[ i].levelBind >> 8) & 0xFFu;
+		const u64 m = __ballot( bind == BIND_UNIQUE || bind == BIND_CONTENT);
+		if (m) first = base + (u32)__builtin_ctzll( m);
+	}
 	u64 outBase = 0;
 	u32 total = 0;
-	for (int phase=0; phase<2 && !w.err; ++phase)
+	if (first < n)
 	{
-		u32 n = w.nEvents, mi = 0, ordpos = 0, origpos = 0, lastbind = BIND_CONTENT, out = 0;
-		bool started = false;
-		// phase 1 of the reference: up to the first content/unique event
-		for (; mi<n; ++mi)
+		for (int phase=0; phase<2 && !w.err; ++phase)
 		{
-			Event m; ldEvent( m, &w.events[ mi]);
-			u32 bind = (m.levelBind >> 8) & 0xFFu;
-			lastbind = bind;
-			if (bind == BIND_UNIQUE || bind == BIND_CONTENT)
+			u32 out = 0;			// lexems written so far
+			u32 runMax = 0;			// start of the rightmost counted event so far (valid from `first` on)
+			u32 runOrd = 1;			// ordinal position after the events so far
+			u32 prevBind = BIND_CONTENT;	// bind of the event before this step's first one
+			for (u32 base=0; base<n; base+=64)
 			{
-				ordpos = 1; origpos = m.origpos; started = true;
-				if (phase) { u32* o = P.lexems + 4*(outBase + out); o[0] = m.id; o[1] = 1; o[2] = m.origpos; o[3] = m.origsize; }
-				++out; ++mi;
-				break;
+				const u32 i = base + LANE;
+				uint4 e = make_uint4( 0, 0, 0, 0xFF00u);		// {id, origpos, origsize, levelBind}
+				if (i < n) e = *(const uint4*)&w.events[ i];
+				const u32 bind = (e.w >> 8) & 0xFFu;
+				u32 pb = (u32)__shfl_up( (int)bind, 1);
+				if (LANE == 0) pb = prevBind;
+				const bool valid = i < n;
+				const bool after = valid && i > first;			// the state machine proper
+				const bool isFirst = valid && i == first;
+				const bool dropped = after && bind == BIND_UNIQUE && pb == BIND_UNIQUE;
+				const bool counted = (after && !dropped && (bind == BIND_UNIQUE || bind == BIND_CONTENT)) || isFirst;
+				// start of the rightmost counted event strictly before me
+				const u32 mine = counted ? e.y + 1u : 0u;		// +1: 0 = none
+				const u32 inclMax = scanMax( mine);
+				u32 exclMax = (u32)__shfl_up( (int)inclMax, 1);
+				if (LANE == 0) exclMax = 0;
+				if (runMax > exclMax) exclMax = runMax;
+				const bool advances = counted && !isFirst && (e.y + 1u) > exclMax;
+				const u32 inclOrd = scanAdd( advances ? 1u : 0u);
+				const u32 ord = runOrd + inclOrd;			// ordinal position after me
+				bool emit; u32 pos;
+				if (!valid) { emit = false; pos = 0; }
+				else if (i < first) { emit = (bind == BIND_SUCCESSOR); pos = 1; }
+				else if (dropped) { emit = false; pos = 0; }
+				else { emit = true; pos = (bind == BIND_SUCCESSOR) ? ord + 1u : ord; }
+				const u32 inclOut = scanAdd( emit ? 1u : 0u);
+				if (phase && emit)
+				{
+					u32* o = P.lexems + 4*(outBase + out + inclOut - 1u);
+					*(uint4*)o = make_uint4( e.x, pos, e.y, e.z);
+				}
+				out += uni( (u32)__shfl( (int)inclOut, 63));
+				runOrd += uni( (u32)__shfl( (int)inclOrd, 63));
+				const u32 stepMax = uni( (u32)__shfl( (int)inclMax, 63));
+				if (stepMax > runMax) runMax = stepMax;
+				prevBind = uni( (u32)__shfl( (int)bind, 63));
 			}
-			else if (bind == BIND_SUCCESSOR)
+			if (!phase)
 			{
-				if (phase) { u32* o = P.lexems + 4*(outBase + out); o[0] = m.id; o[1] = 1; o[2] = m.origpos; o[3] = m.origsize; }
-				++out;
+				total = out;
+				u64 b = 0;
+				if (LANE == 0) b = atomicAdd( (unsigned long long*)&P.counters[ L1C_LEXEMS], (unsigned long long)total);
+				outBase = ((u64)uni( (u32)(b >> 32)) << 32) | uni( (u32)b);
+				if (outBase + total > P.lexemCapacity) { w.err = L1D_ERR_OUTPUT; total = 0; }
+				if (!total) break;
 			}
-		}
-		if (!started) out = 0;
-		for (; mi<n && started; ++mi)
-		{
-			Event m; ldEvent( m, &w.events[ mi]);
-			u32 bind = (m.levelBind >> 8) & 0xFFu;
-			u32 pos = 0; bool emit = true;
-			if (bind == BIND_UNIQUE && lastbind == BIND_UNIQUE) emit = false;
-			else if (bind == BIND_UNIQUE || bind == BIND_CONTENT)
-			{
-				if (m.origpos > origpos) { origpos = m.origpos; ++ordpos; }
-				pos = ordpos;
-			}
-			else if (bind == BIND_SUCCESSOR) pos = ordpos+1;
-			else pos = ordpos;
-			if (emit)
-			{
-				if (phase) { u32* o = P.lexems + 4*(outBase + out); o[0] = m.id; o[1] = pos; o[2] = m.origpos; o[3] = m.origsize; }
-				++out;
-			}
-			lastbind = bind;
-		}
-		if (!phase)
-		{
-			total = out;
-			u64 b = 0;
-			if (LANE == 0) b = atomicAdd( (unsigned long long*)&P.counters[ L1C_LEXEMS], (unsigned long long)total);
-			outBase = ((u64)uni( (u32)(b >> 32)) << 32) | uni( (u32)b);
-			if (outBase + total > P.lexemCapacity) { w.err = L1D_ERR_OUTPUT; total = 0; }
-			if (!total) break;
 		}
 	}
 	if (LANE == 0)
