@@ -1345,21 +1345,24 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 		{
 			u64 todo = liveMask;
 			bool full = false;
-			while (todo)
+			const u32 lens = WINDOW[ LANE];			// the 64 list lengths, one read
+			u32 myIdx = 0;
+			while (todo)					// one round per distinct expiry position in the batch
 			{
 				const u32 leader = (u32)__builtin_ctzll( todo);
 				const u32 wsel = (u32)__builtin_amdgcn_readlane( widx, leader);
 				const bool mine = live && widx == wsel;
 				const u64 grp = __ballot( mine);
-				const u32 cnt = ldu( &WINDOW[ wsel]);
+				const u32 cnt = (u32)__builtin_amdgcn_readlane( lens, wsel);
 				const u32 ng = (u32)__popcll( grp);
 				winReserve( w, P, wsel, cnt, ng);
 				if (w.err) { full = true; break; }
-				if (mine) WINARR[ winEntryIndex( w, P, wsel, cnt + (u32)__popcll( grp & lanesBelow()))] = r;
+				if (mine) myIdx = cnt + (u32)__popcll( grp & lanesBelow());
 				WINDOW[ wsel] = cnt + ng;
 				todo &= ~grp;
 			}
 			if (full) return;
+			if (live) WINARR[ winEntryIndex( w, P, widx, myIdx)] = r;	// all lists at once
 		}
 		// ---- triggers: bucket positions in (program, template) order
 		u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;		// my installs per bucket, 16 x 8 bit
