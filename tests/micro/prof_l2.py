@@ -17,6 +17,6 @@ for op in (None, "sequence"):
             if 2 in codes: ctx.growArena()
             continue
         ms = ctx.lastKernelMs(); p = c["prof"]; tot = float(sum(p)) or 1.0
-        print("op=%s: %.1f ms, %d events -> %.2f M ev/s; fire %.2f install %.2f dispose %.2f expiry %.2f (ticks/event in phases %.0f)" % (
+        print("op=%s: %.1f ms, %d events -> %.2f M ev/s; slots %.2f %.2f %.2f %.2f (ticks/event %.0f)" % (
             op, ms, c["events"], c["events"]/ms/1e3, p[0]/tot, p[1]/tot, p[2]/tot, p[3]/tot, tot/c["events"]), flush=True)
         break
