@@ -237,7 +237,24 @@ private:
 		{
 			uint32_t lo = r[i].first, hi = r[i].second;
 			if (lo < 0x80) { ascii.addRange( lo, std::min<uint32_t>( hi, 0x7F)); haveAscii = true; lo = 0x80; }
-			if (lo <= hi) splitUtf8( lo, hi, alts);
+			if (lo > hi) continue;
+			if (lo == 0x80 && hi >= 0x10FFFF)
+			{
+				// every character beyond ASCII (negated ASCII classes, '.'): on valid UTF-8 -- which the
+				// reference's Hyperscan UTF-8 mode requires of its input too -- the lead byte alone
+				// decides the length, so ((L4 C | L3) C | L2) C with shared continuation positions
+				// (6 positions) reports exactly what the 26 positions of the exact range split report
+				ByteSet l2, l3, l4, c;
+				l2.addRange( 0xC2, 0xDF); l3.addRange( 0xE0, 0xEF); l4.addRange( 0xF0, 0xF4); c.addRange( 0x80, 0xBF);
+				std::vector<Tree> s4; s4.push_back( Tree::leaf( l4)); s4.push_back( Tree::leaf( c));
+				std::vector<Tree> a3; a3.push_back( Tree::cat( s4)); a3.push_back( Tree::leaf( l3));
+				std::vector<Tree> s3; s3.push_back( Tree::alt( a3)); s3.push_back( Tree::leaf( c));
+				std::vector<Tree> a2; a2.push_back( Tree::cat( s3)); a2.push_back( Tree::leaf( l2));
+				std::vector<Tree> s2; s2.push_back( Tree::alt( a2)); s2.push_back( Tree::leaf( c));
+				alts.push_back( Tree::cat( s2));
+				continue;
+			}
+			splitUtf8( lo, hi, alts);
 		}
 		if (haveAscii) alts.insert( alts.begin(), Tree::leaf( ascii));
 		return Tree::alt( alts);

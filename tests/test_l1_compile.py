@@ -53,6 +53,7 @@ def test_random_regex_tables_vs_oracle_and_python_re(seed):
                 continue
             try:        # documented limit of this version: 64 byte positions per expression
                 one = spa.PatternLexerInstance()
+                one.defineOption("DOTALL")
                 one.defineLexem(1, p, 0, 1, "content")
                 one.compile()
             except spa.PatternError as e:

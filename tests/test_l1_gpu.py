@@ -57,6 +57,7 @@ def test_random_regex_sets(seed):
             try:
                 re.compile(p)
                 one = spa.PatternLexerInstance()
+                one.defineOption("DOTALL")
                 one.defineLexem(1, p, 0, 1, "content")
                 one.compile()
             except (re.error, spa.PatternError):
