@@ -171,6 +171,65 @@ def test_rules_with_many_triggers(seed):
     _compare(gpu, ref, ndocs)
 
 
+def _random_tree(rng, nfeat, depth, maxdepth):
+    """(range, push function) of a random expression tree (BASELINE.json configs[3]: nested
+    within/sequence expressions; generator after testRandomExpressionTreeMatch.cpp:239-338 with the
+    depth limit lifted: range = argc + random + sum of the children's ranges)."""
+    if depth >= maxdepth or (depth > 0 and rng.random() < 0.35):
+        t = int(rng.integers(1, nfeat + 1))
+        var = "t%d" % depth if rng.random() < 0.3 else None
+
+        def push(m, t=t, var=var):
+            m.pushTerm(t)
+            if var:
+                m.attachVariable(var)
+        return 1, push
+    op = ["sequence", "within", "sequence_struct", "within_struct", "any", "sequence_imm", "and"][int(rng.integers(0, 7))]
+    argc = int(rng.integers(2, 4))
+    children = [_random_tree(rng, nfeat, depth + 1, maxdepth) for _ in range(argc)]
+    rg = argc + int(rng.integers(0, 4)) + sum(c[0] for c in children)
+    card = int(rng.integers(1, argc + 1)) if op in ("any", "and") and rng.random() < 0.4 else 0
+    var = "e%d" % depth if depth > 0 and rng.random() < 0.3 else None
+
+    def push(m):
+        n = argc
+        if op in ("sequence_struct", "within_struct"):
+            m.pushTerm(synth.DELIM)
+            n += 1
+        for _, c in children:
+            c(m)
+        m.pushExpression(op, n, rg, card)
+        if var:
+            m.attachVariable(var)
+    return rg, push
+
+
+@pytest.mark.parametrize("seed,maxdepth,ntrees,n", [(61, 3, 60, 250), (62, 5, 60, 250), (63, 8, 16, 120)])
+def test_random_expression_trees(seed, maxdepth, ntrees, n):
+    rng = np.random.default_rng(seed)
+    nfeat = 6
+    trees = [_random_tree(rng, nfeat, 0, maxdepth)[1] for _ in range(ntrees)]
+
+    def build(m):
+        for i, push in enumerate(trees):
+            push(m)
+            m.definePattern("tree_%d" % i, "", True)
+        m.compile()
+    ndocs = 16
+    lex = np.zeros((ndocs * n, 4), np.uint32)
+    offs = np.arange(ndocs + 1, dtype=np.uint64) * n
+    for d in range(ndocs):
+        ids = rng.integers(1, nfeat + 1, size=n)
+        ids[rng.random(n) < 0.05] = synth.DELIM
+        lex[d * n:(d + 1) * n, 0] = ids
+        lex[d * n:(d + 1) * n, 1] = np.arange(1, n + 1)
+        lex[d * n:(d + 1) * n, 2] = np.arange(n) * 2
+        lex[d * n:(d + 1) * n, 3] = 1
+    gpu, ref, m, o = _run_both(build, lex, offs)
+    assert len(ref.results) > 50
+    _compare(gpu, ref, ndocs)
+
+
 def test_not_ascending_positions_is_an_error():
     m = spa.PatternMatcherInstance()
     m.pushTerm(1)
