@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include "l1_tables.h"
 #include "l1_device.h"
+#include "wave_scan.h"
 
 using namespace spa;
 
@@ -420,13 +421,8 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 						}
 					}
 					// exclusive prefix sum of the counts over the lanes (report order = lane order)
-					u32 incl = mycount;
-					for (int d=1; d<64; d<<=1)
-					{
-						u32 up = __shfl_up( incl, d);
-						if ((int)LANE >= d) incl += up;
-					}
-					u32 total = uni( __shfl( incl, 63));
+					u32 incl = waveScanAdd( mycount);
+					u32 total = (u32)__builtin_amdgcn_readlane( incl, 63);
 					u32 at = w.nQueue + incl - mycount;
 					if (w.nQueue + total > P.queueCap) { w.err = L1D_ERR_ARENA; break; }
 					if (mycount)
@@ -493,13 +489,11 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 // pass B writes.
 __device__ __forceinline__ u32 scanAdd( u32 v)
 {
-	for (int d=1; d<64; d<<=1) { u32 up = __shfl_up( v, d); if ((int)LANE >= d) v += up; }
-	return v;
+	return waveScanAdd( v);
 }
 __device__ __forceinline__ u32 scanMax( u32 v)
 {
-	for (int d=1; d<64; d<<=1) { u32 up = __shfl_up( v, d); if ((int)LANE >= d && up > v) v = up; }
-	return v;
+	return waveScanMax( v);
 }
 __device__ void emitLexems( LexWave& w, const L1Params& P, u32 doc)
 {

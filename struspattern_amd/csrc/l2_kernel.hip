@@ -27,6 +27,7 @@
 #include <stdint.h>
 #include "l2_tables.h"
 #include "l2_device.h"
+#include "wave_scan.h"
 
 using namespace spa;
 
@@ -515,12 +516,8 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 		// 64 lanes x DEACT_MAXCHAIN = 256 could overflow an 8-bit field: scan in 16-bit halves
 		u32 lo0 = i0 & 0x00FF00FFu, hi0 = (i0 >> 8) & 0x00FF00FFu, lo1 = i1 & 0x00FF00FFu, hi1 = (i1 >> 8) & 0x00FF00FFu;
 		u32 lo2 = i2 & 0x00FF00FFu, hi2 = (i2 >> 8) & 0x00FF00FFu, lo3 = i3 & 0x00FF00FFu, hi3 = (i3 >> 8) & 0x00FF00FFu;
-		for (int dd=1; dd<64; dd<<=1)
-		{
-			u32 a0 = __shfl_up( lo0, dd), b0 = __shfl_up( hi0, dd), a1 = __shfl_up( lo1, dd), b1 = __shfl_up( hi1, dd);
-			u32 a2 = __shfl_up( lo2, dd), b2 = __shfl_up( hi2, dd), a3 = __shfl_up( lo3, dd), b3 = __shfl_up( hi3, dd);
-			if ((int)LANE >= dd) { lo0 += a0; hi0 += b0; lo1 += a1; hi1 += b1; lo2 += a2; hi2 += b2; lo3 += a3; hi3 += b3; }
-		}
+		lo0 = waveScanAdd( lo0); hi0 = waveScanAdd( hi0); lo1 = waveScanAdd( lo1); hi1 = waveScanAdd( hi1);
+		lo2 = waveScanAdd( lo2); hi2 = waveScanAdd( hi2); lo3 = waveScanAdd( lo3); hi3 = waveScanAdd( hi3);
 		// field h of word ws: h&3 == 0 -> lo bits 0..15, 1 -> hi bits 0..15, 2 -> lo bits 16..31, 3 -> hi bits 16..31
 		auto incl = [&]( u32 h) -> u32 {
 			u32 ws = h >> 2, f = h & 3u;
@@ -663,7 +660,7 @@ __device__ __forceinline__ void deactivateBatch( HWS* wsBlock, u32* wsArena, KP 
 			}
 			if (__ballot( bad)) { w.err = SPD_ERR_DATAREF; return; }
 			u32 incI = nfree;
-			for (int dd=1; dd<64; dd<<=1) { u32 up = __shfl_up( incI, dd); if ((int)LANE >= dd) incI += up; }
+			incI = waveScanAdd( incI);
 			const u32 totalI = (u32)__builtin_amdgcn_readlane( incI, 63);
 			if (freeRef)
 			{
@@ -1379,11 +1376,7 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 			}
 		}
 		u32 i0 = c0, i1 = c1, i2 = c2, i3 = c3;		// inclusive prefix sums over the lanes (fields stay < 256: 64 x MAXT)
-		for (int dd=1; dd<64; dd<<=1)
-		{
-			u32 u0 = __shfl_up( i0, dd), u1 = __shfl_up( i1, dd), u2 = __shfl_up( i2, dd), u3 = __shfl_up( i3, dd);
-			if ((int)LANE >= dd) { i0 += u0; i1 += u1; i2 += u2; i3 += u3; }
-		}
+		i0 = waveScanAdd( i0); i1 = waveScanAdd( i1); i2 = waveScanAdd( i2); i3 = waveScanAdd( i3);
 		const u32 e0 = i0 - c0, e1 = i1 - c1, e2 = i2 - c2, e3 = i3 - c3;
 		const u32 t0 = (u32)__builtin_amdgcn_readlane( i0, 63), t1 = (u32)__builtin_amdgcn_readlane( i1, 63);
 		const u32 t2 = (u32)__builtin_amdgcn_readlane( i2, 63), t3 = (u32)__builtin_amdgcn_readlane( i3, 63);
@@ -1784,7 +1777,7 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 				}
 				if (__ballot( deep)) { sequential = true; break; }
 				u32 incl = n;
-				for (int dd=1; dd<64; dd<<=1) { u32 up = __shfl_up( incl, dd); if ((int)LANE >= dd) incl += up; }
+				incl = waveScanAdd( incl);
 				total += (u32)__builtin_amdgcn_readlane( incl, 63);
 			}
 			if (sequential)
@@ -1828,7 +1821,7 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 					u32 n = 0;
 					if (ri < nres) n = P.results[ (resBase + ri)*9 + 8];
 					u32 incl = n;
-					for (int dd=1; dd<64; dd<<=1) { u32 up = __shfl_up( incl, dd); if ((int)LANE >= dd) incl += up; }
+					incl = waveScanAdd( incl);
 					if (ri < nres)
 					{
 						const u64 mine = ip + (incl - n);
