@@ -75,7 +75,7 @@ int sp_lexer_define_option( sp_lexer_t* l, const char* name, double value)
 int sp_lexer_compile( sp_lexer_t* l)
 { LGUARD( SP_ERR_COMPILE, l->compiler.compile()); }
 
-// Flat dump for tests: header of 8 words {nofPasses, nofClasses, maxExceptions, nofPatterns, nofPositions, 0,0,0},
+// Flat dump for tests: header of 8 words {nofPasses, nofClasses, maxExceptions, nofPatterns, nofPositions, nofLiterals, reportsOrdered, 0},
 // byteClass[256], classCtx[nofClasses], charMask, startMask, acceptMask, shiftDst, selfLoop,
 // exCount[nofPasses], exSrc, exDst, then per pattern {id, word, levelBind, prefixLen, suffixLen, mask}
 size_t sp_lexer_dump_tables( const sp_lexer_t* l, uint64_t** out)
@@ -102,6 +102,7 @@ size_t sp_lexer_dump_tables( const sp_lexer_t* l, uint64_t** out)
 	}
 	// whole-word literals: count, then per literal {len, patCount, bytes..., pattern indices...}
 	b[5] = T.nofLiterals;
+	b[6] = T.reportsOrdered ? 1 : 0;
 	for (size_t i=0; i<T.literals.size(); ++i)
 	{
 		const DevLiteral& e = T.literals[i];
@@ -261,6 +262,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.symbolMask = (uint32_t)T.symbols.size()-1;
 	P.literals = (const DevLiteral*)c->dLiterals.ptr; P.literalText = (const uint8_t*)c->dLiteralText.ptr;
 	P.litPats = (const uint32_t*)c->dLitPats.ptr; P.literalMask = (uint32_t)T.literals.size()-1; P.nofLiterals = T.nofLiterals;
+	P.reportsOrdered = T.reportsOrdered ? 1u : 0u;
 	P.nofPasses = T.nofPasses; P.nofClasses = T.nofClasses; P.maxExceptions = T.maxExceptions ? T.maxExceptions : 1;
 	P.nofPatterns = (uint32_t)T.patterns.size();
 	P.text = (const uint8_t*)d_text; P.docOffsets = (const uint64_t*)d_doc_offsets; P.ndocs = (uint32_t)ndocs;

@@ -765,27 +765,79 @@ void LexCompiler::compile()
 		autos.push_back( makeAutomaton( tree, d.expression));
 	}
 
-	// 2. layout: patterns in definition order, never straddling a 64-bit word (report order for equal
-	//    end offsets is ascending pattern index = ascending (pass, lane, bit))
+	// 2. layout: a pattern never straddles a 64-bit word.  Patterns in definition order make the report
+	//    order for equal end offsets (ascending pattern index) fall out of the (pass, lane, bit) order;
+	//    but in-order packing leaves ~8% of the bits unused, and when that costs a whole pass (every pass
+	//    is a full unit of work per input byte) the patterns are packed first-fit by decreasing size
+	//    instead and the kernel sorts the (few) reports that share an end offset.
 	std::vector<uint32_t> bitBase( autos.size(), 0);
-	uint32_t word = 0, used = 0;
-	T.wordPatBegin.clear(); T.wordPats.clear();
-	T.wordPatBegin.push_back( 0);
+	std::vector<uint32_t> wordOf( autos.size(), 0);
 	T.nofPositions = 0;
-	for (size_t pi=0; pi<autos.size(); ++pi)
+	uint32_t word = 0;
 	{
-		uint32_t n = (uint32_t)autos[ pi].pos.size();
-		if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
-		T.nofPositions += n;
-		if (used + n > 64) { ++word; used = 0; T.wordPatBegin.push_back( (uint32_t)T.wordPats.size()); }
-		bitBase[ pi] = used;
-		T.patterns[ pi].word = word;
-		uint64_t mask = n == 64 ? ~0ull : (((1ull << n) - 1) << used);
-		T.patterns[ pi].maskLo = (uint32_t)mask; T.patterns[ pi].maskHi = (uint32_t)(mask >> 32);
-		T.wordPats.push_back( (uint32_t)pi);
-		used += n;
+		uint32_t used = 0; bool any = false;
+		for (size_t pi=0; pi<autos.size(); ++pi)
+		{
+			uint32_t n = (uint32_t)autos[ pi].pos.size();
+			if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
+			T.nofPositions += n;
+			if (used + n > 64) { ++word; used = 0; }
+			bitBase[ pi] = used; wordOf[ pi] = word; used += n; any = true;
+		}
+		if (!any) word = 0; else ++word;		// word = number of words used
 	}
-	uint32_t nwords = T.wordPats.empty() ? 0 : word+1;
+	T.reportsOrdered = true;
+	{
+		const uint32_t perPass = L1_WORDS_PER_PASS;
+		const uint32_t passesInOrder = (word + perPass-1) / perPass;
+		const uint32_t passesMin = (T.nofPositions + 64*perPass-1) / (64*perPass);
+		if (passesInOrder > passesMin && passesInOrder > 1)
+		{
+			std::vector<size_t> bySize;
+			for (size_t pi=0; pi<autos.size(); ++pi) if (T.patterns[ pi].word != L1_WORD_LITERAL) bySize.push_back( pi);
+			std::stable_sort( bySize.begin(), bySize.end(), [&]( size_t a, size_t b) { return autos[ a].pos.size() > autos[ b].pos.size(); });
+			std::vector<uint32_t> fill;
+			std::vector<uint32_t> base2( autos.size(), 0), word2( autos.size(), 0);
+			size_t firstOpen = 0;
+			for (size_t k=0; k<bySize.size(); ++k)
+			{
+				const size_t pi = bySize[ k];
+				const uint32_t n = (uint32_t)autos[ pi].pos.size();
+				size_t wi = firstOpen;
+				while (wi < fill.size() && fill[ wi] + n > 64) ++wi;
+				if (wi == fill.size()) fill.push_back( 0);
+				base2[ pi] = fill[ wi]; word2[ pi] = (uint32_t)wi; fill[ wi] += n;
+				while (firstOpen < fill.size() && fill[ firstOpen] == 64) ++firstOpen;
+			}
+			const uint32_t passesPacked = ((uint32_t)fill.size() + perPass-1) / perPass;
+			if (passesPacked < passesInOrder)
+			{
+				bitBase.swap( base2); wordOf.swap( word2); word = (uint32_t)fill.size();
+				T.reportsOrdered = false;
+			}
+		}
+	}
+	T.wordPatBegin.clear(); T.wordPats.clear();
+	{
+		// patterns of every word (ascending pattern index inside a word)
+		std::vector<std::vector<uint32_t> > perWord( word);
+		for (size_t pi=0; pi<autos.size(); ++pi)
+		{
+			if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
+			const uint32_t n = (uint32_t)autos[ pi].pos.size(), used = bitBase[ pi];
+			T.patterns[ pi].word = wordOf[ pi];
+			uint64_t mask = n == 64 ? ~0ull : (((1ull << n) - 1) << used);
+			T.patterns[ pi].maskLo = (uint32_t)mask; T.patterns[ pi].maskHi = (uint32_t)(mask >> 32);
+			perWord[ wordOf[ pi]].push_back( (uint32_t)pi);
+		}
+		T.wordPatBegin.push_back( 0);
+		for (uint32_t wi=0; wi<word; ++wi)
+		{
+			T.wordPats.insert( T.wordPats.end(), perWord[ wi].begin(), perWord[ wi].end());
+			T.wordPatBegin.push_back( (uint32_t)T.wordPats.size());
+		}
+	}
+	uint32_t nwords = word;
 	T.nofPasses = (nwords + L1_WORDS_PER_PASS-1) / L1_WORDS_PER_PASS;
 	if (T.nofPasses == 0) T.nofPasses = 1;
 	const uint32_t totalWords = T.nofPasses * L1_WORDS_PER_PASS;

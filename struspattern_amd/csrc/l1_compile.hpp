@@ -40,6 +40,7 @@ struct LexTables
 	std::vector<uint32_t> litPats;
 	uint32_t nofLiterals;
 	uint32_t nofPositions;
+	bool reportsOrdered;			// patterns sit in the words in definition order (else the kernel sorts the reports of one end offset)
 };
 
 class LexCompiler

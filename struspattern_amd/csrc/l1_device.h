@@ -36,6 +36,7 @@ struct L1Params
 	uint32_t ldsWords;		// 0 = read the tables from global memory
 	uint32_t ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst;	// word offsets inside the image
 	uint32_t nofPasses, nofClasses, maxExceptions, nofPatterns;
+	uint32_t reportsOrdered;	// 0: the reports of one end offset have to be sorted by pattern index
 	// input
 	const uint8_t* text;		// all documents back to back
 	const uint64_t* docOffsets;	// ndocs+1 byte offsets

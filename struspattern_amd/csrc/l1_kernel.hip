@@ -447,6 +447,43 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 					}
 					w.nQueue += total;
 				}
+				if (!P.reportsOrdered && !w.err)
+				{
+					// the patterns are packed by size, not in definition order: bring the reports of this end
+					// offset into ascending pattern index (the order the reference's handler sees them in)
+					const u32 g = w.nQueue - groupStart;
+					if (g > 1)
+					{
+						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+						if (g <= 64u)
+						{
+							uint4 e = make_uint4( 0, 0xFFFFFFFFu, 0, 0);
+							if (LANE < g) e = *(const uint4*)(w.queue + 4*(u64)(groupStart + LANE));
+							u32 rank = 0;
+							for (u32 j=0; j<g; ++j) { const u32 pj = (u32)__builtin_amdgcn_readlane( e.y, j); if (pj < e.y) ++rank; }
+							if (LANE < g) *(uint4*)(w.queue + 4*(u64)(groupStart + rank)) = e;
+						}
+						else
+						{
+							for (u32 a=groupStart+1; a<w.nQueue; ++a)		// insertion sort, one entry at a time
+							{
+								const u32* src = w.queue + 4*(u64)a;
+								const u32 k0 = ldu( &src[0]), k1 = ldu( &src[1]), k2 = ldu( &src[2]), k3 = ldu( &src[3]);
+								u32 b = a;
+								while (b > groupStart && ldu( &w.queue[ 4*(u64)(b-1)+1]) > k1)
+								{
+									u32* dst = w.queue + 4*(u64)b; const u32* s2 = w.queue + 4*(u64)(b-1);
+									const u32 m0 = ldu( &s2[0]), m1 = ldu( &s2[1]), m2 = ldu( &s2[2]), m3 = ldu( &s2[3]);
+									dst[0] = m0; dst[1] = m1; dst[2] = m2; dst[3] = m3;
+									--b;
+								}
+								u32* dst = w.queue + 4*(u64)b;
+								dst[0] = k0; dst[1] = k1; dst[2] = k2; dst[3] = k3;
+							}
+						}
+						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+					}
+				}
 				PROF_ACC( 2, tHit);
 			}
 			if (P.nofLiterals)

@@ -113,3 +113,20 @@ def test_symbols_and_names():
     assert lx.getSymbol(1, "cat") == 7 and lx.getSymbol(1, "dog") == 0
     with pytest.raises(spa.PatternError):
         lx.defineSymbol(8, 1, "cat")                   # symbol defined twice (:286-290)
+
+
+def test_size_ordered_packing_reports_the_same():
+    """610 synthetic patterns need two passes in definition order and one when packed by size; the raw
+    reports (sorted by end offset, pattern index) must not depend on the packing."""
+    from struspattern_amd import synth
+    vocab = synth.vocabulary(3000, 77)
+    pats = synth.lexer_patterns(610, vocab, 6)
+    text, offs = synth.text_documents(1, 1500, vocab, 106, utf8=False)
+    lx = spa.PatternLexerInstance()
+    synth.apply_lexer_patterns(lx, pats)
+    dump = lx.dumpTables()
+    assert int(dump[0]) == 1 and int(dump[6]) == 0
+    o = oracle.L1Lexer()
+    synth.apply_lexer_patterns(o, pats)
+    raw, _ = o.matchDocs(text, [0, len(text)], raw=True)
+    assert Tables(dump).raw_reports(text) == [(int(r[0]), int(r[1]), int(r[2])) for r in raw]

@@ -81,12 +81,16 @@ def test_random_regex_sets(seed):
 
 # the (5000, ..) case compiles to 3 automaton passes: the kernel instance for 4 must stop at the tables' end
 @pytest.mark.parametrize("npat,ndocs,docbytes,utf8,seed", [(64, 16, 2000, False, 1), (256, 24, 4096, False, 2), (256, 8, 3000, True, 3), (700, 6, 2000, False, 4),
-                                                            (5000, 6, 3000, False, 5)])
+                                                            (5000, 6, 3000, False, 5),
+                                                            # 610 patterns fill one pass only when packed by size: the kernel sorts the reports of an end offset
+                                                            (610, 12, 3000, False, 6)])
 def test_synthetic_lexer_workload(npat, ndocs, docbytes, utf8, seed):
     vocab = synth.vocabulary(6000 if npat > 3000 else 3000, 77)
     pats = synth.lexer_patterns(npat, vocab, seed)
     text, offs = synth.text_documents(ndocs, docbytes, vocab, 100 + seed, utf8=utf8)
     lx, o = _both(lambda x: synth.apply_lexer_patterns(x, pats))
+    if npat == 610:
+        assert int(lx.dumpTables()[6]) == 0 and int(lx.dumpTables()[0]) == 1
     gpu = lx.createContext().matchDocs(text, offs)
     ref, roffs = o.matchDocs(text, offs, nthreads=8)
     assert len(ref) > 100
