@@ -527,24 +527,61 @@ struct Glushkov
 	}
 };
 
-// Is the expression exactly  \b <word characters> \b  ?  Then it matches precisely the maximal runs of
-// word characters that equal the literal, and (from,to) = the run: no automaton bits are needed.
-bool wholeWordLiteral( const Tree& t, std::string& word)
+// Is the expression exactly  \b <word characters> \b  or  \b ( word | word | ... ) \b  ?  Then it matches
+// precisely the maximal runs of word characters that equal one of the words, and (from,to) = the run:
+// no automaton bits are needed, the words go into the token hash table.
+static bool literalWordOf( const Tree& t, std::string& word)
 {
+	word.clear();
+	if (t.op == T_SET)
+	{
+		int only = -1, n = 0;
+		for (unsigned c=0; c<256; ++c) if (t.set.has( c)) { only = (int)c; ++n; }
+		if (n != 1 || !isWordChar( (unsigned)only)) return false;
+		word.push_back( (char)only);
+		return true;
+	}
+	if (t.op != T_CAT || t.kids.empty()) return false;
+	for (size_t i=0; i<t.kids.size(); ++i)
+	{
+		std::string one;
+		if (t.kids[i].op != T_SET || !literalWordOf( t.kids[i], one)) return false;
+		word += one;
+	}
+	return !word.empty() && word.size() <= 64;
+}
+bool wholeWordLiterals( const Tree& t, std::vector<std::string>& words)
+{
+	words.clear();
 	if (t.op != T_CAT || t.kids.size() < 3) return false;
 	if (t.kids.front().op != T_ASSERT || t.kids.front().assertion != A_WB) return false;
 	if (t.kids.back().op != T_ASSERT || t.kids.back().assertion != A_WB) return false;
-	word.clear();
+	if (t.kids.size() == 3)
+	{
+		// \b ( w1 | w2 | .. ) \b   (the group may be capturing: the selected sub-expression is checked by the caller)
+		const Tree* inner = &t.kids[1];
+		while (inner->op == T_GROUP) inner = &inner->kids[0];
+		if (inner->op == T_ALT)
+		{
+			for (size_t i=0; i<inner->kids.size(); ++i)
+			{
+				std::string w;
+				if (!literalWordOf( inner->kids[i], w)) return false;
+				if (std::find( words.begin(), words.end(), w) == words.end()) words.push_back( w);
+			}
+			return !words.empty();
+		}
+	}
+	std::string word;
 	for (size_t i=1; i+1<t.kids.size(); ++i)
 	{
-		const Tree& k = t.kids[i];
-		if (k.op != T_SET) return false;
-		int only = -1, n = 0;
-		for (unsigned c=0; c<256; ++c) if (k.set.has( c)) { only = (int)c; ++n; }
-		if (n != 1 || !isWordChar( (unsigned)only)) return false;
-		word.push_back( (char)only);
+		std::string one;
+		if (t.kids[i].op != T_SET || !literalWordOf( t.kids[i], one)) return false;
+		word += one;
 	}
-	return !word.empty() && word.size() <= 64;
+	if (word.empty() || word.size() > 64) return false;
+	words.push_back( word);
+	return true;
 }
 
 int ctxOfByte( unsigned c) { return c == '\n' ? CTX_NEWLINE : isWordChar( c) ? CTX_WORD : CTX_OTHER; }
@@ -751,11 +788,11 @@ void LexCompiler::compile()
 			dp.levelBind |= (1u << 17);
 		}
 		if (m_symbols.count( d.id)) dp.levelBind |= (1u << 16);
-		std::string word;
-		if (wholeWordLiteral( tree, word))
+		std::vector<std::string> words;
+		if (!d.resultIndex && wholeWordLiterals( tree, words))
 		{
 			dp.word = L1_WORD_LITERAL;
-			literalWords[ word].push_back( (uint32_t)di);
+			for (size_t wi=0; wi<words.size(); ++wi) literalWords[ words[ wi]].push_back( (uint32_t)di);
 			T.patterns.push_back( dp);
 			autos.push_back( Automaton());
 			for (int c=0; c<CTX_COUNT; ++c) { autos.back().start[c] = 0; autos.back().accept[c] = 0; }

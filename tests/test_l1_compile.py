@@ -116,11 +116,11 @@ def test_symbols_and_names():
 
 
 def test_size_ordered_packing_reports_the_same():
-    """610 synthetic patterns need two passes in definition order and one when packed by size; the raw
+    """4800 synthetic patterns need two passes in definition order and one when packed by size; the raw
     reports (sorted by end offset, pattern index) must not depend on the packing."""
     from struspattern_amd import synth
-    vocab = synth.vocabulary(3000, 77)
-    pats = synth.lexer_patterns(610, vocab, 6)
+    vocab = synth.vocabulary(6000, 77)
+    pats = synth.lexer_patterns(4800, vocab, 6)
     text, offs = synth.text_documents(1, 1500, vocab, 106, utf8=False)
     lx = spa.PatternLexerInstance()
     synth.apply_lexer_patterns(lx, pats)

@@ -79,18 +79,20 @@ def test_random_regex_sets(seed):
         assert np.array_equal(gpu.lexems, ref), pats
 
 
-# the (5000, ..) case compiles to 3 automaton passes: the kernel instance for 4 must stop at the tables' end
+# the (11000, ..) case compiles to 3 automaton passes (a pass count that is not a power of two)
 @pytest.mark.parametrize("npat,ndocs,docbytes,utf8,seed", [(64, 16, 2000, False, 1), (256, 24, 4096, False, 2), (256, 8, 3000, True, 3), (700, 6, 2000, False, 4),
-                                                            (5000, 6, 3000, False, 5),
-                                                            # 610 patterns fill one pass only when packed by size: the kernel sorts the reports of an end offset
-                                                            (610, 12, 3000, False, 6)])
+                                                            (11000, 4, 2000, False, 5),
+                                                            # 4800 patterns fill one pass only when packed by size: the kernel sorts the reports of an end offset
+                                                            (4800, 12, 3000, False, 6)])
 def test_synthetic_lexer_workload(npat, ndocs, docbytes, utf8, seed):
-    vocab = synth.vocabulary(6000 if npat > 3000 else 3000, 77)
+    vocab = synth.vocabulary(12000 if npat > 6000 else 6000 if npat > 3000 else 3000, 77)
     pats = synth.lexer_patterns(npat, vocab, seed)
     text, offs = synth.text_documents(ndocs, docbytes, vocab, 100 + seed, utf8=utf8)
     lx, o = _both(lambda x: synth.apply_lexer_patterns(x, pats))
-    if npat == 610:
+    if npat == 4800:
         assert int(lx.dumpTables()[6]) == 0 and int(lx.dumpTables()[0]) == 1
+    if npat == 11000:
+        assert int(lx.dumpTables()[0]) == 3
     gpu = lx.createContext().matchDocs(text, offs)
     ref, roffs = o.matchDocs(text, offs, nthreads=8)
     assert len(ref) > 100
