@@ -176,7 +176,16 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 			if (bytes <= 144*1024 && T.nofPasses <= 8)
 			{
 				c->ldsWords = (uint32_t)img.size();
-				c->blockThreads = bytes <= 20*1024 ? 256 : bytes <= 40*1024 ? 512 : 1024;
+				// as many workgroups per CU as copies of the image fit into the 160 KB of LDS, sharing the waves
+				// the register budget allows (5 per SIMD up to 2 passes, 4 beyond)
+				const unsigned maxWaves = T.nofPasses <= 2 ? 20u : 16u;
+				unsigned copies = (unsigned)((160*1024 - 1024) / (bytes ? bytes : 1));
+				if (copies < 1) copies = 1;
+				if (copies > 5) copies = 5;
+				unsigned wpb = maxWaves / copies;
+				if (wpb > 16) wpb = 16;
+				if (wpb < 1) wpb = 1;
+				c->blockThreads = 64 * wpb;
 			}
 			else { c->ldsWords = 0; c->blockThreads = 256; }
 		}
