@@ -177,7 +177,8 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 			{
 				c->ldsWords = (uint32_t)img.size();
 				// as many workgroups per CU as copies of the image fit into the 160 KB of LDS, sharing the waves
-				// the register budget allows (5 per SIMD up to 2 passes, 4 beyond)
+				// the register budget allows (5 per SIMD up to 2 passes, 4 beyond; two 10-wave workgroups of the
+				// 3-pass instance at 96 registers were measured not to share a CU)
 				const unsigned maxWaves = T.nofPasses <= 2 ? 20u : 16u;
 				unsigned copies = (unsigned)((160*1024 - 1024) / (bytes ? bytes : 1));
 				if (copies < 1) copies = 1;

@@ -673,8 +673,11 @@ __device__ void lexDocuments( const L1Params& P)
 // spill 22..96 of them, which was measured faster than halving the waves (512-thread groups).
 #define SPA_L1_KERNEL( NAME, N, T) \
 extern "C" __global__ __launch_bounds__(T) void spa_l1_lex_kernel_##NAME( L1Params P) { if (P.ldsWords) lexDocuments<N,true>( P); else lexDocuments<N,false>( P); }
-SPA_L1_KERNEL( p1, 1, 1024)
-SPA_L1_KERNEL( p2, 2, 1024)
+// up to 2 passes: under 96 registers (5 waves per SIMD, 20 per CU)
+#define SPA_L1_KERNEL5( NAME, N, T) \
+extern "C" __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5,8))) void spa_l1_lex_kernel_##NAME( L1Params P) { if (P.ldsWords) lexDocuments<N,true>( P); else lexDocuments<N,false>( P); }
+SPA_L1_KERNEL5( p1, 1, 1024)
+SPA_L1_KERNEL5( p2, 2, 1024)
 SPA_L1_KERNEL( p3, 3, 1024)
 SPA_L1_KERNEL( p4, 4, 1024)
 SPA_L1_KERNEL( p5, 5, 1024)
