@@ -18,6 +18,7 @@
 //  4. ORDPOS ordinal positions and the output records, once per document.
 // Integer/byte work, HBM-streaming input: no MFMA.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include "l1_tables.h"
 #include "l1_device.h"
@@ -346,11 +347,12 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 		// 64 document bytes per load, one per lane; replayed byte by byte through a scalar register
 		u32 mine = (tile + LANE < len) ? w.doc[ tile + LANE] : 0u;
 		u32 inTile = (len - tile) < 64 ? (len - tile) : 64;	// document bytes in this tile
-		u32 steps = (tile + 64 > len) ? inTile + 1 : 64;	// +1: the virtual end-of-document step
-		for (u32 k=0; k<steps && !w.err; ++k)
+		// one byte step; the virtual step behind the last byte (matches that end with the document) is a
+		// separate instance so that the hot one carries no end-of-document conditions
+		auto step = [&]( auto atEndTag, const u32 k)
 		{
+			constexpr bool atEnd = decltype(atEndTag)::value;
 			const u32 i = tile + k;
-			const bool atEnd = (i >= len);
 			const u32 b = atEnd ? 0u : (u32)__builtin_amdgcn_readlane( mine, k);
 			const u32 sh = (b & 3u)*8;
 			const u32 cls = atEnd ? 0u : (((u32)__builtin_amdgcn_readlane( clsReg, b >> 2) >> sh) & 0xFFu);
@@ -506,7 +508,9 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 				__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 				drainQueue( w, P, T);
 			}
-		}
+		};
+		for (u32 k=0; k<inTile && !w.err; ++k) step( std::false_type(), k);
+		if (tile + 64 > len && !w.err) step( std::true_type(), inTile);
 	}
 	if (!w.err && w.nQueue)
 	{
