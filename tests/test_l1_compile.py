@@ -130,3 +130,13 @@ def test_size_ordered_packing_reports_the_same():
     synth.apply_lexer_patterns(o, pats)
     raw, _ = o.matchDocs(text, [0, len(text)], raw=True)
     assert Tables(dump).raw_reports(text) == [(int(r[0]), int(r[1]), int(r[2])) for r in raw]
+
+
+def test_classes_covering_all_non_ascii_characters():
+    """'.' and negated ASCII classes take the compact 6-position form for "any character beyond ASCII";
+    on valid UTF-8 of every sequence length (incl. the first and last code point of each length) the
+    reports must equal the oracle's, which splits the ranges exactly."""
+    text = ("a\u0080b\u07ffc\u0800d\uffffe\U00010000f\U0010ffffg x\u00e9y \u20ac\u20ac z").encode("utf-8")
+    for pats in (["a.b", "[^a-z ]+", "\\b[^\\s]+\\b", ".", "[^\\x00-\\x7f]{2}", "x[^q]y"], ["[^.]{3}", "(?:.|q){2}z"]):
+        assert _product_reports(pats, text) == _oracle_reports(pats, text), pats
+        assert _product_reports(pats, text, options=()) == _oracle_reports(pats, text, options=()), pats
