@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--regexes", type=int, default=0)
     ap.add_argument("--rules", type=int, default=10000)
     ap.add_argument("--docs", type=int, default=0)
-    ap.add_argument("--docbytes", type=int, default=65536)
+    ap.add_argument("--docbytes", type=int, default=0, help="document size (default: 16 KiB in the pipeline workload, 64 KiB in the lexer workload)")
     ap.add_argument("--docsize", type=int, default=1000, help="tokens per document (workload l2)")
     ap.add_argument("--features", type=int, default=10000, help="distinct tokens (workload l2)")
     ap.add_argument("--op", default="", help="fix the rule operator (default: the 5-way Zipf mix)")
@@ -82,6 +82,8 @@ def main():
     from struspattern_amd import synth
 
     wl = args.workload
+    if not args.docbytes:
+        args.docbytes = 16384 if wl == "pipeline" else 65536
     stream = torch.cuda.current_stream().cuda_stream
     lctx = mctx = None
     pats = rules = None
@@ -89,9 +91,10 @@ def main():
     nbytes = 0
     if wl in ("pipeline", "lexer"):
         nreg = args.regexes or (10000 if wl == "pipeline" else 256)
-        # documents per step: a multiple of the resident waves of both kernels (4096 lexer / 3072 automaton
-        # wave slots on 256 CUs), so that the static one-wave-per-document assignment runs full rounds
-        ndocs = args.docs or (12288 if wl == "pipeline" else 8192)
+        # documents per step: 805 MB of text as 16 KiB documents (a document is one sequential job of one
+        # wave in both kernels: the shorter the jobs, the smaller the idle tail of a launch); the count is a
+        # multiple of the resident waves of both kernels (4096 lexer / 3072 automaton slots on 256 CUs)
+        ndocs = args.docs or (49152 if wl == "pipeline" else 8192)
         vocab = synth.vocabulary(30000, 1)
         if wl == "pipeline":
             pats, rules = synth.pipeline_workload(nreg, args.rules, vocab, seed=4)
