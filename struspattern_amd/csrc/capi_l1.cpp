@@ -41,7 +41,7 @@ struct sp_lexer_ctx
 	int device;
 	std::string lasterror;
 	DeviceBuffer dByteClass, dClassCtx, dCharMask, dStartMask, dAcceptMask, dShiftDst, dSelfLoop, dExSrc, dExDst, dExCount,
-		dWordPatBegin, dWordPats, dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit;
+		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit;
 	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst; unsigned blockThreads;
 	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus;
 	uint32_t queueCap, eventCap;
@@ -152,8 +152,6 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 		c->dExSrc.upload( T.exSrc.data(), T.exSrc.size()*8);
 		c->dExDst.upload( T.exDst.data(), T.exDst.size()*8);
 		c->dExCount.upload( T.exCount.data(), T.exCount.size()*4);
-		c->dWordPatBegin.upload( T.wordPatBegin.data(), T.wordPatBegin.size()*4);
-		c->dWordPats.upload( T.wordPats.data(), T.wordPats.size()*4);
 		c->dPatOfBit.upload( T.patOfBit.data(), T.patOfBit.size()*4);
 		c->dPatterns.upload( T.patterns.data(), T.patterns.size()*sizeof(DevLexPattern));
 		c->dSymbols.upload( T.symbols.data(), T.symbols.size()*sizeof(DevSymbol));
@@ -266,8 +264,8 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.charMask = (const uint64_t*)c->dCharMask.ptr; P.startMask = (const uint64_t*)c->dStartMask.ptr;
 	P.acceptMask = (const uint64_t*)c->dAcceptMask.ptr; P.shiftDst = (const uint64_t*)c->dShiftDst.ptr;
 	P.selfLoop = (const uint64_t*)c->dSelfLoop.ptr; P.exSrc = (const uint64_t*)c->dExSrc.ptr; P.exDst = (const uint64_t*)c->dExDst.ptr;
-	P.exCount = (const uint32_t*)c->dExCount.ptr; P.wordPatBegin = (const uint32_t*)c->dWordPatBegin.ptr;
-	P.wordPats = (const uint32_t*)c->dWordPats.ptr; P.patOfBit = (const uint32_t*)c->dPatOfBit.ptr; P.patterns = (const DevLexPattern*)c->dPatterns.ptr;
+	P.exCount = (const uint32_t*)c->dExCount.ptr;
+	P.patOfBit = (const uint32_t*)c->dPatOfBit.ptr; P.patterns = (const DevLexPattern*)c->dPatterns.ptr;
 	P.symbols = (const DevSymbol*)c->dSymbols.ptr; P.symbolText = (const uint8_t*)c->dSymbolText.ptr;
 	P.symbolMask = (uint32_t)T.symbols.size()-1;
 	P.literals = (const DevLiteral*)c->dLiterals.ptr; P.literalText = (const uint8_t*)c->dLiteralText.ptr;

@@ -21,8 +21,6 @@ struct L1Params
 	const uint64_t* exSrc;		// [pass][maxExceptions][64]
 	const uint64_t* exDst;
 	const uint32_t* exCount;	// [pass]
-	const uint32_t* wordPatBegin;
-	const uint32_t* wordPats;
 	const uint32_t* patOfBit;	// [word][64]: pattern owning automaton bit
 	const DevLexPattern* patterns;
 	const DevSymbol* symbols;
