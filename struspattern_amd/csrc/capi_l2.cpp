@@ -342,6 +342,7 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	}
 	if (c->arenaWaves < nwaves)
 	{
+		if (getenv( "SPA_L2_VERBOSE")) fprintf( stderr, "[spa] arena: rules %u bucket %u items %u refs %u staged %u winCap %u -> %.2f MB per wave, %u waves\n", c->arena.maxRules, c->arena.bucketCap, c->arena.maxItems, c->arena.maxRefs, c->arena.maxStaged, c->arena.winCap, c->arena.totalWords*4/1e6, nwaves);
 		size_t perWave = (size_t)c->arena.totalWords * sizeof(uint32_t);
 		size_t full = (size_t)c->numCUs*SPA_L2_WAVES_PER_CU;
 		if (full * perWave > ((size_t)48 << 30)) full = ((size_t)48 << 30) / perWave;
