@@ -105,7 +105,7 @@ struct Rule		// rule instance + its action slot (hpp:87-104, :171-186) + 4 trigg
 	u32 value, count, flags, start_ordpos;
 	u32 end_ordpos, start_origseg, start_origpos, program;
 	u32 trigMask, dataRef, ext, owner;	// trigMask: occupied slots; ext: continuation block+1 (programs with more than 4 triggers); owner: rule of a continuation block
-	u32 _pad[4];
+	u32 nInline, _pad[3];			// 1: one captured item sits in trigger slots 2 and 3 (see inlineItem)
 	Trig trig[4];				// trigger id = 4*block + slot, filled in installation order
 };
 struct Item { u32 variable, next, _a, _b; EvData d; };	// captured variable (hpp:262-271), 48 B
@@ -343,6 +343,40 @@ __device__ __forceinline__ void joinItems( WSR w, KP P, u32 dest, u32 src)	// cp
 		u32 variable = ldu( &S->variable); EvData d; ldEv( d, &S->d); it = ldu( &S->next);
 		appendItem( w, P, dest, variable, d);
 	}
+}
+
+// ---------------------------------------------------------------- captured item kept in the rule block
+// Until a rule completes (and a result or follow event has to share the list) the items it has
+// captured are private to it, and most rule instances expire without completing.  The usual rule has
+// at most two installed triggers and has captured one item by then: that item is kept in the two unused
+// trigger slots of the rule's own cache line {variable,sseg,eseg,spos | epos,sord,eord,sub} (+ fmt in
+// the padding) -- no item or reference record is allocated, linked, counted or released for it.  It
+// moves to a shared list (materializeItems) when a second item arrives or the rule completes.
+__device__ __forceinline__ void inlineItem( HRule* R, u32 variable, const EvData& d)
+{
+	st4( &R->trig[ 2], variable, d.sseg, d.eseg, d.spos);
+	st4( &R->trig[ 3], d.epos, d.sord, d.eord, d.sub);
+	R->_pad[ 0] = d.fmt;
+	R->nInline = 1;
+}
+__device__ __forceinline__ u32 materializeItems( WSR w, KP P, HRule* R)
+{
+	const u32 ref = createRef( w, P);
+	if (w.err) return 0;
+	if (ldu( &R->nInline))
+	{
+		const u32 it = allocItem( w, P);
+		if (w.err) return 0;
+		HItem* I = &ITEMS[ it];
+		const uint4 a = ldu4( &R->trig[ 2]), b = ldu4( &R->trig[ 3]);
+		st4( I, a.x, 0, 0, 0);
+		st4( W( I) + 4, a.y, a.z, a.w, b.x);
+		st4( W( I) + 8, b.y, b.z, b.w, ldu( &R->_pad[ 0]));
+		REFS[ 2*(ref-1)] = it+1;
+		R->nInline = 0;
+	}
+	R->dataRef = ref;
+	return ref;
 }
 
 // ---------------------------------------------------------------- event trigger table (cpp:114-257)
@@ -909,12 +943,25 @@ __device__ __forceinline__ void fireSignal( WSR w, KP P, u32 r, u32 sigtype, u32
 		{
 			if (variable)
 			{
-				if (!dataRef) { dataRef = createRef( w, P); R->dataRef = dataRef; }
-				if (!w.err) appendItem( w, P, dataRef, variable, d);
+				if (!dataRef)
+				{
+					const uint4 q2 = ldu4( W( R) + 8), q3 = ldu4( W( R) + 12);	// {trigMask,dataRef,ext,owner} {nInline,..}
+					if (!q3.x && !(q2.x & 0xCu) && !q2.z)
+					{
+						if (d.sub) addRef( w, P, d.sub);
+						inlineItem( R, variable, d);
+					}
+					else
+					{
+						dataRef = materializeItems( w, P, R);
+						if (!w.err) appendItem( w, P, dataRef, variable, d);
+					}
+				}
+				else appendItem( w, P, dataRef, variable, d);
 			}
 			else if (d.sub)
 			{
-				if (!dataRef) { dataRef = createRef( w, P); R->dataRef = dataRef; }
+				if (!dataRef) dataRef = materializeItems( w, P, R);
 				if (!w.err) joinItems( w, P, dataRef, d.sub);
 			}
 		}
@@ -940,6 +987,8 @@ __device__ __forceinline__ void fireSignal( WSR w, KP P, u32 r, u32 sigtype, u32
 		{
 			const uint4 g0 = ldu4( &P.programs[ q1.w]), g1 = ldu4( W( &P.programs[ q1.w]) + 4);	// {initsigval,initcount,event,resultHandle} {formatHandle,..}
 			u32 fevent = g0.z, handle = g0.w, fmt = g1.x;
+			// a follow event / result shares the captured items from here on: an item kept in the block moves to a list
+			if (P.withItems && !dataRef && (fevent || handle) && ldu( &R->nInline)) dataRef = materializeItems( w, P, R);
 			if (fevent)
 			{
 				if (w.nFollow < CAP_FOLLOW)
@@ -1053,7 +1102,7 @@ __device__ __forceinline__ void installProgram( WSR w, KP P, u32 keyevent, const
 	u32 count = ldu( &G->initcount) & 0xFFFFu;		// ActionSlot::count is 16 bit (hpp:98)
 	R->value = ldu( &G->initsigval); R->count = count; R->flags = F_ACTIVE; R->start_ordpos = 0;
 	R->end_ordpos = 0; R->start_origseg = 0; R->start_origpos = 0; R->program = program;
-	R->trigMask = 0; R->dataRef = 0; R->ext = 0; R->owner = 0;
+	R->trigMask = 0; R->dataRef = 0; R->ext = 0; R->owner = 0; R->nInline = 0;
 	defineDisposeRule( w, P, d.sord + range, r);
 	if (w.err) return;
 
@@ -1087,7 +1136,7 @@ __device__ __forceinline__ void installProgram( WSR w, KP P, u32 keyevent, const
 				if (w.err) return;
 				HRule* X = &RULES[ nb];
 				X->value = 0; X->count = 0; X->flags = F_EXT; X->start_ordpos = 0;
-				X->trigMask = 0; X->dataRef = 0; X->ext = 0; X->owner = r;
+				X->trigMask = 0; X->dataRef = 0; X->ext = 0; X->owner = r; X->nInline = 0;
 				RULES[ blk].trigMask = blkMask; RULES[ blk].ext = nb+1;
 				blk = nb; slot = 0; blkMask = 0;
 			}
@@ -1415,8 +1464,18 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 		// captured variables: the replayed event's item first, then the key triggers' in order (LIFO list: last on top)
 		const bool emitFollow = live && match && g_event != 0;
 		const bool emitResult = live && match && g_handle != 0;
+		u32 nInlineOut = 0;
 		{
-			const u32 myItems = live ? nItems : 0u;
+			const bool keepInline = live && nItems == 1u && local <= 2u && !emitFollow && !emitResult;
+			const u32 myItems = (live && !keepInline) ? nItems : 0u;
+			if (keepInline)
+			{
+				HRule* R = &RULES[ r];
+				if (itemVar0) { st4( &R->trig[ 2], itemVar0, ld.sseg, ld.eseg, ld.spos); st4( &R->trig[ 3], ld.epos, ld.sord, ld.eord, ld.sub); R->_pad[ 0] = ld.fmt; }
+#pragma unroll
+				for (int j=0; j<MAXT; ++j) if (keyVar[ j]) { st4( &R->trig[ 2], keyVar[ j], d.sseg, d.eseg, d.spos); st4( &R->trig[ 3], d.epos, d.sord, d.eord, d.sub); R->_pad[ 0] = d.fmt; }
+				nInlineOut = 1;
+			}
 			const u64 ib0 = __ballot( myItems & 1u), ib1 = __ballot( myItems & 2u), ib2 = __ballot( myItems & 4u), rmk = __ballot( myItems != 0);
 			if (rmk)
 			{
@@ -1505,6 +1564,7 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 			st4( R, value, count, flags, start_ordpos);
 			st4( W( R) + 4, end_ordpos, start_origseg, start_origpos, program);
 			st4( W( R) + 8, head, dataRef, 0, 0);		// {trigMask, dataRef, ext, owner}
+			R->nInline = nInlineOut;
 		}
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		} // segments
