@@ -128,6 +128,20 @@ const char* sp_matcher_variable_name(const sp_matcher_t* m, uint32_t variable);
 /* canonical dump of the compiled ProgramTable (test hook; format in csrc/l2_compile.hpp) */
 size_t sp_matcher_dump_table(const sp_matcher_t* m, uint32_t** out);
 
+/* ---- result format strings (definePattern's formatstring, src/patternMatcher.cpp:561-566, :172-181, :253-262).
+ * The device does not build strings: it reports which format applies and what its arguments are.
+ *   - a result with a format handle: its item list holds the ARGUMENTS of the format string; the
+ *     reference returns such a result with a value and an empty item list (:253-262).
+ *   - an item with a format handle (a variable bound to a sub-pattern that has a format string): the
+ *     `nsub` records that follow it are the arguments of ITS format (nested the same way) and are not
+ *     items of the enclosing list (:172-181); items without a format are followed by their sub-items
+ *     as siblings (:185-188), as in a matcher without format strings.
+ * Format strings are numbered 1..sp_matcher_format_count() in definePattern order.  The formatter
+ * itself (PatternResultFormat) lives in strusAnalyzer, outside the reference repository; the host
+ * mirrors implement "{variable}" / "{variable|separator}" substitution as its documentation describes. */
+uint32_t sp_matcher_format_count(const sp_matcher_t* m);
+const char* sp_matcher_format_string(const sp_matcher_t* m, uint32_t format_handle);
+
 /* PatternMatcherInstanceInterface::createContext (src/patternMatcher.cpp:586).  `device` is the
  * HIP device ordinal.  Fails with SP_ERR_DEVICE when no GPU is usable: there is no CPU fallback. */
 sp_matcher_ctx_t* sp_matcher_ctx_create(const sp_matcher_t* m, int device);
@@ -140,6 +154,9 @@ int sp_matcher_ctx_put_input(sp_matcher_ctx_t* c, const sp_lexem_t* lexems, cons
 /* PatternMatcherContextInterface::fetchResults (:271): runs the document on the GPU. */
 int sp_matcher_ctx_fetch_results(sp_matcher_ctx_t* c, sp_result_t** results, size_t* nresults,
                                  sp_result_item_t** items, size_t* nitems);
+/* format handles of the results / items of the last sp_matcher_ctx_fetch_results (borrowed pointers,
+ * valid until the next fetch or reset; NULL when the matcher has no format strings) */
+int sp_matcher_ctx_fetch_formats(sp_matcher_ctx_t* c, const uint32_t** result_format, const uint32_t** item_format);
 /* PatternMatcherContextInterface::getStatistics (:303) of the last fetch */
 int sp_matcher_ctx_statistics(sp_matcher_ctx_t* c, sp_matcher_stats_t* out);
 /* PatternMatcherContextInterface::reset (:320) */
@@ -157,6 +174,9 @@ typedef struct sp_match_batch {
 	uint64_t* doc_result_offsets;  /* ndocs+1 */
 	uint64_t* doc_stats;           /* ndocs x 4: programs installed, alt-key programs installed, signals fired, sum of active triggers */
 	int32_t* doc_status;           /* ndocs x SP_DOC_* */
+	/* matchers with format strings only (else NULL), see "result format strings" below */
+	uint32_t* result_format;       /* nresults: format handle of the result (0 = none) */
+	uint32_t* item_format;         /* nitems x {format handle of the item, nsub} */
 } sp_match_batch_t;
 
 /* host buffers in, host buffers out (PCIe both ways) */
@@ -174,6 +194,8 @@ typedef struct sp_match_device_batch {
 	void* d_doc_stats;           /* uint64_t[ndocs*4] */
 	void* d_doc_status;          /* int32_t[ndocs] */
 	void* d_counters;            /* uint64_t[8]: results, items, events, failed docs, ... */
+	void* d_result_format;       /* uint32_t[] parallel to d_results, NULL without format strings */
+	void* d_item_format;         /* uint32_t[][2] parallel to d_items, NULL without format strings */
 } sp_match_device_batch_t;
 int sp_matcher_ctx_match_docs_device(sp_matcher_ctx_t* c, const void* d_lexems, const void* d_origseg,
                                      const void* d_doc_offsets, size_t ndocs, size_t nlexems,

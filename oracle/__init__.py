@@ -33,6 +33,8 @@ class _L2Out(ctypes.Structure):
         ("doc_result_offsets", ctypes.POINTER(ctypes.c_uint64)),
         ("doc_stats", ctypes.POINTER(ctypes.c_uint64)),
         ("doc_status", ctypes.POINTER(ctypes.c_int32)),
+        ("result_format", ctypes.POINTER(ctypes.c_uint32)),
+        ("item_format", ctypes.POINTER(ctypes.c_uint32)),
     ]
 
 
@@ -151,11 +153,17 @@ class L2Matcher:
             offs = np.ctypeslib.as_array(out.doc_result_offsets, shape=(ndocs + 1,)).copy()
             stats = np.ctypeslib.as_array(out.doc_stats, shape=(ndocs * 4 + 1,))[:ndocs * 4].reshape(-1, 4).copy()
             status = np.ctypeslib.as_array(out.doc_status, shape=(ndocs + 1,))[:ndocs].copy()
+            rfmt = ifmt = None
+            if out.result_format:
+                rfmt = np.ctypeslib.as_array(out.result_format, shape=(out.nresults + 1,))[:out.nresults].copy()
+                ifmt = np.ctypeslib.as_array(out.item_format, shape=(out.nitems * 2 + 2,))[:out.nitems * 2].reshape(-1, 2).copy()
         finally:
             self._L.orc_l2_free_out(ctypes.byref(out))
         if rc != 0:
             raise OracleError(self._L.orc_l2_last_error(self._h).decode())
-        return L2Results(res, items, offs, stats, status)
+        r = L2Results(res, items, offs, stats, status)
+        r.result_format, r.item_format = rfmt, ifmt
+        return r
 
 
 POSBIND = {"content": 0, "successor": 1, "predecessor": 2, "unique": 3}

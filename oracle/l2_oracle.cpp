@@ -1037,8 +1037,7 @@ void MatcherContext::putInput( const Lexem& term)
 	++m_nofEvents;
 }
 
-// patternMatcher.cpp:164-190 (format strings are a "next" row, SURVEY 8(f).1: the
-// formathandle!=0 branch is treated as "no nested expansion", items carry positions only)
+// patternMatcher.cpp:164-190
 void MatcherContext::gatherResultItems( std::vector<ResultItem>& out, u32 dataref) const
 {
 	u32 itr = m_sm->getEventDataItemListIdx( dataref-1);
@@ -1050,6 +1049,11 @@ void MatcherContext::gatherResultItems( std::vector<ResultItem>& out, u32 datare
 		ri.start_ordpos = item->data.start_ordpos; ri.end_ordpos = item->data.end_ordpos;
 		ri.start_origseg = item->data.start_origseg; ri.start_origpos = item->data.start_origpos;
 		ri.end_origseg = item->data.end_origseg; ri.end_origpos = item->data.end_origpos;
+		ri.formatHandle = item->data.formathandle;
+		if (item->data.formathandle && item->data.subdataref)
+		{
+			gatherResultItems( ri.args, item->data.subdataref);	// :175-179: arguments of the item's format string
+		}
 		out.push_back( ri);
 		if (item->data.subdataref && !item->data.formathandle)
 		{
@@ -1107,6 +1111,8 @@ std::vector<MatchResult> MatcherContext::fetchResults() const
 		m.start_ordpos = r.start_ordpos; m.end_ordpos = r.end_ordpos;
 		m.start_origseg = r.start_origseg; m.start_origpos = r.start_origpos;
 		m.end_origseg = r.end_origseg; m.end_origpos = r.end_origpos;
+		m.formatHandle = r.formatHandle;
+		// :253-266: with a format handle the gathered list feeds the format string, without one it is the item list
 		if (r.eventDataReferenceIdx) gatherResultItems( m.items, r.eventDataReferenceIdx);
 		rt.push_back( m);
 	}

@@ -328,11 +328,20 @@ private:
 // Input lexem (analyzer::PatternLexem stand-in)
 struct Lexem { u32 id, ordpos, origseg, origpos, origsize; };
 
-struct ResultItem { u32 variable, start_ordpos, end_ordpos, start_origseg, start_origpos, end_origseg, end_origpos; };
+// `formatHandle` != 0: the reference evaluates that format string over `args` (its subresitemlist,
+// patternMatcher.cpp:172-181 / :253-262) into the item / result value; the formatter itself is in
+// strusAnalyzer (not in the reference repository), so the oracle keeps handle + arguments.
+struct ResultItem
+{
+	u32 variable, start_ordpos, end_ordpos, start_origseg, start_origpos, end_origseg, end_origpos;
+	u32 formatHandle;
+	std::vector<ResultItem> args;
+};
 struct MatchResult
 {
 	u32 resultHandle, start_ordpos, end_ordpos, start_origseg, start_origpos, end_origseg, end_origpos;
-	std::vector<ResultItem> items;
+	u32 formatHandle;
+	std::vector<ResultItem> items;	// the result's items, or the format arguments when formatHandle != 0 (the reference's item list is empty then)
 };
 
 // patternMatcher.cpp:345-733 (PatternMatcherInstance) restated
@@ -371,6 +380,9 @@ private:
 	bool m_exclusive;
 	u32 m_maxResultSize;
 	u32 m_nofFormats = 0;
+public:
+	u32 nofFormats() const {return m_nofFormats;}
+private:
 };
 
 // patternMatcher.cpp:107-341 (PatternMatcherContext) restated

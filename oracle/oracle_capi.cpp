@@ -104,7 +104,31 @@ struct OrcL2Out
 	uint64_t* doc_result_offsets; // ndocs+1
 	uint64_t* doc_stats;	// ndocs x 4: programsInstalled, altKeyProgramsInstalled, signalsFired, sum of open triggers
 	int32_t* doc_status;	// ndocs: 0 ok, -1 error
+	uint32_t* result_format;// nresults (NULL when the matcher has no format strings)
+	uint32_t* item_format;	// nitems x {format handle, nsub}: the nsub records after an item with a format are its arguments
 };
+
+namespace {
+uint64_t countItems( const std::vector<ResultItem>& list)
+{
+	uint64_t n = list.size();
+	for (std::size_t i=0; i<list.size(); ++i) n += countItems( list[i].args);
+	return n;
+}
+void writeItems( const std::vector<ResultItem>& list, OrcL2Out* out, uint64_t& ip)
+{
+	for (std::size_t ii=0; ii<list.size(); ++ii)
+	{
+		const ResultItem& it = list[ii];
+		const uint64_t at = ip++;
+		uint32_t* q = out->items + at*7;
+		q[0]=it.variable; q[1]=it.start_ordpos; q[2]=it.end_ordpos; q[3]=it.start_origseg; q[4]=it.start_origpos;
+		q[5]=it.end_origseg; q[6]=it.end_origpos;
+		writeItems( it.args, out, ip);
+		if (out->item_format) { out->item_format[ 2*at] = it.formatHandle; out->item_format[ 2*at+1] = (uint32_t)(ip - at - 1); }
+	}
+}
+}
 
 // lexems: n x 5 u32 (id, ordpos, origseg, origpos, origsize); doc_offsets: ndocs+1 lexem indices.
 // One MatcherContext per document (testRandomTokenPatternMatch.cpp:130-146), documents spread over
@@ -156,12 +180,18 @@ int orc_l2_run_docs( void* hp, const uint32_t* lexems, const uint64_t* doc_offse
 	for (uint64_t di=0; di<ndocs; ++di)
 	{
 		nres += perdoc[di].size();
-		for (std::size_t ri=0; ri<perdoc[di].size(); ++ri) nitems += perdoc[di][ri].items.size();
+		for (std::size_t ri=0; ri<perdoc[di].size(); ++ri) nitems += countItems( perdoc[di][ri].items);
 	}
 	out->nresults = nres; out->nitems = nitems;
 	out->results = (uint32_t*)std::malloc( (nres*9+1)*sizeof(uint32_t));
 	out->items = (uint32_t*)std::malloc( (nitems*7+1)*sizeof(uint32_t));
 	out->doc_result_offsets = (uint64_t*)std::malloc( (ndocs+1)*sizeof(uint64_t));
+	out->result_format = 0; out->item_format = 0;
+	if (h->inst.nofFormats())
+	{
+		out->result_format = (uint32_t*)std::malloc( (nres+1)*sizeof(uint32_t));
+		out->item_format = (uint32_t*)std::malloc( (nitems+1)*2*sizeof(uint32_t));
+	}
 	uint64_t rp=0, ip=0;
 	for (uint64_t di=0; di<ndocs; ++di)
 	{
@@ -171,14 +201,9 @@ int orc_l2_run_docs( void* hp, const uint32_t* lexems, const uint64_t* doc_offse
 			const MatchResult& m = perdoc[di][ri];
 			uint32_t* r = out->results + rp*9;
 			r[0]=m.resultHandle; r[1]=m.start_ordpos; r[2]=m.end_ordpos; r[3]=m.start_origseg; r[4]=m.start_origpos;
-			r[5]=m.end_origseg; r[6]=m.end_origpos; r[7]=(uint32_t)ip; r[8]=(uint32_t)m.items.size();
-			for (std::size_t ii=0; ii<m.items.size(); ++ii,++ip)
-			{
-				const ResultItem& it = m.items[ii];
-				uint32_t* q = out->items + ip*7;
-				q[0]=it.variable; q[1]=it.start_ordpos; q[2]=it.end_ordpos; q[3]=it.start_origseg; q[4]=it.start_origpos;
-				q[5]=it.end_origseg; q[6]=it.end_origpos;
-			}
+			r[5]=m.end_origseg; r[6]=m.end_origpos; r[7]=(uint32_t)ip; r[8]=(uint32_t)countItems( m.items);
+			if (out->result_format) out->result_format[ rp] = m.formatHandle;
+			writeItems( m.items, out, ip);
 		}
 	}
 	out->doc_result_offsets[ ndocs] = rp;
@@ -189,7 +214,7 @@ int orc_l2_run_docs( void* hp, const uint32_t* lexems, const uint64_t* doc_offse
 void orc_l2_free_out( OrcL2Out* out)
 {
 	std::free( out->results); std::free( out->items); std::free( out->doc_result_offsets);
-	std::free( out->doc_stats); std::free( out->doc_status);
+	std::free( out->doc_stats); std::free( out->doc_status); std::free( out->result_format); std::free( out->item_format);
 	std::memset( out, 0, sizeof(*out));
 }
 

@@ -31,7 +31,9 @@ class PatternError(RuntimeError):
 class MatchBatch:
     """Results of a batch of documents (host copies)."""
 
-    def __init__(self, results, items, doc_offsets, stats, status):
+    def __init__(self, results, items, doc_offsets, stats, status, result_format=None, item_format=None):
+        self.result_format = result_format  # (n,) u32 format handle per result, None without format strings
+        self.item_format = item_format      # (m, 2) u32 {format handle, nsub} per item (see resultformat.py)
         self.results = results          # (n, 9) u32: handle, ordpos, ordend, origseg, origpos, origendseg, origend, item_begin, item_count
         self.items = items              # (m, 7) u32: variable, ordpos, ordend, origseg, origpos, origendseg, origend
         self.doc_offsets = doc_offsets  # (ndocs+1,) u64
@@ -40,6 +42,14 @@ class MatchBatch:
 
     def doc(self, i):
         return self.results[self.doc_offsets[i]:self.doc_offsets[i + 1]]
+
+
+def _formats_of(b):
+    if not b.result_format:
+        return None, None
+    rf = np.ctypeslib.as_array(b.result_format, shape=(b.nresults + 1,))[:b.nresults].copy()
+    itf = np.ctypeslib.as_array(b.item_format, shape=(b.nitems * 2 + 2,))[:b.nitems * 2].reshape(-1, 2).copy()
+    return rf, itf
 
 
 class PatternMatcherContext:
@@ -89,6 +99,17 @@ class PatternMatcherContext:
             self._L.sp_free(items)
         return r, it
 
+    def fetchFormats(self, nresults, nitems):
+        """format handles of the results / items of the last fetchResults() (None, None without format strings)."""
+        rf = ctypes.POINTER(ctypes.c_uint32)()
+        itf = ctypes.POINTER(ctypes.c_uint32)()
+        self._L.sp_matcher_ctx_fetch_formats(self._h, ctypes.byref(rf), ctypes.byref(itf))
+        if not rf and not self._inst.formatCount():
+            return None, None
+        r = np.ctypeslib.as_array(rf, shape=(nresults + 1,))[:nresults].copy() if nresults else np.zeros(0, np.uint32)
+        i = np.ctypeslib.as_array(itf, shape=(nitems * 2 + 2,))[:nitems * 2].reshape(-1, 2).copy() if nitems else np.zeros((0, 2), np.uint32)
+        return r, i
+
     def getStatistics(self):
         st = capi.SpMatcherStats()
         self._L.sp_matcher_ctx_statistics(self._h, ctypes.byref(st))
@@ -118,9 +139,10 @@ class PatternMatcherContext:
             offs = np.ctypeslib.as_array(b.doc_result_offsets, shape=(ndocs + 1,)).copy()
             stats = np.ctypeslib.as_array(b.doc_stats, shape=(ndocs * 4 + 1,))[:ndocs * 4].reshape(-1, 4).copy()
             status = np.ctypeslib.as_array(b.doc_status, shape=(ndocs + 1,))[:ndocs].copy()
+            rfmt, ifmt = _formats_of(b)
         finally:
             self._L.sp_match_batch_free(ctypes.byref(b))
-        return MatchBatch(res, items, offs, stats, status)
+        return MatchBatch(res, items, offs, stats, status, rfmt, ifmt)
 
     # -- batch mode (device-resident buffers; pointers are raw device addresses, e.g. torch data_ptr())
     def matchDocsDevice(self, d_lexems, d_doc_offsets, ndocs, nlexems, stream=0, d_origseg=0):
@@ -152,9 +174,10 @@ class PatternMatcherContext:
             offs = np.ctypeslib.as_array(b.doc_result_offsets, shape=(ndocs + 1,)).copy()
             stats = np.ctypeslib.as_array(b.doc_stats, shape=(ndocs * 4 + 1,))[:ndocs * 4].reshape(-1, 4).copy()
             status = np.ctypeslib.as_array(b.doc_status, shape=(ndocs + 1,))[:ndocs].copy()
+            rfmt, ifmt = _formats_of(b)
         finally:
             self._L.sp_match_batch_free(ctypes.byref(b))
-        return MatchBatch(res, items, offs, stats, status)
+        return MatchBatch(res, items, offs, stats, status, rfmt, ifmt)
 
     def batchCounters(self):
         arr = (ctypes.c_uint64 * 8)()
@@ -241,6 +264,13 @@ class PatternMatcherInstance:
 
     def variableName(self, vid):
         s = self._L.sp_matcher_variable_name(self._h, vid)
+        return s.decode() if s else None
+
+    def formatCount(self):
+        return int(self._L.sp_matcher_format_count(self._h))
+
+    def formatString(self, handle):
+        s = self._L.sp_matcher_format_string(self._h, handle)
         return s.decode() if s else None
 
     def dumpTable(self):

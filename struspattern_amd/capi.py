@@ -35,6 +35,7 @@ class SpMatchBatch(ctypes.Structure):
         ("ndocs", ctypes.c_size_t), ("nresults", ctypes.c_size_t), ("nitems", ctypes.c_size_t),
         ("results", P(SpResult)), ("items", P(SpResultItem)),
         ("doc_result_offsets", P(c_u64)), ("doc_stats", P(c_u64)), ("doc_status", P(ctypes.c_int32)),
+        ("result_format", P(c_u32)), ("item_format", P(c_u32)),
     ]
 
 
@@ -53,6 +54,7 @@ class SpMatchDeviceBatch(ctypes.Structure):
     _fields_ = [
         ("ndocs", ctypes.c_size_t), ("d_results", c_vp), ("d_items", c_vp), ("d_doc_result_offsets", c_vp),
         ("d_doc_stats", c_vp), ("d_doc_status", c_vp), ("d_counters", c_vp),
+        ("d_result_format", c_vp), ("d_item_format", c_vp),
     ]
 
 
@@ -77,6 +79,9 @@ SIGNATURES = {
     "sp_matcher_variable_id": (c_u32, [c_vp, c_cp]),
     "sp_matcher_variable_name": (c_cp, [c_vp, c_u32]),
     "sp_matcher_dump_table": (ctypes.c_size_t, [c_vp, P(P(c_u32))]),
+    "sp_matcher_format_count": (c_u32, [c_vp]),
+    "sp_matcher_format_string": (c_cp, [c_vp, c_u32]),
+    "sp_matcher_ctx_fetch_formats": (ctypes.c_int, [c_vp, P(P(c_u32)), P(P(c_u32))]),
     "sp_matcher_ctx_create": (c_vp, [c_vp, ctypes.c_int]),
     "sp_matcher_ctx_free": (None, [c_vp]),
     "sp_matcher_ctx_last_error": (c_cp, [c_vp]),

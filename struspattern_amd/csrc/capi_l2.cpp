@@ -91,6 +91,9 @@ struct sp_matcher_ctx
 	DeviceBuffer dCursor, dCounters;
 	// batch buffers (grown on demand)
 	DeviceBuffer dLexems, dOrigseg, dDocOffsets, dResults, dItems, dDocRange, dDocStats, dDocStatus;
+	DeviceBuffer dResultFormat, dItemFormat;	// only for matchers with format strings
+	bool withFormats;
+	std::vector<uint32_t> curResultFormat, curItemFormat;	// of the last sp_matcher_ctx_fetch_results
 	uint64_t resultCapacity, itemCapacity, minResultCapacity, minItemCapacity;
 	size_t lastNdocs;
 	hipEvent_t evStart, evStop; bool evValid;
@@ -103,7 +106,7 @@ struct sp_matcher_ctx
 	sp_matcher_stats_t lastStats;
 
 	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),arenaWaves(0),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
-		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
+		,withFormats(false),lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
 		std::memset( &lastStats, 0, sizeof(lastStats));
@@ -160,6 +163,9 @@ const char* sp_matcher_pattern_name( const sp_matcher_t* m, uint32_t handle) { r
 uint32_t sp_matcher_variable_id( const sp_matcher_t* m, const char* name) { return m->compiler.variables().get( name); }
 const char* sp_matcher_variable_name( const sp_matcher_t* m, uint32_t variable) { return m->compiler.variables().key( variable); }
 
+uint32_t sp_matcher_format_count( const sp_matcher_t* m) { return m->compiler.formatCount(); }
+const char* sp_matcher_format_string( const sp_matcher_t* m, uint32_t format_handle) { return m->compiler.formatString( format_handle); }
+
 size_t sp_matcher_dump_table( const sp_matcher_t* m, uint32_t** out)
 {
 	std::vector<uint32_t> buf = m->compiler.dump();
@@ -198,6 +204,7 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 		c->keymask = (uint32_t)ft.keytab.size()-1;
 		c->nofStopWords = ft.nofStopWords;
 		c->arena.nStop = ft.nofStopWords;
+		c->withFormats = m->compiler.formatCount() != 0;
 		c->dCursor.alloc( 64);
 		c->dCounters.alloc( SPC_COUNT*sizeof(uint64_t));
 		HIP_CHECK( hipEventCreate( &c->evStart));
@@ -261,6 +268,13 @@ int sp_matcher_ctx_batch_fetch( sp_matcher_ctx_t* c, sp_match_batch_t* out)
 		std::vector<sp_result_item_t> rawitems( nitems+1);
 		if (nres) HIP_CHECK( hipMemcpy( raw.data(), c->dResults.ptr, nres*sizeof(sp_result_t), hipMemcpyDeviceToHost));
 		if (nitems) HIP_CHECK( hipMemcpy( rawitems.data(), c->dItems.ptr, nitems*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
+		std::vector<uint32_t> rawrf, rawif;
+		if (c->withFormats)
+		{
+			rawrf.resize( nres+1); rawif.resize( 2*nitems+2);
+			if (nres) HIP_CHECK( hipMemcpy( rawrf.data(), c->dResultFormat.ptr, nres*sizeof(uint32_t), hipMemcpyDeviceToHost));
+			if (nitems) HIP_CHECK( hipMemcpy( rawif.data(), c->dItemFormat.ptr, 2*nitems*sizeof(uint32_t), hipMemcpyDeviceToHost));
+		}
 		uint64_t total = 0, totalItems = 0;
 		for (size_t di=0; di<ndocs; ++di)
 		{
@@ -271,6 +285,12 @@ int sp_matcher_ctx_batch_fetch( sp_matcher_ctx_t* c, sp_match_batch_t* out)
 		out->results = (sp_result_t*)std::malloc( (total+1)*sizeof(sp_result_t));
 		out->items = (sp_result_item_t*)std::malloc( (totalItems+1)*sizeof(sp_result_item_t));
 		if (!out->results || !out->items) throw std::bad_alloc();
+		if (c->withFormats)
+		{
+			out->result_format = (uint32_t*)std::malloc( (total+1)*sizeof(uint32_t));
+			out->item_format = (uint32_t*)std::malloc( (totalItems+1)*2*sizeof(uint32_t));
+			if (!out->result_format || !out->item_format) throw std::bad_alloc();
+		}
 		uint64_t rp = 0, ip = 0;
 		for (size_t di=0; di<ndocs; ++di)
 		{
@@ -280,6 +300,11 @@ int sp_matcher_ctx_batch_fetch( sp_matcher_ctx_t* c, sp_match_batch_t* out)
 				sp_result_t r = raw[ range[ 2*di]+ri];
 				uint32_t ib = r.item_begin, ic = r.item_count;
 				r.item_begin = (uint32_t)ip;
+				if (c->withFormats)
+				{
+					out->result_format[ rp] = rawrf[ range[ 2*di]+ri];
+					for (uint32_t k=0; k<ic; ++k) { out->item_format[ 2*(ip+k)] = rawif[ 2*(ib+k)]; out->item_format[ 2*(ip+k)+1] = rawif[ 2*(ib+k)+1]; }
+				}
 				for (uint32_t k=0; k<ic; ++k) out->items[ ip++] = rawitems[ ib+k];
 				out->results[ rp++] = r;
 			}
@@ -365,6 +390,11 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		c->dItems.alloc( wantItems*sizeof(sp_result_item_t));
 		c->itemCapacity = wantItems;
 	}
+	if (c->withFormats)
+	{
+		c->dResultFormat.reserve( c->resultCapacity*sizeof(uint32_t));
+		c->dItemFormat.reserve( c->itemCapacity*2*sizeof(uint32_t));
+	}
 	c->dDocRange.reserve( (ndocs+1)*2*sizeof(uint64_t));
 	c->dDocStats.reserve( (ndocs+1)*4*sizeof(uint64_t));
 	c->dDocStatus.reserve( (ndocs+1)*sizeof(int32_t));
@@ -391,6 +421,8 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	P.docRange = (uint64_t*)c->dDocRange.ptr;
 	P.docStats = (uint64_t*)c->dDocStats.ptr;
 	P.docStatus = (int32_t*)c->dDocStatus.ptr;
+	P.withFormats = c->withFormats ? 1u : 0u;
+	P.resultFormat = (uint32_t*)c->dResultFormat.ptr; P.itemFormat = (uint32_t*)c->dItemFormat.ptr;
 
 #if defined(SPA_TRACE) || defined(SPA_POLL)
 	static uint32_t* traceHost = 0;
@@ -448,6 +480,8 @@ int sp_matcher_ctx_match_docs_device( sp_matcher_ctx_t* c, const void* d_lexems,
 			out->d_doc_result_offsets = c->dDocRange.ptr;
 			out->d_doc_stats = c->dDocStats.ptr; out->d_doc_status = c->dDocStatus.ptr;
 			out->d_counters = c->dCounters.ptr;
+			out->d_result_format = c->withFormats ? c->dResultFormat.ptr : 0;
+			out->d_item_format = c->withFormats ? c->dItemFormat.ptr : 0;
 		}
 	});
 }
@@ -465,6 +499,8 @@ int sp_matcher_ctx_match_lexed_device( sp_matcher_ctx_t* c, const void* d_lexems
 			out->d_doc_result_offsets = c->dDocRange.ptr;
 			out->d_doc_stats = c->dDocStats.ptr; out->d_doc_status = c->dDocStatus.ptr;
 			out->d_counters = c->dCounters.ptr;
+			out->d_result_format = c->withFormats ? c->dResultFormat.ptr : 0;
+			out->d_item_format = c->withFormats ? c->dItemFormat.ptr : 0;
 		}
 	});
 }
@@ -545,6 +581,13 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 		std::vector<sp_result_item_t> rawitems( nitems+1);
 		if (nres) HIP_CHECK( hipMemcpy( raw.data(), c->dResults.ptr, nres*sizeof(sp_result_t), hipMemcpyDeviceToHost));
 		if (nitems) HIP_CHECK( hipMemcpy( rawitems.data(), c->dItems.ptr, nitems*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
+		std::vector<uint32_t> rawrf, rawif;
+		if (c->withFormats)
+		{
+			rawrf.resize( nres+1); rawif.resize( 2*nitems+2);
+			if (nres) HIP_CHECK( hipMemcpy( rawrf.data(), c->dResultFormat.ptr, nres*sizeof(uint32_t), hipMemcpyDeviceToHost));
+			if (nitems) HIP_CHECK( hipMemcpy( rawif.data(), c->dItemFormat.ptr, 2*nitems*sizeof(uint32_t), hipMemcpyDeviceToHost));
+		}
 		// regroup by document (the device appends whole documents in completion order)
 		uint64_t total = 0, totalItems = 0;
 		for (size_t di=0; di<ndocs; ++di)
@@ -556,6 +599,12 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 		out->results = (sp_result_t*)std::malloc( (total+1)*sizeof(sp_result_t));
 		out->items = (sp_result_item_t*)std::malloc( (totalItems+1)*sizeof(sp_result_item_t));
 		if (!out->results || !out->items) throw std::bad_alloc();
+		if (c->withFormats)
+		{
+			out->result_format = (uint32_t*)std::malloc( (total+1)*sizeof(uint32_t));
+			out->item_format = (uint32_t*)std::malloc( (totalItems+1)*2*sizeof(uint32_t));
+			if (!out->result_format || !out->item_format) throw std::bad_alloc();
+		}
 		uint64_t rp = 0, ip = 0;
 		// `exclusive` option: covered results are dropped on the way out (src/patternMatcher.cpp:192-246, :278-289)
 		const bool exclusive = c->inst->compiler.exclusive();
@@ -587,6 +636,11 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 				sp_result_t r = raw[ b+ri];
 				uint32_t ib = r.item_begin, ic = r.item_count;
 				r.item_begin = (uint32_t)ip;
+				if (c->withFormats)
+				{
+					out->result_format[ rp] = rawrf[ b+ri];
+					for (uint32_t k=0; k<ic; ++k) { out->item_format[ 2*(ip+k)] = rawif[ 2*(ib+k)]; out->item_format[ 2*(ip+k)+1] = rawif[ 2*(ib+k)+1]; }
+				}
 				for (uint32_t k=0; k<ic; ++k) out->items[ ip++] = rawitems[ ib+k];
 				out->results[ rp++] = r;
 			}
@@ -607,7 +661,7 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 void sp_match_batch_free( sp_match_batch_t* b)
 {
 	std::free( b->results); std::free( b->items); std::free( b->doc_result_offsets);
-	std::free( b->doc_stats); std::free( b->doc_status);
+	std::free( b->doc_stats); std::free( b->doc_status); std::free( b->result_format); std::free( b->item_format);
 	std::memset( b, 0, sizeof(*b));
 }
 
@@ -655,10 +709,20 @@ int sp_matcher_ctx_fetch_results( sp_matcher_ctx_t* c, sp_result_t** results, si
 	c->lastStats.nofAltKeyProgramsInstalled = (double)b.doc_stats[1];
 	c->lastStats.nofSignalsFired = (double)b.doc_stats[2];
 	c->lastStats.nofTriggersAvgActive = c->curLexems.empty() ? 0.0 : (double)b.doc_stats[3] / (double)c->curLexems.size();
+	c->curResultFormat.clear(); c->curItemFormat.clear();
+	if (b.result_format) c->curResultFormat.assign( b.result_format, b.result_format + b.nresults);
+	if (b.item_format) c->curItemFormat.assign( b.item_format, b.item_format + 2*b.nitems);
 	*results = b.results; *nresults = b.nresults; b.results = 0;
 	if (items) { *items = b.items; b.items = 0; }
 	if (nitems) *nitems = b.nitems;
 	sp_match_batch_free( &b);
+	return SP_OK;
+}
+
+int sp_matcher_ctx_fetch_formats( sp_matcher_ctx_t* c, const uint32_t** result_format, const uint32_t** item_format)
+{
+	*result_format = c->withFormats ? c->curResultFormat.data() : 0;
+	*item_format = c->withFormats ? c->curItemFormat.data() : 0;
 	return SP_OK;
 }
 
@@ -671,6 +735,7 @@ int sp_matcher_ctx_statistics( sp_matcher_ctx_t* c, sp_matcher_stats_t* out)
 int sp_matcher_ctx_reset( sp_matcher_ctx_t* c)
 {
 	c->curLexems.clear(); c->curOrigseg.clear(); c->curHasSeg = false;
+	c->curResultFormat.clear(); c->curItemFormat.clear();
 	std::memset( &c->lastStats, 0, sizeof(c->lastStats));
 	return SP_OK;
 }

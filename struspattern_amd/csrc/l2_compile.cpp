@@ -200,6 +200,7 @@ void RuleCompiler::definePattern( const std::string& name, const std::string& fo
 	uint32_t handle = m_patterns.getOrCreate( name);
 	uint32_t outEvent = eventId( EV_REFERENCE, handle);
 	uint32_t format = formatstring.empty() ? 0 : ++m_formats;
+	if (format) m_formatStrings.push_back( formatstring);
 	uint32_t program = top.program;
 	if (!program)
 	{

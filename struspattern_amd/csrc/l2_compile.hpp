@@ -56,6 +56,8 @@ public:
 	uint32_t maxResultSize() const		{return m_maxResultSize;}
 	const SymbolIndex& patterns() const	{return m_patterns;}
 	const SymbolIndex& variables() const	{return m_variables;}
+	uint32_t formatCount() const		{return m_formats;}
+	const char* formatString( uint32_t handle) const	{return (handle && handle <= m_formatStrings.size()) ? m_formatStrings[ handle-1].c_str() : 0;}
 
 	void flatten( FlatTables& out) const;
 	// canonical dump (same format as oracle's orc_l2_dump_table, see oracle/oracle_capi.cpp)
@@ -92,6 +94,7 @@ private:
 	std::vector<Node> m_stack;
 	uint32_t m_exprEvents;
 	uint32_t m_formats;
+	std::vector<std::string> m_formatStrings;
 	float m_stopwordOccurrenceFactor;
 	float m_weightFactor;
 	uint32_t m_maxRange;

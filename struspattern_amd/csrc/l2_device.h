@@ -50,6 +50,10 @@ struct L2Params
 	uint64_t* docRange;		// ndocs x (first result, count)
 	uint64_t* docStats;		// ndocs x 4
 	int32_t* docStatus;		// ndocs
+	// patterns with format strings only (withFormats != 0)
+	uint32_t withFormats;
+	uint32_t* resultFormat;		// [resultCapacity] format handle of the result (0 = none)
+	uint32_t* itemFormat;		// [itemCapacity] x {format handle, records of the item's subtree that follow it}
 	uint32_t* trace;		// debug builds only (host-mapped), else NULL
 };
 

@@ -111,7 +111,7 @@ struct Rule		// rule instance + its action slot (hpp:87-104, :171-186) + 4 trigg
 struct Item { u32 variable, next, _a, _b; EvData d; };	// captured variable (hpp:262-271), 48 B
 struct Follow { EvData d; u32 event, _a, _b, _c; };	// 48 B
 struct StopLog { EvData d; u32 timestamp, _a, _b, _c; };// 48 B
-struct StagedResult { u32 handle, sord, eord, sseg, spos, eseg, epos, dataRef; };	// 32 B
+struct StagedResult { u32 program, sord, eord, sseg, spos, eseg, epos, dataRef; };	// 32 B; result and format handle are read from programs[program] at document end
 
 // ---------------------------------------------------------------- where the per-document state lives
 // Records and lists: a per-wave arena in HBM whose capacities grow on demand (layout: ArenaLayout).
@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void fireSignal( WSR w, KP P, u32 r, u32 sigtype, u32
 				if (w.nStaged < P.arena.maxStaged)
 				{
 					StagedResult* S = &STAGED[ w.nStaged++];
-					st4( S, handle, start_ordpos, end_ordpos, start_origseg);
+					st4( S, q1.w, start_ordpos, end_ordpos, start_origseg);
 					st4( W( S) + 4, start_origpos, d.eseg, d.epos, dataRef);
 					if (dataRef) addRef( w, P, dataRef);
 				}
@@ -1543,7 +1543,7 @@ __device__ __forceinline__ void installBatch( WSR w, KP P, u32 keyevent, u32 lb,
 				if (emitResult)
 				{
 					StagedResult* S = &STAGED[ w.nStaged + (u32)__popcll( rm & lanesBelow())];
-					st4( S, g_handle, start_ordpos, end_ordpos, start_origseg);
+					st4( S, program, start_ordpos, end_ordpos, start_origseg);
 					st4( W( S) + 4, start_origpos, d.eseg, d.epos, dataRef);
 				}
 				w.nStaged += nr;
@@ -1689,6 +1689,47 @@ __device__ __forceinline__ u32 walkItems( WSR w, KP P, u32 ref, u32* out)
 	return n;
 }
 
+// Patterns with format strings (patternMatcher.cpp:172-188): an item that carries a format handle keeps
+// its sub-items to itself (they are the arguments of its format string, not items of the result).  The
+// output keeps them in place: item i is followed by the `nsub` records of its subtree and
+// fmtout[2i..2i+1] = {format handle, nsub}; the host evaluates the format strings from that.
+__device__ __forceinline__ u32 walkItemsFormatted( WSR w, KP P, u32 ref, u32* out, u32* fmtout)
+{
+	u32 n = 0, sp = 0;
+	u32 cur = ldu( &REFS[ 2*(ref-1)]);
+	for (u32 guard=0;; ++guard)
+	{
+		if (guard > (1u<<22)) { w.err = SPD_ERR_INTERNAL; break; }
+		if (!cur)
+		{
+			if (!sp) break;
+			sp -= 2;
+			cur = ldu( &GSTACK[ sp]);
+			const u32 owner = ldu( &GSTACK[ sp+1]);		// 1-based index of the formatted item whose subtree ends here
+			if (owner && out) fmtout[ 2*(u64)(owner-1)+1] = n - owner;
+			continue;
+		}
+		const HItem* I = &ITEMS[ cur-1];
+		EvData d; ldEv( d, &I->d);
+		if (out)
+		{
+			u32* o = out + (u64)n*7;
+			o[0] = ldu( &I->variable); o[1] = d.sord; o[2] = d.eord; o[3] = d.sseg; o[4] = d.spos; o[5] = d.eseg; o[6] = d.epos;
+			fmtout[ 2*(u64)n] = d.fmt; fmtout[ 2*(u64)n+1] = 0;
+		}
+		++n;
+		cur = ldu( &I->next);
+		if (d.sub)
+		{
+			if (sp+2 > P.arena.maxGStack) { ARENA_FAIL; break; }
+			GSTACK[ sp] = cur; GSTACK[ sp+1] = d.fmt ? n : 0u;
+			sp += 2;
+			cur = ldu( &REFS[ 2*(d.sub-1)]);
+		}
+	}
+	return n;
+}
+
 // the same walk done by one lane for its own result (independent loads per lane); sub-lists nest
 // rarely and shallowly: a lane that would need more than 4 levels reports `deep` and the document's
 // items are written by the sequential walk instead
@@ -1824,8 +1865,8 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 		{
 			// pass 1: every lane walks the item list of its own result and counts
 			u32 total = 0;
-			bool sequential = false;
-			for (u32 base=0; base<nres; base+=64)
+			bool sequential = P.withFormats != 0;	// format arguments nest: those item lists are walked one by one
+			for (u32 base=0; base<nres && !sequential; base+=64)
 			{
 				const u32 ri = base + LANE;
 				u32 n = 0; bool deep = false;
@@ -1846,7 +1887,7 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 				for (u32 ri=0; ri<nres && !w.err; ++ri)
 				{
 					u32 ref = ldu( &STAGED[ ri].dataRef);
-					if (ref) total += walkItems( w, P, ref, 0);
+					if (ref) total += P.withFormats ? walkItemsFormatted( w, P, ref, 0, 0) : walkItems( w, P, ref, 0);
 				}
 			}
 			u64 itemBase = 0;
@@ -1865,7 +1906,7 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 				for (u32 ri=0; ri<nres; ++ri)
 				{
 					u32 ref = ldu( &STAGED[ ri].dataRef);
-					u32 n = ref ? walkItems( w, P, ref, P.items + ip*7) : 0;
+					u32 n = !ref ? 0u : P.withFormats ? walkItemsFormatted( w, P, ref, P.items + ip*7, P.itemFormat + ip*2) : walkItems( w, P, ref, P.items + ip*7);
 					u32* o = P.results + (resBase + ri)*9;
 					o[7] = (u32)ip; o[8] = n;
 					ip += n;
@@ -1901,7 +1942,9 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 			{
 				const StagedResult* S = &STAGED[ ri];
 				u32* o = P.results + (resBase + ri)*9;
-				o[0] = S->handle; o[1] = S->sord; o[2] = S->eord; o[3] = S->sseg; o[4] = S->spos; o[5] = S->eseg; o[6] = S->epos;
+				const uint4 g0 = ld4( &P.programs[ S->program]);		// {initsigval,initcount,event,resultHandle}
+				o[0] = g0.w; o[1] = S->sord; o[2] = S->eord; o[3] = S->sseg; o[4] = S->spos; o[5] = S->eseg; o[6] = S->epos;
+				if (P.withFormats) P.resultFormat[ resBase + ri] = P.programs[ S->program].formatHandle;
 				if (!P.withItems) { o[7] = 0; o[8] = 0; }
 			}
 		}

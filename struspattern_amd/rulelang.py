@@ -123,6 +123,7 @@ class Program:
         self.patterns = []        # pattern names in definition order
         self.symbols = {}         # (token name, text) -> symbol id
         self.variables = []       # variable names in order of first use
+        self.formats = []         # non-empty format strings in definePattern order (format handle = index+1)
         self._next_id = 1
 
     def _new_id(self):
@@ -262,6 +263,8 @@ def load(text, lexer, matcher, posbind="content"):
             sc2.expect("]")
         sc2.expect(";")
         matcher.definePattern(name, fmt, not private)
+        if fmt:
+            prg.formats.append(fmt)
         if name not in prg.patterns:
             prg.patterns.append(name)
 
@@ -275,6 +278,13 @@ def name_tables(prg, matcher):
     pat = {int(matcher.patternId(n)): n for n in prg.patterns}
     var = {int(matcher.variableId(n)): n for n in prg.variables}
     return (lambda h: pat.get(int(h), "?")), (lambda v: var.get(int(v), "?"))
+
+
+def formatter(prg, matcher):
+    """resultformat.Formatter over the program's name tables and format strings."""
+    from . import resultformat
+    pn, vn = name_tables(prg, matcher)
+    return resultformat.Formatter(pn, vn, lambda h: prg.formats[h - 1] if 0 < h <= len(prg.formats) else None)
 
 
 def format_tokens(prg, text, lexems, origin=0):
