@@ -10,8 +10,10 @@
 #include "strus/errorBufferInterface.hpp"
 #include "strus/patternLexerInterface.hpp"
 #include "strus/patternMatcherInterface.hpp"
+#include "strus/lib/pattern_resultformat.hpp"
 #include "../../include/strus_pattern_amd.h"
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -130,7 +132,8 @@ private:
 class MatcherContext :public PatternMatcherContextInterface
 {
 public:
-	MatcherContext( sp_matcher_ctx_t* h, const sp_matcher_t* inst, ErrorBufferInterface* e) :m_h(h),m_inst(inst),m_errorhnd(e){}
+	MatcherContext( sp_matcher_ctx_t* h, const sp_matcher_t* inst, const std::vector<const PatternResultFormat*>* formats, ErrorBufferInterface* e)
+		:m_h(h),m_inst(inst),m_formats(formats),m_errorhnd(e),m_resultFormatContext(e){}
 	virtual ~MatcherContext() { sp_matcher_ctx_free( m_h); }
 	virtual void putInput( const analyzer::PatternLexem& term)
 	{
@@ -149,19 +152,33 @@ public:
 			m_errorhnd->report( codeOf( rc), "failed to fetch pattern match result: %s", sp_matcher_ctx_last_error( m_h));
 			return rt;
 		}
-		rt.reserve( nres);
-		for (size_t ri=0; ri<nres; ++ri)
+		const uint32_t* resfmt = 0; const uint32_t* itemfmt = 0;
+		(void)sp_matcher_ctx_fetch_formats( m_h, &resfmt, &itemfmt);
+		try
 		{
-			const sp_result_t& r = res[ri];
-			std::vector<analyzer::PatternMatcherResultItem> il;
-			for (uint32_t k=0; k<r.item_count; ++k)
+			rt.reserve( nres);
+			for (size_t ri=0; ri<nres; ++ri)
 			{
-				const sp_result_item_t& it = items[ r.item_begin + k];
-				il.push_back( analyzer::PatternMatcherResultItem( sp_matcher_variable_name( m_inst, it.variable), 0/*value*/, it.ordpos, it.ordend,
-						analyzer::Position( (int)it.origseg, (int)it.origpos), analyzer::Position( (int)it.origendseg, (int)it.origend)));
+				const sp_result_t& r = res[ri];
+				// src/patternMatcher.cpp:248-269: a result with a format string gets a value built from
+				// its items and an empty item list, any other result keeps its items
+				std::vector<analyzer::PatternMatcherResultItem> il;
+				gatherResultItems( il, items, itemfmt, r.item_begin, r.item_begin + r.item_count);
+				const char* value = 0;
+				const uint32_t fmt = resfmt ? resfmt[ ri] : 0;
+				if (fmt)
+				{
+					value = m_resultFormatContext.map( formatOf( fmt), il.data(), il.size());
+					il.clear();
+				}
+				rt.push_back( analyzer::PatternMatcherResult( sp_matcher_pattern_name( m_inst, r.handle), value, r.ordpos, r.ordend,
+						analyzer::Position( (int)r.origseg, (int)r.origpos), analyzer::Position( (int)r.origendseg, (int)r.origend), il));
 			}
-			rt.push_back( analyzer::PatternMatcherResult( sp_matcher_pattern_name( m_inst, r.handle), 0/*value*/, r.ordpos, r.ordend,
-					analyzer::Position( (int)r.origseg, (int)r.origpos), analyzer::Position( (int)r.origendseg, (int)r.origend), il));
+		}
+		catch (const std::exception& e)
+		{
+			m_errorhnd->report( ErrorCodeRuntimeError, "failed to fetch pattern match result: %s", e.what());
+			rt.clear();
 		}
 		sp_free( res); sp_free( items);
 		return rt;
@@ -179,18 +196,52 @@ public:
 		}
 		return stats;
 	}
-	virtual void reset() { sp_matcher_ctx_reset( m_h); }
+	virtual void reset() { sp_matcher_ctx_reset( m_h); m_resultFormatContext.clear(); }
 private:
+	const PatternResultFormat* formatOf( uint32_t handle) const
+	{
+		if (!m_formats || !handle || handle > m_formats->size() || !(*m_formats)[ handle-1]) throw std::runtime_error( "result refers to an undefined format string");
+		return (*m_formats)[ handle-1];
+	}
+	// src/patternMatcher.cpp:164-190 over the flattened records: an item with a format handle is followed
+	// by the records of its format arguments (include/strus_pattern_amd.h, "result format strings")
+	void gatherResultItems( std::vector<analyzer::PatternMatcherResultItem>& out, const sp_result_item_t* items, const uint32_t* itemfmt, size_t begin, size_t end)
+	{
+		for (size_t i=begin; i<end; ++i)
+		{
+			const sp_result_item_t& it = items[ i];
+			const char* value = 0;
+			const uint32_t fmt = itemfmt ? itemfmt[ 2*i] : 0;
+			if (fmt)
+			{
+				const size_t nsub = itemfmt[ 2*i+1];
+				std::vector<analyzer::PatternMatcherResultItem> args;
+				gatherResultItems( args, items, itemfmt, i+1, i+1+nsub);
+				value = m_resultFormatContext.map( formatOf( fmt), args.data(), args.size());
+				i += nsub;
+			}
+			out.push_back( analyzer::PatternMatcherResultItem( sp_matcher_variable_name( m_inst, it.variable), value, it.ordpos, it.ordend,
+					analyzer::Position( (int)it.origseg, (int)it.origpos), analyzer::Position( (int)it.origendseg, (int)it.origend)));
+		}
+	}
 	sp_matcher_ctx_t* m_h;
 	const sp_matcher_t* m_inst;
+	const std::vector<const PatternResultFormat*>* m_formats;
 	ErrorBufferInterface* m_errorhnd;
+	PatternResultFormatContext m_resultFormatContext;
 };
 
-class MatcherInstance :public PatternMatcherInstanceInterface
+class MatcherInstance :public PatternMatcherInstanceInterface, public PatternResultFormatVariableMap
 {
 public:
-	explicit MatcherInstance( ErrorBufferInterface* e) :m_h(sp_matcher_create()),m_errorhnd(e) { if (!m_h) throw std::bad_alloc(); }
+	explicit MatcherInstance( ErrorBufferInterface* e) :m_h(sp_matcher_create()),m_errorhnd(e),m_resultFormatTable(this,e) { if (!m_h) throw std::bad_alloc(); }
 	virtual ~MatcherInstance() { sp_matcher_free( m_h); }
+	// PatternResultFormatVariableMap (src/patternMatcher.cpp:46-66)
+	virtual const char* getVariable( const std::string& name_) const
+	{
+		uint32_t id = sp_matcher_variable_id( m_h, name_.c_str());
+		return id ? sp_matcher_variable_name( m_h, id) : 0;
+	}
 	virtual void defineTermFrequency( unsigned int termid, double df)
 	{ check( sp_matcher_define_term_frequency( m_h, termid, df), "failed to define term frequency: %s"); }
 	virtual void pushTerm( unsigned int termid)
@@ -205,12 +256,26 @@ public:
 	virtual void attachVariable( const std::string& name_)
 	{ check( sp_matcher_attach_variable( m_h, name_.c_str()), "failed to attach variable to top element of the pattern match expression stack: %s"); }
 	virtual void definePattern( const std::string& name_, const std::string& formatstring, bool visible)
-	{ check( sp_matcher_define_pattern( m_h, name_.c_str(), formatstring.c_str(), visible ? 1 : 0), "failed to close pattern definition on the pattern match expression stack: %s"); }
+	{
+		// src/patternMatcher.cpp:561-566: format handle = position in the list of format strings, as in the C-ABI
+		const PatternResultFormat* fmt = 0;
+		if (!formatstring.empty())
+		{
+			try { fmt = m_resultFormatTable.createResultFormat( formatstring.c_str()); }
+			catch (const std::bad_alloc&) { m_errorhnd->report( ErrorCodeOutOfMem, "memory allocation error in %s", "strus pattern"); return; }
+			if (!fmt) return;
+		}
+		if (check( sp_matcher_define_pattern( m_h, name_.c_str(), formatstring.c_str(), visible ? 1 : 0), "failed to close pattern definition on the pattern match expression stack: %s")
+		&&  !formatstring.empty())
+		{
+			m_resultFormatHandles.push_back( fmt);
+		}
+	}
 	virtual PatternMatcherContextInterface* createContext() const
 	{
 		sp_matcher_ctx_t* c = sp_matcher_ctx_create( m_h, 0/*device*/);
 		if (!c) { m_errorhnd->report( ErrorCodeRuntimeError, "failed to create pattern match context: %s", sp_matcher_last_error( m_h)); return 0; }
-		try { return new MatcherContext( c, m_h, m_errorhnd); }
+		try { return new MatcherContext( c, m_h, &m_resultFormatHandles, m_errorhnd); }
 		catch (const std::bad_alloc&) { sp_matcher_ctx_free( c); m_errorhnd->report( ErrorCodeOutOfMem, "memory allocation error in %s", "strus pattern"); return 0; }
 	}
 	virtual void defineOption( const std::string& name_, double value)
@@ -228,6 +293,8 @@ private:
 	}
 	sp_matcher_t* m_h;
 	ErrorBufferInterface* m_errorhnd;
+	PatternResultFormatTable m_resultFormatTable;
+	std::vector<const PatternResultFormat*> m_resultFormatHandles;
 };
 
 class Matcher :public PatternMatcherInterface

@@ -10,6 +10,7 @@
 #include "strus/patternLexerInterface.hpp"
 #include "strus/patternMatcherInterface.hpp"
 #include "strus/analyzerModule.hpp"
+#include "strus/lib/pattern_resultformat.hpp"
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -134,6 +135,79 @@ static void testCharRegexMatch( strus::PatternLexerInterface* pl, ErrorBuffer& e
 	std::cerr << "charRegexMatch OK (" << result.size() << " lexems); compile error text: " << err.fetchError() << std::endl;
 }
 
+// Result format strings through the C++ interface (src/patternMatcher.cpp:164-190, :248-269): the money
+// example of the reference's web page (doc/webpage/introduction_struspattern.htm:146-160) on token ids.
+static std::string resolveValue( const char* value, const std::string& src)
+{
+	std::string rt;
+	strus::PatternResultFormatChunk chunk;
+	char const* vi = value;
+	while (strus::PatternResultFormatChunk::parseNext( chunk, vi))
+	{
+		if (chunk.value) rt.append( chunk.value, chunk.valuesize);
+		else rt.append( src, chunk.start_pos, chunk.end_pos - chunk.start_pos);
+	}
+	return rt;
+}
+
+static void testResultFormat( strus::PatternMatcherInterface* pt, ErrorBuffer& err)
+{
+	enum {AMOUNT=1, CURRENCY_CHF=2, CURRENCY_EUR=3};
+	const std::string src = "3'645 Eur";
+	std::unique_ptr<strus::PatternMatcherInstanceInterface> inst( pt->createInstance());
+	inst->pushTerm( CURRENCY_CHF); inst->definePattern( "Currency", "CHF", true);
+	inst->pushTerm( CURRENCY_EUR); inst->definePattern( "Currency", "EUR", true);
+	inst->pushTerm( AMOUNT); inst->attachVariable( "value");
+	inst->pushPattern( "Currency"); inst->attachVariable( "currency");
+	inst->pushExpression( strus::PatternMatcherInstanceInterface::OpSequenceImm, 2, 2, 0);
+	inst->definePattern( "MoneyAmount", "{currency} {value}", true);
+	inst->pushTerm( AMOUNT); inst->attachVariable( "value");
+	inst->pushPattern( "Currency"); inst->attachVariable( "currency");
+	inst->pushExpression( strus::PatternMatcherInstanceInterface::OpSequenceImm, 2, 2, 0);
+	inst->definePattern( "Plain", "", true);
+	inst->compile();
+	if (err.hasError()) throw std::runtime_error( std::string("resultFormat: error creating automaton: ") + err.fetchError());
+	std::unique_ptr<strus::PatternMatcherContextInterface> ctx( inst->createContext());
+	if (!ctx.get()) throw std::runtime_error( std::string("failed to create context: ") + err.fetchError());
+	ctx->putInput( strus::analyzer::PatternLexem( AMOUNT, 1, strus::analyzer::Position( 0, 0), 5));
+	ctx->putInput( strus::analyzer::PatternLexem( CURRENCY_EUR, 2, strus::analyzer::Position( 0, 6), 3));
+	std::vector<strus::analyzer::PatternMatcherResult> results = ctx->fetchResults();
+	if (err.hasError()) throw std::runtime_error( std::string("resultFormat: error fetching results: ") + err.fetchError());
+	int seen = 0;
+	for (size_t i=0; i<results.size(); ++i)
+	{
+		const strus::analyzer::PatternMatcherResult& r = results[i];
+		std::string name( r.name());
+		if (name == "Currency")
+		{
+			if (!r.value() || std::string( r.value()) != "EUR" || !r.items().empty()) throw std::runtime_error( "resultFormat: constant format string");
+			seen |= 1;
+		}
+		else if (name == "MoneyAmount")
+		{
+			// the page: an input "3'645 Eur" would generate a value "EUR 3'645"
+			if (!r.value() || resolveValue( r.value(), src) != "EUR 3'645" || !r.items().empty()) throw std::runtime_error( "resultFormat: variable substitution");
+			seen |= 2;
+		}
+		else if (name == "Plain")
+		{
+			if (r.value() || r.items().size() != 2) throw std::runtime_error( "resultFormat: result without a format string");
+			const strus::analyzer::PatternMatcherResultItem& cur = r.items()[0];
+			const strus::analyzer::PatternMatcherResultItem& val = r.items()[1];
+			if (std::string( cur.name()) != "currency" || !cur.value() || std::string( cur.value()) != "EUR") throw std::runtime_error( "resultFormat: item value of a formatted sub-pattern");
+			if (std::string( val.name()) != "value" || val.value() || val.origpos().ofs() != 0 || val.origend().ofs() != 5) throw std::runtime_error( "resultFormat: plain item");
+			seen |= 4;
+		}
+	}
+	if (seen != 7 || results.size() != 3) throw std::runtime_error( "resultFormat: unexpected result set");
+	// an unknown variable in a format string is an error of definePattern
+	std::unique_ptr<strus::PatternMatcherInstanceInterface> bad( pt->createInstance());
+	bad->pushTerm( 1); bad->definePattern( "X", "{nosuchvariable}", true);
+	if (!err.hasError()) throw std::runtime_error( "resultFormat: unknown variable not reported");
+	(void)err.fetchError();
+	std::cerr << "resultFormat OK (" << results.size() << " results)" << std::endl;
+}
+
 int main( int argc, const char** argv)
 {
 	try
@@ -146,6 +220,7 @@ int main( int argc, const char** argv)
 		if (!pt.get() || !pl.get()) throw std::runtime_error( "failed to create the interfaces");
 		testSimpleTokenPatternMatch( pt.get(), err, argv[1]);
 		testCharRegexMatch( pl.get(), err, argv[2]);
+		testResultFormat( pt.get(), err);
 		// 2. through the module entry point, like the strus module loader
 		void* mod = dlopen( argv[3], RTLD_NOW | RTLD_LOCAL);
 		if (!mod) throw std::runtime_error( std::string("dlopen failed: ") + dlerror());

@@ -48,7 +48,9 @@ def main(argv=None):
             for line in rulelang.format_tokens(prg, doc, lb.doc(di)):
                 print(line)
         res = mb.doc(di)
-        for line in rulelang.format_results(doc, res, mb.items, mt.patternName, mt.variableName, origin=args.origin):
+        for line in rulelang.format_results(doc, res, mb.items, mt.patternName, mt.variableName, origin=args.origin,
+                                            result_format=mb.result_format, item_format=mb.item_format, format_string=mt.formatString,
+                                            first_result=int(mb.doc_offsets[di])):
             print(line)
     print("OK done")
     return 0

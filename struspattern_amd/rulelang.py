@@ -295,8 +295,21 @@ def format_tokens(prg, text, lexems, origin=0):
     return out
 
 
-def format_results(text, results, items, pattern_name, variable_name, origin=0):
-    """The result listing of strusPatternMatch: "Name [ordpos, origpos]: var [ordpos, origpos, size] 'text' ..."."""
+def format_results(text, results, items, pattern_name, variable_name, origin=0, result_format=None, item_format=None, format_string=None, first_result=0):
+    """The result listing of strusPatternMatch: "Name [ordpos, origpos]: var [ordpos, origpos, size] 'text' ...".
+    With format strings (result_format / item_format of the batch, `results` = rows first_result.. of it) a
+    result or item that has a value prints it instead of the text it covers."""
+    if result_format is not None:
+        from . import resultformat
+        fm = resultformat.Formatter(pattern_name, variable_name, format_string)
+        out = []
+        for r in fm.results(results, items, result_format[first_result:first_result + len(results)], item_format, text):
+            parts = ["%s [%d, %d, %d] '%s'" % (i.name, i.ordpos, i.origpos + origin, i.origend - i.origpos, i.value if i.value is not None else i.text(text)) for i in r.items]
+            head = "%s [%d, %d]:" % (r.name, r.ordpos, r.origpos + origin)
+            if r.value is not None:
+                head += " '%s'" % r.value
+            out.append((head + " " + " ".join(parts)).rstrip() if parts else head if r.value is not None else head + " ")
+        return out
     out = []
     for r in results:
         handle, ordpos, ordend, origseg, origpos, origendseg, origend, ib, ic = (int(x) for x in r)
