@@ -132,6 +132,9 @@ def main():
             else:
                 o = lex_out["o"]
                 mctx.matchLexedDevice(o.d_lexems, o.d_doc_ranges, ndocs, nlexems, stream)
+        if os.environ.get("SPA_BENCH_EXTRA_GROW"):      # experiment: a working-set arena larger than needed (locality / TLB reach)
+            for _ in range(int(os.environ["SPA_BENCH_EXTRA_GROW"])):
+                mctx.growArena()
         mc = size_until_ok(run_matcher, mctx.batchCounters, mctx.batchStatus,
                            lambda c: mctx.reserveOutput(int(c["results"] * 1.2) + 1024, int(c["items"] * 1.2) + 1024),
                            mctx.growArena, ndocs, "matcher")
