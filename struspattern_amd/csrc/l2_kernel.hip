@@ -1576,13 +1576,13 @@ __device__ __forceinline__ void doTransition( HWS* wsBlock, u32* wsArena, KP P, 
 {
 	const WSV w( wsBlock, wsArena);
 	w.open += w.nTrig;
-	w.nFollow = 1;
-	stEv( &FOLLOW[0].d, data); FOLLOW[0].event = event;
+	w.nFollow = 1;		// slot 0 of the follow list is the input event itself: it stays in registers
 
 	for (u32 fi=0; fi<w.nFollow && !w.err; ++fi)
 	{
-		EvData d; ldEv( d, &FOLLOW[ fi].d);
-		u32 ev = ldu( &FOLLOW[ fi].event);
+		EvData d = data;
+		u32 ev = event;
+		if (fi) { ldEv( d, &FOLLOW[ fi].d); ev = ldu( &FOLLOW[ fi].event); }
 		w.nDispose = 0;
 		TRACE2( 6, fi); TRACE2( 7, ev);
 
