@@ -178,12 +178,19 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 				// the register budget allows (5 per SIMD up to 2 passes, 4 beyond; two 10-wave workgroups of the
 				// 3-pass instance at 96 registers were measured not to share a CU)
 				const unsigned maxWaves = T.nofPasses <= 2 ? 20u : 16u;
-				unsigned copies = (unsigned)((160*1024 - 1024) / (bytes ? bytes : 1));
-				if (copies < 1) copies = 1;
-				if (copies > 5) copies = 5;
-				unsigned wpb = maxWaves / copies;
-				if (wpb > 16) wpb = 16;
-				if (wpb < 1) wpb = 1;
+				unsigned maxCopies = (unsigned)((160*1024 - 1024) / (bytes ? bytes : 1));
+				if (maxCopies < 1) maxCopies = 1;
+				if (maxCopies > 5) maxCopies = 5;
+				// waves per workgroup in multiples of 4 (one per SIMD): workgroups of 6 or 10 waves load the four
+				// SIMDs unevenly and the next workgroup does not fit beside them (measured: 3 x 6 waves of the
+				// 2-pass instance ran at the speed of 10-12 resident waves)
+				unsigned best = 0, wpb = 4;
+				for (unsigned cp=maxCopies; cp>=1; --cp)
+				{
+					unsigned wv = (maxWaves / cp) & ~3u;
+					if (wv > 16) wv = 16;
+					if (wv * cp > best) { best = wv * cp; wpb = wv; }
+				}
 				c->blockThreads = 64 * wpb;
 			}
 			else { c->ldsWords = 0; c->blockThreads = 256; }

@@ -8,6 +8,7 @@
 // src/patternLexer.cpp:391-405): every end offset of a non-empty match once, with its leftmost start.
 #include "l1_compile.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <stdexcept>
@@ -854,6 +855,105 @@ void LexCompiler::compile()
 			}
 		}
 	}
+	// bit of every position of every pattern inside its word (contiguous in the two layouts above)
+	std::vector<std::vector<uint8_t> > bitOf( autos.size());
+	for (size_t pi=0; pi<autos.size(); ++pi)
+	{
+		if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
+		for (size_t k=0; k<autos[ pi].pos.size(); ++k) bitOf[ pi].push_back( (uint8_t)(bitBase[ pi] + k));
+	}
+	// 2b. shared first position.  Many sets hold families of patterns that begin alike ([a-z]+ing\b,
+	//     [a-z]+ed\b, ..; \bun\w+, \bup\w+, ..).  When the first position of a pattern is its only start
+	//     position, is not accepting and has no edge coming back into it, "position 0 is live" means the
+	//     same for every pattern with an identical position 0 (same bytes, same self loop, same start
+	//     contexts): such patterns can share that one bit when they sit in the same word -- the edges
+	//     from the shared bit to each pattern's own positions become one exception row of that word, and
+	//     the pattern's mask (accept attribution, start-of-match run) is its own bits plus the shared one.
+	{
+		// Opt-in (SPA_L1_SHARE=on: when it saves a pass, =force: always; tests): on the 10k-pattern benchmark set
+		// it takes the tables from 3 passes to 2 but the lexer kernel only from 226 to 219 ms -- the per-byte
+		// scalar work and the report handling dominate, not the pass count -- so the default stays the plain layout.
+		const char* shareEnv = getenv( "SPA_L1_SHARE");
+		const bool shareForce = shareEnv && !std::strcmp( shareEnv, "force");
+		const bool shareOff = !(shareForce || (shareEnv && !std::strcmp( shareEnv, "on")));
+		std::map<std::string,std::vector<size_t> > groups;
+		std::vector<size_t> singles;
+		for (size_t pi=0; pi<autos.size() && !shareOff; ++pi)
+		{
+			if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
+			const Automaton& a = autos[ pi];
+			bool ok = a.pos.size() >= 2;
+			uint64_t anyStart = 0;
+			for (int c=0; c<CTX_COUNT && ok; ++c) { ok = (a.start[ c] & ~1ull) == 0 && (a.accept[ c] & 1ull) == 0; anyStart |= a.start[ c]; }
+			for (size_t k=1; k<a.pos.size() && ok; ++k) ok = (a.follow[ k] & 1ull) == 0;
+			if (!ok || !anyStart) { singles.push_back( pi); continue; }
+			std::string key;
+			for (unsigned c=0; c<256; c+=8) { unsigned char b = 0; for (unsigned x=0; x<8; ++x) if (a.pos[ 0].has( c+x)) b |= (unsigned char)(1u << x); key.push_back( (char)b); }
+			key.push_back( (char)(a.follow[ 0] & 1ull));
+			for (int c=0; c<CTX_COUNT; ++c) key.push_back( (char)(a.start[ c] & 1ull));
+			groups[ key].push_back( pi);
+		}
+		if (!shareOff)
+		{
+			struct Bin { uint32_t used; std::vector<size_t> members; bool shared; };
+			std::vector<Bin> bins;
+			for (std::map<std::string,std::vector<size_t> >::iterator gi=groups.begin(); gi!=groups.end(); ++gi)
+			{
+				std::vector<size_t>& mem = gi->second;
+				if (mem.size() < 2) { singles.push_back( mem[ 0]); continue; }
+				std::stable_sort( mem.begin(), mem.end(), [&]( size_t a, size_t b) { return autos[ a].pos.size() > autos[ b].pos.size(); });
+				const size_t firstBin = bins.size();
+				for (size_t k=0; k<mem.size(); ++k)
+				{
+					const uint32_t chain = (uint32_t)autos[ mem[ k]].pos.size() - 1;
+					size_t bi = firstBin;
+					while (bi < bins.size() && bins[ bi].used + chain > 64) ++bi;
+					if (bi == bins.size()) { Bin b; b.used = 1; b.shared = true; bins.push_back( b); }
+					bins[ bi].members.push_back( mem[ k]); bins[ bi].used += chain;
+				}
+			}
+			// everything else first-fit by decreasing size into what is left (a bin opened here has no shared bit)
+			std::sort( singles.begin(), singles.end());
+			std::stable_sort( singles.begin(), singles.end(), [&]( size_t a, size_t b) { return autos[ a].pos.size() > autos[ b].pos.size(); });
+			for (size_t k=0; k<singles.size(); ++k)
+			{
+				const Automaton& a = autos[ singles[ k]];
+				const uint32_t n = (uint32_t)a.pos.size();
+				// a pattern with exception edges of its own stays out of the words that spend their exception
+				// row on a shared first position (a second row is paid by every word of the pass)
+				bool ownEx = false;
+				for (uint32_t q=0; q<n && !ownEx; ++q) ownEx = (a.follow[ q] & ~(1ull << q) & ~(q+1 < n ? (1ull << (q+1)) : 0ull)) != 0;
+				size_t bi = 0;
+				while (bi < bins.size() && (bins[ bi].used + n > 64 || (ownEx && bins[ bi].shared))) ++bi;
+				if (bi == bins.size()) { Bin b; b.used = 0; b.shared = false; bins.push_back( b); }
+				bins[ bi].members.push_back( singles[ k] | ((size_t)1 << 62)); bins[ bi].used += n;
+			}
+			const uint32_t perPass = L1_WORDS_PER_PASS;
+			const uint32_t passesNow = word ? (word + perPass-1) / perPass : 1;
+			const uint32_t passesShared = bins.empty() ? 1 : ((uint32_t)bins.size() + perPass-1) / perPass;
+			if (!bins.empty() && (passesShared < passesNow || shareForce))
+			{
+				T.nofPositions = 0;
+				for (size_t bi=0; bi<bins.size(); ++bi)
+				{
+					uint32_t next = bins[ bi].shared ? 1 : 0;
+					T.nofPositions += next;
+					for (size_t k=0; k<bins[ bi].members.size(); ++k)
+					{
+						const bool single = (bins[ bi].members[ k] >> 62) != 0;
+						const size_t pi = bins[ bi].members[ k] & (((size_t)1 << 62) - 1);
+						const size_t n = autos[ pi].pos.size();
+						bitOf[ pi].clear();
+						wordOf[ pi] = (uint32_t)bi;
+						if (!single) bitOf[ pi].push_back( 0);			// the shared first position
+						for (size_t q=single?0:1; q<n; ++q) { bitOf[ pi].push_back( (uint8_t)next++); ++T.nofPositions; }
+					}
+				}
+				word = (uint32_t)bins.size();
+				T.reportsOrdered = false;
+			}
+		}
+	}
 	T.wordPatBegin.clear(); T.wordPats.clear();
 	{
 		// patterns of every word (ascending pattern index inside a word)
@@ -861,9 +961,9 @@ void LexCompiler::compile()
 		for (size_t pi=0; pi<autos.size(); ++pi)
 		{
 			if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
-			const uint32_t n = (uint32_t)autos[ pi].pos.size(), used = bitBase[ pi];
 			T.patterns[ pi].word = wordOf[ pi];
-			uint64_t mask = n == 64 ? ~0ull : (((1ull << n) - 1) << used);
+			uint64_t mask = 0;
+			for (size_t k=0; k<bitOf[ pi].size(); ++k) mask |= 1ull << bitOf[ pi][ k];
 			T.patterns[ pi].maskLo = (uint32_t)mask; T.patterns[ pi].maskHi = (uint32_t)(mask >> 32);
 			perWord[ wordOf[ pi]].push_back( (uint32_t)pi);
 		}
@@ -884,7 +984,7 @@ void LexCompiler::compile()
 	for (size_t pi=0; pi<autos.size(); ++pi)
 	{
 		if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
-		for (uint32_t k=0; k<(uint32_t)autos[ pi].pos.size(); ++k) T.patOfBit[ (size_t)T.patterns[ pi].word*64 + bitBase[ pi] + k] = (uint32_t)pi;
+		for (uint32_t k=0; k<(uint32_t)autos[ pi].pos.size(); ++k) T.patOfBit[ (size_t)T.patterns[ pi].word*64 + bitOf[ pi][ k]] = (uint32_t)pi;	// a shared bit never accepts: any owner will do
 	}
 
 	// 3. byte classes: bytes that no position distinguishes (and that share a context) are one class
@@ -920,6 +1020,7 @@ void LexCompiler::compile()
 	T.acceptMask.assign( (size_t)T.nofPasses * CTX_COUNT * 64, 0);
 	T.shiftDst.assign( (size_t)T.nofPasses * 64, 0);
 	T.selfLoop.assign( (size_t)T.nofPasses * 64, 0);
+	std::vector<std::map<uint64_t,uint64_t> > exBySrc( totalWords);	// src bit -> dst set (edges that are neither self loop nor shift)
 	std::vector<std::map<uint64_t,uint64_t> > exOfWord( totalWords);	// dst set -> src set
 	std::vector<unsigned char> repOfClass( T.nofClasses, 0);
 	for (unsigned c=256; c-->0;) repOfClass[ T.byteClass[ c]] = (unsigned char)c;
@@ -927,25 +1028,37 @@ void LexCompiler::compile()
 	{
 		const Automaton& a = autos[ pi];
 		if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
-		const uint32_t w = T.patterns[ pi].word, base = bitBase[ pi];
+		const uint32_t w = T.patterns[ pi].word;
+		const std::vector<uint8_t>& bit = bitOf[ pi];
 		const uint32_t pass = w / 64, lane = w % 64;
 		const uint32_t n = (uint32_t)a.pos.size();
+		auto place = [&]( uint64_t local) -> uint64_t		// pattern-local position set -> bits of the word
+		{
+			uint64_t rt = 0;
+			for (uint32_t k=0; k<n; ++k) if (local & (1ull << k)) rt |= 1ull << bit[ k];
+			return rt;
+		};
 		for (uint32_t k=0; k<n; ++k)
 		{
 			for (uint32_t cls=0; cls<T.nofClasses; ++cls)
 			{
-				if (a.pos[k].has( repOfClass[ cls])) T.charMask[ ((size_t)pass*T.nofClasses + cls)*64 + lane] |= 1ull << (base+k);
+				if (a.pos[k].has( repOfClass[ cls])) T.charMask[ ((size_t)pass*T.nofClasses + cls)*64 + lane] |= 1ull << bit[ k];
 			}
 			uint64_t f = a.follow[ k];
-			if (f & (1ull << k)) { T.selfLoop[ pass*64 + lane] |= 1ull << (base+k); f &= ~(1ull << k); }
-			if (k+1 < n && (f & (1ull << (k+1)))) { T.shiftDst[ pass*64 + lane] |= 1ull << (base+k+1); f &= ~(1ull << (k+1)); }
-			if (f) exOfWord[ w][ f << base] |= 1ull << (base+k);
+			if (f & (1ull << k)) { T.selfLoop[ pass*64 + lane] |= 1ull << bit[ k]; f &= ~(1ull << k); }
+			if (k+1 < n && (f & (1ull << (k+1))) && bit[ k+1] == bit[ k]+1) { T.shiftDst[ pass*64 + lane] |= 1ull << bit[ k+1]; f &= ~(1ull << (k+1)); }
+			if (f) exBySrc[ w][ 1ull << bit[ k]] |= place( f);
 		}
 		for (int c=0; c<CTX_COUNT; ++c)
 		{
-			T.startMask[ ((size_t)pass*CTX_COUNT + c)*64 + lane] |= a.start[ c] << base;
-			T.acceptMask[ ((size_t)pass*CTX_COUNT + c)*64 + lane] |= a.accept[ c] << base;
+			T.startMask[ ((size_t)pass*CTX_COUNT + c)*64 + lane] |= place( a.start[ c]);
+			T.acceptMask[ ((size_t)pass*CTX_COUNT + c)*64 + lane] |= place( a.accept[ c]);
 		}
+	}
+	// one exception row per distinct destination set of a word (sources with the same destinations share it)
+	for (uint32_t w=0; w<totalWords; ++w)
+	{
+		for (std::map<uint64_t,uint64_t>::const_iterator it=exBySrc[ w].begin(); it!=exBySrc[ w].end(); ++it) exOfWord[ w][ it->second] |= it->first;
 	}
 	T.maxExceptions = 0;
 	T.exCount.assign( T.nofPasses, 0);

@@ -140,3 +140,66 @@ def test_classes_covering_all_non_ascii_characters():
     for pats in (["a.b", "[^a-z ]+", "\\b[^\\s]+\\b", ".", "[^\\x00-\\x7f]{2}", "x[^q]y"], ["[^.]{3}", "(?:.|q){2}z"]):
         assert _product_reports(pats, text) == _oracle_reports(pats, text), pats
         assert _product_reports(pats, text, options=()) == _oracle_reports(pats, text, options=()), pats
+
+
+SHARED_HEAD_PATTERNS = [
+    "[a-z]+ing\\b", "[a-z]+ed\\b", "[a-z]+s\\b", "[a-z]+ings\\b",        # one looping first position for four patterns
+    "\\bun[a-z]+\\b", "\\bup[a-z]*\\b", "\\bunder\\s\\w+\\b", "\\bu\\b",    # 'u' after a word boundary
+    "\\b[A-Z]an[a-z]*\\b", "\\b[A-Z][a-z]+\\b", "\\b[A-Z]\\.",               # [A-Z] after a word boundary
+    "a+b", "a+c", "ab", "ac", "a+",                                        # looping and plain 'a' are different heads; "a+" accepts in its head
+    "(ab)+c", "(ab)+d",                                                    # an edge leads back into the first position: not shared
+    "[0-9]+th\\b", "[0-9]+st\\b", "[0-9]+\\b",
+    "x[0-9]{1,3}y", "x[0-9]{2}z",                                          # members with exception edges of their own
+]
+SHARED_HEAD_TEXT = (b"Running under water the singer sings songs and tested beds. Uncle Dan and Ann upped the "
+                    b"unders, up u un. A. B.C aaab aab ab ac abababc ababd a 5th 21st 7 x1y x12y x123y x12z x1234y "
+                    b"undertaking  understood upkeep Andes Dans wings")
+
+
+def test_patterns_sharing_their_first_position(monkeypatch):
+    """SPA_L1_SHARE=force packs patterns with an identical first position onto one shared bit whenever they
+    qualify; the raw reports (end offset, pattern, leftmost start) must be those of the unshared tables and
+    of the oracle."""
+    expected = _oracle_reports(SHARED_HEAD_PATTERNS, SHARED_HEAD_TEXT)
+    assert len(expected) > 60
+    monkeypatch.setenv("SPA_L1_SHARE", "off")
+    lx = spa.PatternLexerInstance()
+    for i, p in enumerate(SHARED_HEAD_PATTERNS):
+        lx.defineLexem(i + 1, p, 0, 1, "content")
+    lx.compile()
+    plain = lx.dumpTables()
+    assert Tables(plain).raw_reports(SHARED_HEAD_TEXT) == expected
+    monkeypatch.setenv("SPA_L1_SHARE", "force")
+    lx = spa.PatternLexerInstance()
+    for i, p in enumerate(SHARED_HEAD_PATTERNS):
+        lx.defineLexem(i + 1, p, 0, 1, "content")
+    lx.compile()
+    shared = lx.dumpTables()
+    # 4+4+3+2+2+3(th/st: "[0-9]+\\b" accepts in its head)... the exact count is the layout's business: fewer positions, same reports
+    assert int(shared[4]) <= int(plain[4]) - 10 and int(shared[6]) == 0
+    assert Tables(shared).raw_reports(SHARED_HEAD_TEXT) == expected
+
+
+def test_sharing_the_first_position_saves_a_pass(monkeypatch):
+    """1150 suffix / prefix patterns need two passes bit for bit and one with shared first positions
+    (SPA_L1_SHARE=on takes that layout when it saves a pass); the reports stay those of the oracle."""
+    import itertools
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    sufs = ["".join(t) for t in itertools.product(letters[:12], letters[:10], letters[:5])]
+    pats = ["[a-z]+%s\\b" % s for s in sufs[:520]] + ["\\b%s[a-z]*\\b" % s for s in sufs[40:560]] + ["\\b[A-Z]%s[a-z]*\\b" % s[:2] for s in sufs[::5][:110]]
+    pats = list(dict.fromkeys(pats))
+    monkeypatch.setenv("SPA_L1_SHARE", "on")
+    lx = spa.PatternLexerInstance()
+    for i, p in enumerate(pats):
+        lx.defineLexem(i + 1, p, 0, 1, "content")
+    lx.compile()
+    dump = lx.dumpTables()
+    assert int(dump[0]) == 1 and int(dump[6]) == 0 and int(dump[4]) < 4096
+    monkeypatch.setenv("SPA_L1_SHARE", "off")
+    lx2 = spa.PatternLexerInstance()
+    for i, p in enumerate(pats):
+        lx2.defineLexem(i + 1, p, 0, 1, "content")
+    lx2.compile()
+    assert int(lx2.dumpTables()[0]) == 2
+    text = (" ".join(sufs[k] + "x" + sufs[(7 * k) % 600] + " " + sufs[(3 * k) % 600].capitalize() for k in range(0, 600, 13))).encode()
+    assert Tables(dump).raw_reports(text) == _oracle_reports(pats, text, options=())
