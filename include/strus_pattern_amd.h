@@ -204,7 +204,8 @@ int sp_matcher_ctx_match_docs_device(sp_matcher_ctx_t* c, const void* d_lexems, 
  * sp_lexer_ctx_match_docs_device are consumed in place, nothing leaves HBM in between */
 int sp_matcher_ctx_match_lexed_device(sp_matcher_ctx_t* c, const void* d_lexems, const void* d_doc_ranges,
                                       size_t ndocs, size_t nlexems_hint, void* stream, sp_match_device_batch_t* out);
-/* copies the results of the last device batch to the host, grouped by document */
+/* copies the results of the last device batch to the host, grouped by document (as sp_matcher_ctx_match_docs
+ * returns them, `exclusive` elimination included) */
 int sp_matcher_ctx_batch_fetch(sp_matcher_ctx_t* c, sp_match_batch_t* out);
 /* waits for the stream and returns counters[0..7] = {results, items, events, failed docs, 0..} */
 int sp_matcher_ctx_batch_counters(sp_matcher_ctx_t* c, uint64_t counters[8]);

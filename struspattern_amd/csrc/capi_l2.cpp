@@ -105,8 +105,8 @@ struct sp_matcher_ctx
 	std::vector<uint32_t> curOrigseg; bool curHasSeg;
 	sp_matcher_stats_t lastStats;
 
-	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),arenaWaves(0),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
-		,withFormats(false),lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
+	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
+		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
 		std::memset( &lastStats, 0, sizeof(lastStats));
@@ -240,7 +240,105 @@ int sp_matcher_ctx_set_arena( sp_matcher_ctx_t* c, uint32_t max_rules, uint32_t 
 	return SP_OK;
 }
 
-// copies the device results of the last batch to the host, grouped by document (test/verification hook)
+} // extern "C"
+
+namespace {
+
+// Host copy of the device results of the last launch, regrouped by document (the device appends whole
+// documents in completion order), with the `exclusive` elimination of fetchResults applied on the way.
+void copyOutBatch( sp_matcher_ctx* c, size_t ndocs, const uint64_t* counters, sp_match_batch_t* out)
+{
+	std::vector<uint64_t> range( ndocs*2+2);
+	if (ndocs) HIP_CHECK( hipMemcpy( range.data(), c->dDocRange.ptr, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
+	out->ndocs = ndocs;
+	out->doc_stats = (uint64_t*)std::malloc( (ndocs*4+1)*sizeof(uint64_t));
+	out->doc_status = (int32_t*)std::malloc( (ndocs+1)*sizeof(int32_t));
+	out->doc_result_offsets = (uint64_t*)std::malloc( (ndocs+1)*sizeof(uint64_t));
+	if (!out->doc_stats || !out->doc_status || !out->doc_result_offsets) throw std::bad_alloc();
+	if (ndocs)
+	{
+		HIP_CHECK( hipMemcpy( out->doc_stats, c->dDocStats.ptr, ndocs*4*sizeof(uint64_t), hipMemcpyDeviceToHost));
+		HIP_CHECK( hipMemcpy( out->doc_status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+	}
+	uint64_t nres = counters[ SPC_RESULTS] < c->resultCapacity ? counters[ SPC_RESULTS] : c->resultCapacity;
+	uint64_t nitems = counters[ SPC_ITEMS] < c->itemCapacity ? counters[ SPC_ITEMS] : c->itemCapacity;
+	std::vector<sp_result_t> raw( nres+1);
+	std::vector<sp_result_item_t> rawitems( nitems+1);
+	if (nres) HIP_CHECK( hipMemcpy( raw.data(), c->dResults.ptr, nres*sizeof(sp_result_t), hipMemcpyDeviceToHost));
+	if (nitems) HIP_CHECK( hipMemcpy( rawitems.data(), c->dItems.ptr, nitems*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
+	std::vector<uint32_t> rawrf, rawif;
+	if (c->withFormats)
+	{
+		rawrf.resize( nres+1); rawif.resize( 2*nitems+2);
+		if (nres) HIP_CHECK( hipMemcpy( rawrf.data(), c->dResultFormat.ptr, nres*sizeof(uint32_t), hipMemcpyDeviceToHost));
+		if (nitems) HIP_CHECK( hipMemcpy( rawif.data(), c->dItemFormat.ptr, 2*nitems*sizeof(uint32_t), hipMemcpyDeviceToHost));
+	}
+	// regroup by document (the device appends whole documents in completion order)
+	uint64_t total = 0, totalItems = 0;
+	for (size_t di=0; di<ndocs; ++di)
+	{
+		if (out->doc_status[ di] != 0) { range[ 2*di+1] = 0; continue; }
+		total += range[ 2*di+1];
+		for (uint64_t ri=0; ri<range[ 2*di+1]; ++ri) totalItems += raw[ range[ 2*di]+ri].item_count;
+	}
+	out->results = (sp_result_t*)std::malloc( (total+1)*sizeof(sp_result_t));
+	out->items = (sp_result_item_t*)std::malloc( (totalItems+1)*sizeof(sp_result_item_t));
+	if (!out->results || !out->items) throw std::bad_alloc();
+	if (c->withFormats)
+	{
+		out->result_format = (uint32_t*)std::malloc( (total+1)*sizeof(uint32_t));
+		out->item_format = (uint32_t*)std::malloc( (totalItems+1)*2*sizeof(uint32_t));
+		if (!out->result_format || !out->item_format) throw std::bad_alloc();
+	}
+	uint64_t rp = 0, ip = 0;
+	// `exclusive` option: covered results are dropped on the way out (src/patternMatcher.cpp:192-246, :278-289)
+	const bool exclusive = c->inst->compiler.exclusive();
+	const uint32_t maxResultSize = c->inst->compiler.maxResultSize();
+	std::vector<char> covered;
+	for (size_t di=0; di<ndocs; ++di)
+	{
+		out->doc_result_offsets[ di] = rp;
+		const uint64_t b = range[ 2*di], n = range[ 2*di+1];
+		if (exclusive)
+		{
+			covered.assign( n, 0);
+			for (uint64_t ai=0; ai<n; ++ai)
+			{
+				const sp_result_t& r = raw[ b+ai];
+				for (uint64_t ni=ai; ni<n; ++ni)
+				{
+					const sp_result_t& f = raw[ b+ni];
+					if (f.origseg > r.origendseg || f.origpos >= r.origend + maxResultSize) break;
+					bool differ = (f.origendseg != r.origendseg || f.origend != r.origend || f.origseg != r.origseg || f.origpos != r.origpos);
+					if (f.origseg <= r.origseg && f.origpos <= r.origpos && f.origendseg >= r.origendseg && f.origend >= r.origend && differ) covered[ ai] = 1;
+					if (f.origseg >= r.origseg && f.origpos >= r.origpos && f.origendseg <= r.origendseg && f.origend <= r.origend && differ) covered[ ni] = 1;
+				}
+			}
+		}
+		for (uint64_t ri=0; ri<n; ++ri)
+		{
+			if (exclusive && covered[ ri]) continue;
+			sp_result_t r = raw[ b+ri];
+			uint32_t ib = r.item_begin, ic = r.item_count;
+			r.item_begin = (uint32_t)ip;
+			if (c->withFormats)
+			{
+				out->result_format[ rp] = rawrf[ b+ri];
+				for (uint32_t k=0; k<ic; ++k) { out->item_format[ 2*(ip+k)] = rawif[ 2*(ib+k)]; out->item_format[ 2*(ip+k)+1] = rawif[ 2*(ib+k)+1]; }
+			}
+			for (uint32_t k=0; k<ic; ++k) out->items[ ip++] = rawitems[ ib+k];
+			out->results[ rp++] = r;
+		}
+	}
+	out->doc_result_offsets[ ndocs] = rp;
+	out->nresults = rp; out->nitems = ip;
+}
+
+} // namespace
+
+extern "C" {
+
+// copies the device results of the last batch to the host, grouped by document
 int sp_matcher_ctx_batch_fetch( sp_matcher_ctx_t* c, sp_match_batch_t* out)
 {
 	std::memset( out, 0, sizeof(*out));
@@ -250,67 +348,7 @@ int sp_matcher_ctx_batch_fetch( sp_matcher_ctx_t* c, sp_match_batch_t* out)
 		size_t ndocs = c->lastNdocs;
 		uint64_t counters[ SPC_COUNT];
 		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
-		std::vector<uint64_t> range( ndocs*2+2);
-		out->ndocs = ndocs;
-		out->doc_stats = (uint64_t*)std::malloc( (ndocs*4+1)*sizeof(uint64_t));
-		out->doc_status = (int32_t*)std::malloc( (ndocs+1)*sizeof(int32_t));
-		out->doc_result_offsets = (uint64_t*)std::malloc( (ndocs+1)*sizeof(uint64_t));
-		if (!out->doc_stats || !out->doc_status || !out->doc_result_offsets) throw std::bad_alloc();
-		if (ndocs)
-		{
-			HIP_CHECK( hipMemcpy( range.data(), c->dDocRange.ptr, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
-			HIP_CHECK( hipMemcpy( out->doc_stats, c->dDocStats.ptr, ndocs*4*sizeof(uint64_t), hipMemcpyDeviceToHost));
-			HIP_CHECK( hipMemcpy( out->doc_status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
-		}
-		uint64_t nres = counters[ SPC_RESULTS] < c->resultCapacity ? counters[ SPC_RESULTS] : c->resultCapacity;
-		uint64_t nitems = counters[ SPC_ITEMS] < c->itemCapacity ? counters[ SPC_ITEMS] : c->itemCapacity;
-		std::vector<sp_result_t> raw( nres+1);
-		std::vector<sp_result_item_t> rawitems( nitems+1);
-		if (nres) HIP_CHECK( hipMemcpy( raw.data(), c->dResults.ptr, nres*sizeof(sp_result_t), hipMemcpyDeviceToHost));
-		if (nitems) HIP_CHECK( hipMemcpy( rawitems.data(), c->dItems.ptr, nitems*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
-		std::vector<uint32_t> rawrf, rawif;
-		if (c->withFormats)
-		{
-			rawrf.resize( nres+1); rawif.resize( 2*nitems+2);
-			if (nres) HIP_CHECK( hipMemcpy( rawrf.data(), c->dResultFormat.ptr, nres*sizeof(uint32_t), hipMemcpyDeviceToHost));
-			if (nitems) HIP_CHECK( hipMemcpy( rawif.data(), c->dItemFormat.ptr, 2*nitems*sizeof(uint32_t), hipMemcpyDeviceToHost));
-		}
-		uint64_t total = 0, totalItems = 0;
-		for (size_t di=0; di<ndocs; ++di)
-		{
-			if (out->doc_status[ di] != 0) range[ 2*di+1] = 0;
-			total += range[ 2*di+1];
-			for (uint64_t ri=0; ri<range[ 2*di+1]; ++ri) totalItems += raw[ range[ 2*di]+ri].item_count;
-		}
-		out->results = (sp_result_t*)std::malloc( (total+1)*sizeof(sp_result_t));
-		out->items = (sp_result_item_t*)std::malloc( (totalItems+1)*sizeof(sp_result_item_t));
-		if (!out->results || !out->items) throw std::bad_alloc();
-		if (c->withFormats)
-		{
-			out->result_format = (uint32_t*)std::malloc( (total+1)*sizeof(uint32_t));
-			out->item_format = (uint32_t*)std::malloc( (totalItems+1)*2*sizeof(uint32_t));
-			if (!out->result_format || !out->item_format) throw std::bad_alloc();
-		}
-		uint64_t rp = 0, ip = 0;
-		for (size_t di=0; di<ndocs; ++di)
-		{
-			out->doc_result_offsets[ di] = rp;
-			for (uint64_t ri=0; ri<range[ 2*di+1]; ++ri)
-			{
-				sp_result_t r = raw[ range[ 2*di]+ri];
-				uint32_t ib = r.item_begin, ic = r.item_count;
-				r.item_begin = (uint32_t)ip;
-				if (c->withFormats)
-				{
-					out->result_format[ rp] = rawrf[ range[ 2*di]+ri];
-					for (uint32_t k=0; k<ic; ++k) { out->item_format[ 2*(ip+k)] = rawif[ 2*(ib+k)]; out->item_format[ 2*(ip+k)+1] = rawif[ 2*(ib+k)+1]; }
-				}
-				for (uint32_t k=0; k<ic; ++k) out->items[ ip++] = rawitems[ ib+k];
-				out->results[ rp++] = r;
-			}
-		}
-		out->doc_result_offsets[ ndocs] = rp;
-		out->nresults = rp; out->nitems = ip;
+		copyOutBatch( c, ndocs, counters, out);
 	});
 }
 
@@ -563,90 +601,7 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 			}
 			if (!grow || attempt >= 12) break;
 		}
-		std::vector<uint64_t> range( ndocs*2+2);
-		if (ndocs) HIP_CHECK( hipMemcpy( range.data(), c->dDocRange.ptr, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
-		out->ndocs = ndocs;
-		out->doc_stats = (uint64_t*)std::malloc( (ndocs*4+1)*sizeof(uint64_t));
-		out->doc_status = (int32_t*)std::malloc( (ndocs+1)*sizeof(int32_t));
-		out->doc_result_offsets = (uint64_t*)std::malloc( (ndocs+1)*sizeof(uint64_t));
-		if (!out->doc_stats || !out->doc_status || !out->doc_result_offsets) throw std::bad_alloc();
-		if (ndocs)
-		{
-			HIP_CHECK( hipMemcpy( out->doc_stats, c->dDocStats.ptr, ndocs*4*sizeof(uint64_t), hipMemcpyDeviceToHost));
-			HIP_CHECK( hipMemcpy( out->doc_status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
-		}
-		uint64_t nres = counters[ SPC_RESULTS] < c->resultCapacity ? counters[ SPC_RESULTS] : c->resultCapacity;
-		uint64_t nitems = counters[ SPC_ITEMS] < c->itemCapacity ? counters[ SPC_ITEMS] : c->itemCapacity;
-		std::vector<sp_result_t> raw( nres+1);
-		std::vector<sp_result_item_t> rawitems( nitems+1);
-		if (nres) HIP_CHECK( hipMemcpy( raw.data(), c->dResults.ptr, nres*sizeof(sp_result_t), hipMemcpyDeviceToHost));
-		if (nitems) HIP_CHECK( hipMemcpy( rawitems.data(), c->dItems.ptr, nitems*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
-		std::vector<uint32_t> rawrf, rawif;
-		if (c->withFormats)
-		{
-			rawrf.resize( nres+1); rawif.resize( 2*nitems+2);
-			if (nres) HIP_CHECK( hipMemcpy( rawrf.data(), c->dResultFormat.ptr, nres*sizeof(uint32_t), hipMemcpyDeviceToHost));
-			if (nitems) HIP_CHECK( hipMemcpy( rawif.data(), c->dItemFormat.ptr, 2*nitems*sizeof(uint32_t), hipMemcpyDeviceToHost));
-		}
-		// regroup by document (the device appends whole documents in completion order)
-		uint64_t total = 0, totalItems = 0;
-		for (size_t di=0; di<ndocs; ++di)
-		{
-			if (out->doc_status[ di] != 0) { range[ 2*di+1] = 0; continue; }
-			total += range[ 2*di+1];
-			for (uint64_t ri=0; ri<range[ 2*di+1]; ++ri) totalItems += raw[ range[ 2*di]+ri].item_count;
-		}
-		out->results = (sp_result_t*)std::malloc( (total+1)*sizeof(sp_result_t));
-		out->items = (sp_result_item_t*)std::malloc( (totalItems+1)*sizeof(sp_result_item_t));
-		if (!out->results || !out->items) throw std::bad_alloc();
-		if (c->withFormats)
-		{
-			out->result_format = (uint32_t*)std::malloc( (total+1)*sizeof(uint32_t));
-			out->item_format = (uint32_t*)std::malloc( (totalItems+1)*2*sizeof(uint32_t));
-			if (!out->result_format || !out->item_format) throw std::bad_alloc();
-		}
-		uint64_t rp = 0, ip = 0;
-		// `exclusive` option: covered results are dropped on the way out (src/patternMatcher.cpp:192-246, :278-289)
-		const bool exclusive = c->inst->compiler.exclusive();
-		const uint32_t maxResultSize = c->inst->compiler.maxResultSize();
-		std::vector<char> covered;
-		for (size_t di=0; di<ndocs; ++di)
-		{
-			out->doc_result_offsets[ di] = rp;
-			const uint64_t b = range[ 2*di], n = range[ 2*di+1];
-			if (exclusive)
-			{
-				covered.assign( n, 0);
-				for (uint64_t ai=0; ai<n; ++ai)
-				{
-					const sp_result_t& r = raw[ b+ai];
-					for (uint64_t ni=ai; ni<n; ++ni)
-					{
-						const sp_result_t& f = raw[ b+ni];
-						if (f.origseg > r.origendseg || f.origpos >= r.origend + maxResultSize) break;
-						bool differ = (f.origendseg != r.origendseg || f.origend != r.origend || f.origseg != r.origseg || f.origpos != r.origpos);
-						if (f.origseg <= r.origseg && f.origpos <= r.origpos && f.origendseg >= r.origendseg && f.origend >= r.origend && differ) covered[ ai] = 1;
-						if (f.origseg >= r.origseg && f.origpos >= r.origpos && f.origendseg <= r.origendseg && f.origend <= r.origend && differ) covered[ ni] = 1;
-					}
-				}
-			}
-			for (uint64_t ri=0; ri<n; ++ri)
-			{
-				if (exclusive && covered[ ri]) continue;
-				sp_result_t r = raw[ b+ri];
-				uint32_t ib = r.item_begin, ic = r.item_count;
-				r.item_begin = (uint32_t)ip;
-				if (c->withFormats)
-				{
-					out->result_format[ rp] = rawrf[ b+ri];
-					for (uint32_t k=0; k<ic; ++k) { out->item_format[ 2*(ip+k)] = rawif[ 2*(ib+k)]; out->item_format[ 2*(ip+k)+1] = rawif[ 2*(ib+k)+1]; }
-				}
-				for (uint32_t k=0; k<ic; ++k) out->items[ ip++] = rawitems[ ib+k];
-				out->results[ rp++] = r;
-			}
-		}
-		out->doc_result_offsets[ ndocs] = rp;
-		out->nresults = rp; out->nitems = ip;
+		copyOutBatch( c, ndocs, counters, out);
 		if (counters[ SPC_FAILED])
 		{
 			size_t bad = 0;
