@@ -4,11 +4,14 @@
 A "step" is one pass of the hot path over one batch of synthetic documents already resident in
 HBM.  One process per GPU (torch.distributed / RCCL when launched by torchrun); documents shard
 across ranks with no data-path collective (weak scaling: fixed work per GPU); the only collective
-is the final reduce of the counters and the max over ranks of the wall time.
+is the final reduce of the counters and the max over ranks of the wall time
+(struspattern_amd/dist.py, the same code the world-2 gloo test runs).
 
 Workloads (--workload):
   pipeline  (default) BASELINE.json configs[4] per-GPU shard: 10k regexes + sentence delimiter ->
-            lexems stay in HBM -> 10k two-term token rules; value = GB/s of text scanned
+            lexems stay in HBM -> 10k two-term token rules; value = GB/s of text scanned.
+            Headline shape: 64 KiB documents; the same bytes cut into
+            16 KiB documents are timed beside it (config.shapes) unless --docbytes fixes one shape.
   lexer     configs[1]: 256 regexes over 64 KiB ASCII documents, lexer kernel only
   l2        configs[2]: 10k rules over a pre-tokenized event stream, rule-automaton kernel only
 """
@@ -25,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "GB/s input text scanned + matches/s, 10k-regex lexer + 10k-rule automaton"
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_bench_pmc_summary.json")
 
 
 def parse_args():
@@ -36,12 +40,12 @@ def parse_args():
     ap.add_argument("--regexes", type=int, default=0)
     ap.add_argument("--rules", type=int, default=10000)
     ap.add_argument("--docs", type=int, default=0)
-    ap.add_argument("--docbytes", type=int, default=0, help="document size (default: 16 KiB in the pipeline workload, 64 KiB in the lexer workload)")
+    ap.add_argument("--docbytes", type=int, default=0, help="document size (default: 64 KiB headline + 16 KiB beside it in the pipeline workload, 64 KiB in the lexer workload)")
     ap.add_argument("--docsize", type=int, default=1000, help="tokens per document (workload l2)")
     ap.add_argument("--features", type=int, default=10000, help="distinct tokens (workload l2)")
     ap.add_argument("--op", default="", help="fix the rule operator (default: the 5-way Zipf mix)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target size of the bounded CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -64,223 +68,343 @@ def size_until_ok(run, counters, status, reserve, grow, ndocs, what):
     raise SystemExit("bench: %s: %d documents still failing" % (what, c["failed_docs"]))
 
 
+class Shape:
+    """One cut of the corpus into documents (device-resident offsets)."""
+
+    def __init__(self, name, offs, torch):
+        self.name = name
+        self.offs = offs
+        self.ndocs = len(offs) - 1
+        self.d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
+        self.lex_out = None
+        self.nlexems = 0
+
+
 def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
+    from struspattern_amd import dist as spdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if torch.cuda.device_count() < 1:   # (counting devices does not initialise the GPU)
         raise SystemExit("bench.py needs a GPU: the match path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
     if world > 1:
+        # the process group comes first: nothing touches the GPU before the rendezvous
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
 
     import struspattern_amd as spa
     from struspattern_amd import synth
 
     wl = args.workload
-    if not args.docbytes:
-        args.docbytes = 16384 if wl == "pipeline" else 65536
     stream = torch.cuda.current_stream().cuda_stream
     lctx = mctx = None
     pats = rules = None
-    text = offs = lex = None
+    text = lex = None
     nbytes = 0
+    shapes = []
+    h2d_ms = None
     if wl in ("pipeline", "lexer"):
         nreg = args.regexes or (10000 if wl == "pipeline" else 256)
-        # documents per step: 805 MB of text as 16 KiB documents (a document is one sequential job of one
-        # wave in both kernels: the shorter the jobs, the smaller the idle tail of a launch); the count is a
-        # multiple of the resident waves of both kernels (4096 lexer / 3072 automaton slots on 256 CUs)
-        ndocs = args.docs or (49152 if wl == "pipeline" else 8192)
         vocab = synth.vocabulary(30000, 1)
         if wl == "pipeline":
             pats, rules = synth.pipeline_workload(nreg, args.rules, vocab, seed=4)
         else:
             pats = synth.lexer_patterns(nreg, vocab, seed=1)
-        text, offs = synth.text_documents(ndocs, args.docbytes, vocab, seed=1000 + rank, utf8=(wl == "pipeline"))
+        # 805 MB of text per step.  The corpus is generated as 16 KiB pieces that end at word boundaries;
+        # a 64 KiB document is four consecutive pieces, so both shapes scan the very same bytes.
+        if wl == "pipeline" and not args.docbytes:
+            piece, group = 16384, [("64KiB", 4), ("16KiB", 1)]
+        else:
+            piece = args.docbytes or 65536
+            group = [("%dKiB" % (piece // 1024), 1)]
+        npieces = args.docs * group[0][1] if args.docs else (805306368 // piece)
+        text, offs = synth.text_documents(npieces, piece, vocab, seed=1000 + rank, utf8=(wl == "pipeline"))
         nbytes = len(text)
         lxi = spa.PatternLexerInstance()
         synth.apply_lexer_patterns(lxi, pats)
         lctx = lxi.createContext(local_rank)
-        d_text = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
-        d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
-        lex_out = {}
-
-        def run_lexer():
-            lex_out["o"] = lctx.matchDocsDevice(d_text.data_ptr(), d_offs.data_ptr(), ndocs, nbytes, stream)
-        lc = size_until_ok(run_lexer, lctx.batchCounters, lctx.batchStatus,
-                           lambda c: lctx.reserveOutput(int(c["lexems"] * 1.2) + 1024), lctx.growArena, ndocs, "lexer")
-        nlexems = int(lc["lexems"])
+        host_text = torch.frombuffer(bytearray(text), dtype=torch.uint8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d_text = host_text.cuda()
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - t0) * 1e3     # pageable host memory -> HBM, reported separately (never part of `value`)
+        for name, g in group:
+            shapes.append(Shape(name, np.ascontiguousarray(offs[::g]) if (len(offs) - 1) % g == 0 else np.concatenate([offs[:-1:g], offs[-1:]]), torch))
+    else:
+        rules = synth.random_rules(args.rules, args.features, seed=2, op=(args.op or None))
+        lex, offs = synth.random_documents(args.docs or 10000, args.docsize, args.features, seed=1000 + rank)
+        d_lex = torch.from_numpy(lex.view(np.int32)).cuda()
+        sh = Shape("%dtok" % args.docsize, offs, torch)
+        sh.nlexems = len(lex)
+        shapes.append(sh)
     if wl in ("pipeline", "l2"):
-        if wl == "l2":
-            ndocs = args.docs or 10000
-            rules = synth.random_rules(args.rules, args.features, seed=2, op=(args.op or None))
-            lex, offs = synth.random_documents(ndocs, args.docsize, args.features, seed=1000 + rank)
-            d_lex = torch.from_numpy(lex.view(np.int32)).cuda()
-            d_loffs = torch.from_numpy(offs.view(np.int64)).cuda()
-            nlexems = len(lex)
         mi = spa.PatternMatcherInstance()
         synth.apply_rules(mi, rules)
         mctx = mi.createContext(local_rank)
 
-        def run_matcher():
-            if wl == "l2":
-                mctx.matchDocsDevice(d_lex.data_ptr(), d_loffs.data_ptr(), ndocs, nlexems, stream)
-            else:
-                o = lex_out["o"]
-                mctx.matchLexedDevice(o.d_lexems, o.d_doc_ranges, ndocs, nlexems, stream)
-        if os.environ.get("SPA_BENCH_EXTRA_GROW"):      # experiment: a working-set arena larger than needed (locality / TLB reach)
-            for _ in range(int(os.environ["SPA_BENCH_EXTRA_GROW"])):
-                mctx.growArena()
-        mc = size_until_ok(run_matcher, mctx.batchCounters, mctx.batchStatus,
-                           lambda c: mctx.reserveOutput(int(c["results"] * 1.2) + 1024, int(c["items"] * 1.2) + 1024),
-                           mctx.growArena, ndocs, "matcher")
+    def run_lexer(sh):
+        sh.lex_out = lctx.matchDocsDevice(d_text.data_ptr(), sh.d_offs.data_ptr(), sh.ndocs, nbytes, stream)
 
-    def step():
+    def run_matcher(sh):
+        if wl == "l2":
+            mctx.matchDocsDevice(d_lex.data_ptr(), sh.d_offs.data_ptr(), sh.ndocs, sh.nlexems, stream)
+        else:
+            mctx.matchLexedDevice(sh.lex_out.d_lexems, sh.lex_out.d_doc_ranges, sh.ndocs, sh.nlexems, stream)
+
+    def step(sh):
         if lctx is not None:
-            run_lexer()
+            run_lexer(sh)
         if mctx is not None:
-            run_matcher()
+            run_matcher(sh)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-
-    # per-kernel launch durations: HIP events recorded by the library on the launch stream
-    l1_ms, l2_ms = [], []
-    for _ in range(args.steps):
-        step()
+    # sizing passes (untimed): output buffers and per-document working sets grow to what the corpus needs
+    for sh in shapes:
         if lctx is not None:
-            l1_ms.append(lctx.lastKernelMs())
+            lc = size_until_ok(lambda: run_lexer(sh), lctx.batchCounters, lctx.batchStatus,
+                               lambda c: lctx.reserveOutput(int(c["lexems"] * 1.2) + 1024), lctx.growArena, sh.ndocs, "lexer")
+            sh.nlexems = int(lc["lexems"])
         if mctx is not None:
-            l2_ms.append(mctx.lastKernelMs())
-    l1_ms = float(np.mean(l1_ms)) if l1_ms else 0.0
-    l2_ms = float(np.mean(l2_ms)) if l2_ms else 0.0
-    lcount = lctx.batchCounters() if lctx is not None else {"lexems": 0, "bytes": 0, "failed_docs": 0}
-    mcount = mctx.batchCounters() if mctx is not None else {"results": 0, "items": 0, "events": 0, "failed_docs": 0}
-    if lcount["failed_docs"] or mcount["failed_docs"]:
-        raise SystemExit("bench: documents failed in the timed region")
+            size_until_ok(lambda: run_matcher(sh), mctx.batchCounters, mctx.batchStatus,
+                          lambda c: mctx.reserveOutput(int(c["results"] * 1.2) + 1024, int(c["items"] * 1.2) + 1024),
+                          mctx.growArena, sh.ndocs, "matcher")
 
-    tot = torch.tensor([float(nbytes), float(lcount["lexems"]), float(mcount["events"]), float(mcount["results"])], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)   # the path's only collective: counters
-        dt = float(tmax[0])
-    gbytes, glexems, gevents, gresults = (float(x) for x in tot)
+    def measure(sh, steps, warmup, collective):
+        for _ in range(warmup):
+            step(sh)
+        torch.cuda.synchronize()
+        if collective and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(sh)
+        torch.cuda.synchronize()
+        if collective and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # per-kernel launch durations: HIP events recorded by the library on the launch stream
+        l1_ms, l2_ms = [], []
+        for _ in range(min(steps, 5)):
+            step(sh)
+            if lctx is not None:
+                l1_ms.append(lctx.lastKernelMs())
+            if mctx is not None:
+                l2_ms.append(mctx.lastKernelMs())
+        lcount = lctx.batchCounters() if lctx is not None else {"lexems": 0, "bytes": 0, "failed_docs": 0}
+        mcount = mctx.batchCounters() if mctx is not None else {"results": 0, "items": 0, "events": 0, "failed_docs": 0}
+        if lcount["failed_docs"] or mcount["failed_docs"]:
+            raise SystemExit("bench: documents failed in the timed region")
+        return {"dt": dt, "steps": steps, "l1_ms": float(np.mean(l1_ms)) if l1_ms else 0.0, "l2_ms": float(np.mean(l2_ms)) if l2_ms else 0.0,
+                "lexems": int(lcount["lexems"]), "events": int(mcount["events"]), "results": int(mcount["results"]), "items": int(mcount["items"])}
+
+    # secondary shapes first (short, no barrier), the headline shape last so that its outputs are the
+    # ones left in the device buffers for the parity sample
+    secondary = {}
+    for sh in shapes[1:]:
+        secondary[sh.name] = measure(sh, max(2, min(args.steps, 5)), 1, False)
+    head = shapes[0]
+    m = measure(head, args.steps, args.warmup, True)
+
+    # the path's only collective: integer counters summed, wall time maxed over the ranks
+    local = {"bytes": nbytes, "lexems": m["lexems"], "events": m["events"], "results": m["results"]}
+    tot, dt = spdist.reduce_step(local, m["dt"], device=torch.device("cuda", local_rank))
 
     if rank == 0:
-        if wl == "l2":
-            value, unit, metric = gresults * args.steps / dt, "matches/s", METRIC + " [rule-automaton stage only: matches/s]"
-        else:
-            value, unit, metric = gbytes * args.steps / dt / 1e9, "GB/s", METRIC
-        # roofline of the dominant kernel (SURVEY.md 8(d) algorithmic bytes per launch)
-        if l1_ms >= l2_ms:
-            kname, kms = "spa_l1_lex_kernel", l1_ms
-            kbytes = float(nbytes) + 16.0 * lcount["lexems"]
-        else:
-            kname, kms = "spa_l2_match_kernel", l2_ms
-            kbytes = 16.0 * mcount["events"] + 36.0 * mcount["results"]
-        achieved = kbytes / (kms * 1e-3) / 1e9
-        out = {
-            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64" if wl != "l2" else "u32", "data": "synthetic",
-            "config": {"workload": {
-                "pipeline": "configs[4] per-GPU shard: %d regexes + %d token rules, %d docs x %d B UTF-8 per step" % (len(pats) if pats else 0, args.rules, ndocs, args.docbytes),
-                "lexer": "configs[1]: %d regexes, %d docs x %d B ASCII per step (lexer only)" % (len(pats) if pats else 0, ndocs, args.docbytes),
-                "l2": "configs[2]: %d rules (%s), %d docs x %d tokens per step (rule automaton only)" % (args.rules, args.op or "5-op Zipf mix", ndocs, args.docsize),
-            }[wl], "bytes_per_step_per_gpu": nbytes, "lexems_per_step_per_gpu": int(lcount["lexems"]),
-                "events_per_step_per_gpu": int(mcount["events"]), "matches_per_step_per_gpu": int(mcount["results"])},
-            "matches_per_s": gresults * args.steps / dt,
-            "events_per_s": gevents * args.steps / dt,
-            "lexems_per_s": glexems * args.steps / dt,
-            "kernel_ms": {"spa_l1_lex_kernel": l1_ms, "spa_l2_match_kernel": l2_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kname, wl, args), "kernel": kname, "kernel_ms": kms,
-                         "algorithmic_bytes_per_launch": kbytes},
-        }
+        out = report(args, wl, world, pats, head, m, tot, dt, secondary, nbytes, h2d_ms)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, wl, pats, rules, text, offs, lex, value, unit)
+            base, parity = cpu_baseline(args, wl, pats, rules, text, head, lex, lctx, mctx)
+            out["cpu_baseline"] = base
+            out["parity_sample"] = parity
         print(json.dumps(out))
+        if out.get("parity_sample") and not out["parity_sample"]["ok"]:
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit("bench: GPU results differ from the oracle on the parity sample: %s" % out["parity_sample"].get("mismatch"))
     if world > 1:
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, wl, args):
-    """HBM-side bytes per launch of `kernel` (read + write) from the committed rocprofv3 PMC passes of
-    this same command (tests/micro/profile_bench.sh -> profiles/r01_bench_pmc_summary.json; FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself,
-    so the figure is only reported for the default workload and configuration it was collected on."""
-    if wl != "pipeline" or args.docs or args.regexes:
-        return None
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")
+def roofline_of(kernel, kms, kbytes, traffic=None, source=None):
+    achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": traffic, "kernel": kernel, "kernel_ms": kms, "algorithmic_bytes_per_launch": kbytes}
+    if source:
+        r["traffic_source"] = source
+    return r
+
+
+def report(args, wl, world, pats, head, m, tot, dt, secondary, nbytes, h2d_ms):
+    steps = args.steps
+    gbytes, gresults, gevents, glexems = tot["bytes"], tot["results"], tot["events"], tot["lexems"]
+    if wl == "l2":
+        value, unit, metric = gresults * steps / dt, "matches/s", METRIC + " [rule-automaton stage only: matches/s]"
+    else:
+        value, unit, metric = gbytes * steps / dt / 1e9, "GB/s", METRIC
+    # algorithmic bytes per launch (SURVEY.md 8(d)): L1 = text + 16 B x lexems; L2 = 16 B x events + 36 B x results;
+    # pipeline = text + 36 B x results
+    b_l1 = float(nbytes) + 16.0 * m["lexems"]
+    b_l2 = 16.0 * m["events"] + 36.0 * m["results"]
+    roofs = {}
+    if m["l1_ms"] > 0:
+        roofs["spa_l1_lex_kernel"] = roofline_of("spa_l1_lex_kernel", m["l1_ms"], b_l1, *pmc_traffic("spa_l1_lex_kernel", wl, args, m["l1_ms"]))
+    if m["l2_ms"] > 0:
+        roofs["spa_l2_match_kernel"] = roofline_of("spa_l2_match_kernel", m["l2_ms"], b_l2, *pmc_traffic("spa_l2", wl, args, m["l2_ms"]))
+    dominant = max(roofs.values(), key=lambda r: r["kernel_ms"])
+    if wl == "pipeline":
+        roofs["pipeline"] = roofline_of("lexer + automaton", m["l1_ms"] + m["l2_ms"], float(nbytes) + 36.0 * m["results"])
+    workload = {
+        "pipeline": "configs[4] per-GPU shard: %d regexes + %d token rules, %d docs x %s UTF-8 per step" % (len(pats) if pats else 0, args.rules, head.ndocs, head.name),
+        "lexer": "configs[1]: %d regexes, %d docs x %s ASCII per step (lexer only)" % (len(pats) if pats else 0, head.ndocs, head.name),
+        "l2": "configs[2]: %d rules (%s), %d docs x %d tokens per step (rule automaton only)" % (args.rules, args.op or "5-op Zipf mix", head.ndocs, args.docsize),
+    }[wl]
+    out = {
+        "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64" if wl != "l2" else "u32", "data": "synthetic",
+        "config": {"workload": workload, "bytes_per_step_per_gpu": nbytes, "lexems_per_step_per_gpu": m["lexems"],
+                   "events_per_step_per_gpu": m["events"], "matches_per_step_per_gpu": m["results"]},
+        "matches_per_s": gresults * steps / dt,
+        "events_per_s": gevents * steps / dt,
+        "lexems_per_s": glexems * steps / dt,
+        "kernel_ms": {"spa_l1_lex_kernel": m["l1_ms"], "spa_l2_match_kernel": m["l2_ms"]},
+        "roofline": dominant,
+        "roofline_all": roofs,
+    }
+    if secondary:
+        out["config"]["shapes"] = {head.name: {"GB/s": value / world if wl != "l2" else None, "ms_per_step": dt / steps * 1e3,
+                                               "kernel_ms": [m["l1_ms"], m["l2_ms"]], "matches": m["results"]}}
+        for name, s in secondary.items():
+            out["config"]["shapes"][name] = {"GB/s": nbytes * s["steps"] / s["dt"] / 1e9, "ms_per_step": s["dt"] / s["steps"] * 1e3,
+                                             "kernel_ms": [s["l1_ms"], s["l2_ms"]], "matches": s["results"],
+                                             "note": "rank 0, same bytes cut into %s documents, %d steps, no barrier" % (name, s["steps"])}
+    if h2d_ms is not None:
+        out["h2d_staging_ms"] = h2d_ms
+        out["h2d_inclusive_GBps"] = nbytes / (dt / steps + h2d_ms * 1e-3) / 1e9
+    return out
+
+
+def pmc_traffic(kernel_prefix, wl, args, kernel_ms):
+    """HBM-side bytes per launch (read + write) of the kernel from the committed rocprofv3 PMC passes of this
+    same command (tests/micro/profile_bench.sh -> profiles/r02_bench_pmc_summary.json; FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself: the figure is
+    reported only for the default configuration and only while the profiled kernel ran as long as the one
+    timed here (within 15 %), i.e. it is the same kernel revision on the same work."""
+    if wl != "pipeline" or args.docs or args.regexes or args.docbytes:
+        return None, None
     try:
-        with open(path) as f:
+        with open(PMC_SUMMARY) as f:
             summ = json.load(f)
         for name, k in summ["kernels"].items():
-            if name.startswith(kernel):
-                return float(k["hbm_read_bytes_per_launch"]) + float(k["hbm_write_bytes_per_launch"])
+            if name.startswith(kernel_prefix):
+                pms = float(k.get("kernel_ms_steady", k.get("kernel_ms", 0.0)))
+                if pms <= 0 or abs(pms - kernel_ms) > 0.15 * kernel_ms:
+                    return None, None
+                return (float(k["hbm_read_bytes_per_launch"]) + float(k["hbm_write_bytes_per_launch"]),
+                        "profiles/" + os.path.basename(PMC_SUMMARY) + " (%s)" % summ.get("commit", "?"))
     except (OSError, KeyError, ValueError):
         pass
+    return None, None
+
+
+def first_difference(gl, gr, rl, rr):
+    """compares lexems / results / items / statistics of the GPU sample with the oracle's; None when equal"""
+    if not (np.array_equal(gl.doc_offsets, rl[1]) and np.array_equal(gl.lexems, rl[0])):
+        return "lexems"
+    if gr is None:
+        return None
+    if not np.array_equal(gr.doc_offsets, rr.doc_offsets):
+        return "result counts per document"
+    if not np.array_equal(gr.results[:, :7], rr.results[:, :7]):
+        return "result tuples"
+    if not (np.array_equal(gr.results[:, 8], rr.results[:, 8]) and np.array_equal(gr.items, rr.items)):
+        return "result items"
+    if not np.array_equal(gr.stats, rr.stats):
+        return "statistics"
     return None
 
 
-def cpu_baseline(args, wl, pats, rules, text, offs, lex, gpu_value, unit):
-    """The oracle (CPU restatement of the reference path) timed on a bounded sample of rank 0's shard.
+def cpu_baseline(args, wl, pats, rules, text, head, lex, lctx, mctx):
+    """The oracle (CPU restatement of the reference path) timed on a bounded sample of rank 0's shard, and
+    its outputs compared with what the GPU produced for the same documents in the last timed launch.
     The reference's own lexer stage is Intel Hyperscan, which is not available here: the L1 number is
-    the scalar NFA restatement ("port"), not Hyperscan."""
+    the scalar NFA restatement ("port"), not Hyperscan.  SURVEY.md 8(d): L2 at 1 thread and at all cores."""
     import oracle
     from struspattern_amd import synth
     # a one-GPU box grants about 16 host cores to the job whatever os.cpu_count() says
     ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    offs = head.offs
     if wl == "l2":
         o = oracle.L2Matcher()
         synth.apply_rules(o, rules)
-        nd = max(1, min(len(offs) - 1, int(args.cpu_seconds * 200000 / max(1, args.docsize))))
+        nd = max(1, min(len(offs) - 1, int(args.cpu_seconds * 100000 / max(1, args.docsize))))
         sub = synth.lexems5(lex[:int(offs[nd])])
         t0 = time.perf_counter()
         r = o.run(sub, offs[:nd + 1], nthreads=1)
-        dt = time.perf_counter() - t0
-        return {"value": len(r.results) / dt, "unit": "matches/s", "cores": 1, "kind": "port", "events_per_s": int(offs[nd]) / dt,
-                "sample": "first %d documents of rank 0's shard (%d events), oracle/l2_oracle.cpp, 1 thread, %.1f s" % (nd, int(offs[nd]), dt)}
+        t1 = time.perf_counter()
+        rall = o.run(sub, offs[:nd + 1], nthreads=ncores)
+        t2 = time.perf_counter()
+        gr = mctx.batchFetch(0, nd)
+        diff = None
+        for what, a, b in (("result counts per document", gr.doc_offsets, r.doc_offsets), ("result tuples", gr.results[:, :7], r.results[:, :7]),
+                           ("result items", gr.items, r.items), ("statistics", gr.stats, r.stats)):
+            if diff is None and not np.array_equal(a, b):
+                diff = what
+        base = {"value": len(rall.results) / (t2 - t1), "unit": "matches/s", "cores": ncores, "kind": "port",
+                "l2": {"events_per_s_1thread": int(offs[nd]) / (t1 - t0), "events_per_s_allcores": int(offs[nd]) / (t2 - t1),
+                       "matches_per_s_1thread": len(r.results) / (t1 - t0), "cores": ncores},
+                "sample": "first %d documents of rank 0's shard (%d events), oracle/l2_oracle.cpp, 1 thread %.1f s, %d threads %.1f s" % (nd, int(offs[nd]), t1 - t0, ncores, t2 - t1)}
+        return base, {"docs": nd, "ok": diff is None, "mismatch": diff, "compared": "results in firing order, items, statistics"}
     ol = oracle.L1Lexer()
     synth.apply_lexer_patterns(ol, pats)
-    # calibrate on one document, then size the sample for about cpu_seconds of wall time on all cores
+    # calibrate on one 16 KB slice, then size the sample for about cpu_seconds of wall time on all cores
+    cal = min(int(offs[1]), 16384)
     t0 = time.perf_counter()
-    ol.matchDocs(text[:int(offs[1])], offs[:2], nthreads=1)
-    t_doc = max(1e-3, time.perf_counter() - t0)
-    nd = max(1, min(len(offs) - 1, int(args.cpu_seconds * ncores / t_doc / 1.5)))
+    ol.matchDocs(text[:cal], np.array([0, cal], np.uint64), nthreads=1)
+    t_byte = max(1e-9, (time.perf_counter() - t0) / max(1, cal))
+    doc_bytes = int(offs[1]) if len(offs) > 1 else 1
+    nd = max(1, min(len(offs) - 1, int(args.cpu_seconds * ncores / (t_byte * doc_bytes) / 1.5)))
+    nthreads = min(ncores, nd)
     sub_text = text[:int(offs[nd])]
     t0 = time.perf_counter()
-    lexems, loffs = ol.matchDocs(sub_text, offs[:nd + 1], nthreads=min(ncores, nd))
+    lexems, loffs = ol.matchDocs(sub_text, offs[:nd + 1], nthreads=nthreads)
     t1 = time.perf_counter()
-    out = {"value": len(sub_text) / (t1 - t0) / 1e9, "unit": "GB/s", "cores": min(ncores, nd), "kind": "port",
-           "sample": "first %d documents of rank 0's shard (%d bytes), oracle lexer (scalar NFA restatement, NOT Hyperscan), %d threads, %.1f s" % (
-               nd, len(sub_text), min(ncores, nd), t1 - t0)}
+    base = {"value": len(sub_text) / (t1 - t0) / 1e9, "unit": "GB/s", "cores": nthreads, "kind": "port",
+            "l1": {"GBps": len(sub_text) / (t1 - t0) / 1e9, "cores": nthreads, "kind": "port",
+                   "note": "oracle lexer: scalar NFA restatement, NOT Hyperscan (reference Hyperscan timing unavailable: library absent)"},
+            "sample": "first %d documents of rank 0's shard (%d bytes), oracle lexer %d threads %.1f s" % (nd, len(sub_text), nthreads, t1 - t0)}
+    gl = lctx.batchFetch(0, nd)
+    gr = rr = None
     if wl == "pipeline":
         om = oracle.L2Matcher()
         synth.apply_rules(om, rules)
-        r = om.run(synth.lexems5(lexems), loffs, nthreads=min(ncores, nd))
+        rr = om.run(synth.lexems5(lexems), loffs, nthreads=nthreads)
         t2 = time.perf_counter()
-        out["value"] = len(sub_text) / (t2 - t0) / 1e9
-        out["matches_per_s"] = len(r.results) / (t2 - t0)
-        out["sample"] += " + oracle automaton %.1f s" % (t2 - t1)
-    return out
+        base["value"] = len(sub_text) / (t2 - t0) / 1e9
+        base["matches_per_s"] = len(rr.results) / (t2 - t0)
+        base["sample"] += " + oracle automaton %.2f s" % (t2 - t1)
+        gr = mctx.batchFetch(0, nd)
+        # L2 restatement alone (SURVEY.md 8(d)): a larger slice of the GPU lexer's output (equal to the oracle
+        # lexer's on the parity sample) so that the timing is not dominated by thread start-up
+        n2 = max(nd, min(len(offs) - 1, int(args.cpu_seconds * 250000 * 6 / max(1, doc_bytes))))
+        g2 = lctx.batchFetch(0, n2)
+        l5 = synth.lexems5(g2.lexems)
+        t3 = time.perf_counter()
+        r1 = om.run(l5, g2.doc_offsets, nthreads=1)
+        t4 = time.perf_counter()
+        om.run(l5, g2.doc_offsets, nthreads=ncores)
+        t5 = time.perf_counter()
+        base["l2"] = {"events_per_s_1thread": len(l5) / (t4 - t3), "events_per_s_allcores": len(l5) / (t5 - t4),
+                      "matches_per_s_1thread": len(r1.results) / (t4 - t3), "cores": ncores, "kind": "port",
+                      "sample": "%d documents (%d events): lexer output of the GPU for rank 0's first documents, oracle/l2_oracle.cpp" % (n2, len(l5))}
+    diff = first_difference(gl, gr, (lexems, loffs), rr)
+    return base, {"docs": nd, "ok": diff is None, "mismatch": diff,
+                  "compared": "lexems, results in firing order, items, statistics of the last timed launch vs the oracle"}
 
 
 if __name__ == "__main__":

@@ -207,6 +207,9 @@ int sp_matcher_ctx_match_lexed_device(sp_matcher_ctx_t* c, const void* d_lexems,
 /* copies the results of the last device batch to the host, grouped by document (as sp_matcher_ctx_match_docs
  * returns them, `exclusive` elimination included) */
 int sp_matcher_ctx_batch_fetch(sp_matcher_ctx_t* c, sp_match_batch_t* out);
+/* the same for the documents [first_doc, first_doc+ndocs) of the last device batch only (a caller that checks a
+ * sample, or picks up the documents of one shard, does not move the whole batch over PCIe) */
+int sp_matcher_ctx_batch_fetch_docs(sp_matcher_ctx_t* c, size_t first_doc, size_t ndocs, sp_match_batch_t* out);
 /* waits for the stream and returns counters[0..7] = {results, items, events, failed docs, 0..} */
 int sp_matcher_ctx_batch_counters(sp_matcher_ctx_t* c, uint64_t counters[8]);
 /* duration of the last rule-automaton kernel in milliseconds (HIP events on the launch stream) */
@@ -274,6 +277,9 @@ typedef struct sp_lex_device_batch {
 /* device-resident text and offsets, asynchronous on `stream` (hipStream_t); lexems stay in HBM */
 int sp_lexer_ctx_match_docs_device(sp_lexer_ctx_t* c, const void* d_text, const void* d_doc_offsets,
                                    size_t ndocs, size_t nbytes, void* stream, sp_lex_device_batch_t* out);
+/* host copy of the lexems of the documents [first_doc, first_doc+ndocs) of the last device batch
+ * (what PatternLexerContextInterface::match returns for each of them, src/patternLexer.cpp:858) */
+int sp_lexer_ctx_batch_fetch_docs(sp_lexer_ctx_t* c, size_t first_doc, size_t ndocs, sp_lex_batch_t* out);
 int sp_lexer_ctx_batch_counters(sp_lexer_ctx_t* c, uint64_t counters[8]);
 int sp_lexer_ctx_batch_status(sp_lexer_ctx_t* c, int32_t* status, size_t ndocs);
 double sp_lexer_ctx_last_kernel_ms(sp_lexer_ctx_t* c);

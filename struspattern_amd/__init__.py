@@ -160,10 +160,14 @@ class PatternMatcherContext:
             raise PatternError("device batch match failed (%d): %s" % (rc, self._err()))
         return out
 
-    def batchFetch(self):
-        """host copy of the last device batch, grouped by document."""
+    def batchFetch(self, first_doc=None, ndocs=None):
+        """host copy of the last device batch, grouped by document; with (first_doc, ndocs) only of
+        that range of documents."""
         b = capi.SpMatchBatch()
-        rc = self._L.sp_matcher_ctx_batch_fetch(self._h, ctypes.byref(b))
+        if first_doc is None:
+            rc = self._L.sp_matcher_ctx_batch_fetch(self._h, ctypes.byref(b))
+        else:
+            rc = self._L.sp_matcher_ctx_batch_fetch_docs(self._h, first_doc, ndocs, ctypes.byref(b))
         try:
             if rc != 0:
                 raise PatternError("fetching the batch failed (%d): %s" % (rc, self._err()))
@@ -369,6 +373,20 @@ class PatternLexerContext:
         if rc != 0:
             raise PatternError("device batch lexer run failed (%d): %s" % (rc, self._err()))
         return out
+
+    def batchFetch(self, first_doc, ndocs):
+        """host copy of the lexems of the documents [first_doc, first_doc+ndocs) of the last device batch."""
+        b = capi.SpLexBatch()
+        rc = self._L.sp_lexer_ctx_batch_fetch_docs(self._h, first_doc, ndocs, ctypes.byref(b))
+        try:
+            if rc != 0:
+                raise PatternError("fetching the lexer batch failed (%d): %s" % (rc, self._err()))
+            lex = np.ctypeslib.as_array(ctypes.cast(b.lexems, ctypes.POINTER(ctypes.c_uint32)), shape=(b.nlexems * 4 + 1,))[:b.nlexems * 4].reshape(-1, 4).copy()
+            offs = np.ctypeslib.as_array(b.doc_lexem_offsets, shape=(ndocs + 1,)).copy()
+            status = np.ctypeslib.as_array(b.doc_status, shape=(ndocs + 1,))[:ndocs].copy()
+        finally:
+            self._L.sp_lex_batch_free(ctypes.byref(b))
+        return LexBatch(lex, offs, status)
 
     def batchCounters(self):
         arr = (ctypes.c_uint64 * 8)()

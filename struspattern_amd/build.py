@@ -6,7 +6,8 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "_build", "libstruspattern_amd.so")
+# SPA_LIB: a variant library built out of tree (tests/micro/ab.sh); the product library otherwise
+LIB = os.environ.get("SPA_LIB") or os.path.join(HERE, "_build", "libstruspattern_amd.so")
 
 
 HOST_LIB = os.path.join(HERE, "_build", "libstrus_pattern.so")
@@ -34,6 +35,8 @@ def build_host(quiet=True):
 
 
 def needs_build():
+    if os.environ.get("SPA_LIB"):
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)

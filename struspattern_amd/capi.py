@@ -94,6 +94,7 @@ SIGNATURES = {
     "sp_matcher_ctx_match_docs_device": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, ctypes.c_size_t, c_vp, P(SpMatchDeviceBatch)]),
     "sp_matcher_ctx_match_lexed_device": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, ctypes.c_size_t, c_vp, P(SpMatchDeviceBatch)]),
     "sp_matcher_ctx_batch_fetch": (ctypes.c_int, [c_vp, P(SpMatchBatch)]),
+    "sp_matcher_ctx_batch_fetch_docs": (ctypes.c_int, [c_vp, ctypes.c_size_t, ctypes.c_size_t, P(SpMatchBatch)]),
     "sp_matcher_ctx_batch_counters": (ctypes.c_int, [c_vp, P(c_u64)]),
     "sp_matcher_ctx_last_kernel_ms": (ctypes.c_double, [c_vp]),
     "sp_matcher_ctx_batch_status": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t]),
@@ -119,6 +120,7 @@ SIGNATURES = {
     "sp_lexer_ctx_match_docs": (ctypes.c_int, [c_vp, c_cp, c_vp, ctypes.c_size_t, P(SpLexBatch)]),
     "sp_lex_batch_free": (None, [P(SpLexBatch)]),
     "sp_lexer_ctx_match_docs_device": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, ctypes.c_size_t, c_vp, P(SpLexDeviceBatch)]),
+    "sp_lexer_ctx_batch_fetch_docs": (ctypes.c_int, [c_vp, ctypes.c_size_t, ctypes.c_size_t, P(SpLexBatch)]),
     "sp_lexer_ctx_batch_counters": (ctypes.c_int, [c_vp, P(c_u64)]),
     "sp_lexer_ctx_batch_status": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t]),
     "sp_lexer_ctx_last_kernel_ms": (ctypes.c_double, [c_vp]),

@@ -255,12 +255,13 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 		size_t full = (size_t)c->numCUs*20;
 		if (full * perWaveWords*4 > ((size_t)48 << 30)) full = ((size_t)48 << 30) / (perWaveWords*4);
 		unsigned alloc = nwaves < full ? (unsigned)full : nwaves;
+		c->arenaWaves = 0;
 		c->dArena.alloc( (size_t)alloc * perWaveWords * 4);
 		c->arenaWaves = alloc; c->arenaWords = perWaveWords;
 	}
 	uint64_t want = (uint64_t)nbytes/3 + 4096;
 	if (want < c->minLexemCapacity) want = c->minLexemCapacity;
-	if (c->lexemCapacity < want) { c->dLexems.alloc( want*sizeof(sp_lexem_t)); c->lexemCapacity = want; }
+	if (c->lexemCapacity < want) { c->lexemCapacity = 0; c->dLexems.alloc( want*sizeof(sp_lexem_t)); c->lexemCapacity = want; }	// (capacity follows the buffer also when the allocation fails)
 	c->dDocRange.reserve( (ndocs+1)*2*sizeof(uint64_t));
 	c->dDocStatus.reserve( (ndocs+1)*sizeof(int32_t));
 	HIP_CHECK( hipMemsetAsync( c->dCounters.ptr, 0, L1C_ALLOC*sizeof(uint64_t), stream));
@@ -342,6 +343,7 @@ int sp_lexer_ctx_match_docs( sp_lexer_ctx_t* c, const char* text, const uint64_t
 {
 	std::memset( out, 0, sizeof(*out));
 	int rc = guardedCall1( c->lasterror, SP_ERR_INVALID, [&]{
+		if (ndocs >= 0xFFFFFFFFull) throw std::runtime_error( "too many documents in one batch");
 		HIP_CHECK( hipSetDevice( c->device));
 		size_t nbytes = ndocs ? (size_t)doc_offsets[ ndocs] : 0;
 		for (size_t di=0; di<ndocs; ++di)
@@ -404,6 +406,47 @@ int sp_lexer_ctx_match_docs( sp_lexer_ctx_t* c, const char* text, const uint64_t
 	});
 	if (rc == SP_OK) return SP_OK;
 	return c->lasterror.find( "document failed") != std::string::npos ? SP_ERR_MATCH : rc;
+}
+
+// host copy of the lexems of the documents [first_doc, first_doc+ndocs) of the last device batch
+int sp_lexer_ctx_batch_fetch_docs( sp_lexer_ctx_t* c, size_t first_doc, size_t ndocs, sp_lex_batch_t* out)
+{
+	std::memset( out, 0, sizeof(*out));
+	return guardedCall1( c->lasterror, SP_ERR_DEVICE, [&]{
+		HIP_CHECK( hipSetDevice( c->device));
+		HIP_CHECK( hipStreamSynchronize( c->lastStream));
+		if (first_doc > c->lastNdocs || ndocs > c->lastNdocs - first_doc) throw std::runtime_error( "document range outside the last batch");
+		uint64_t counters[ L1C_COUNT];
+		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
+		const uint64_t devLexems = counters[ L1C_LEXEMS] < c->lexemCapacity ? counters[ L1C_LEXEMS] : c->lexemCapacity;
+		std::vector<uint64_t> range( ndocs*2+2);
+		out->ndocs = ndocs;
+		out->doc_lexem_offsets = (uint64_t*)std::malloc( (ndocs+1)*sizeof(uint64_t));
+		out->doc_status = (int32_t*)std::malloc( (ndocs+1)*sizeof(int32_t));
+		if (!out->doc_lexem_offsets || !out->doc_status) throw std::bad_alloc();
+		if (ndocs)
+		{
+			HIP_CHECK( hipMemcpy( range.data(), (const uint64_t*)c->dDocRange.ptr + 2*first_doc, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
+			HIP_CHECK( hipMemcpy( out->doc_status, (const int32_t*)c->dDocStatus.ptr + first_doc, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+		}
+		uint64_t total = 0;
+		for (size_t di=0; di<ndocs; ++di)
+		{
+			if (out->doc_status[ di] != 0 || range[ 2*di] + range[ 2*di+1] > devLexems) range[ 2*di+1] = 0;
+			total += range[ 2*di+1];
+		}
+		out->lexems = (sp_lexem_t*)std::malloc( (total+1)*sizeof(sp_lexem_t));
+		if (!out->lexems) throw std::bad_alloc();
+		uint64_t lp = 0;
+		for (size_t di=0; di<ndocs; ++di)
+		{
+			out->doc_lexem_offsets[ di] = lp;
+			if (range[ 2*di+1]) HIP_CHECK( hipMemcpy( out->lexems + lp, (const sp_lexem_t*)c->dLexems.ptr + range[ 2*di], range[ 2*di+1]*sizeof(sp_lexem_t), hipMemcpyDeviceToHost));
+			lp += range[ 2*di+1];
+		}
+		out->doc_lexem_offsets[ ndocs] = lp;
+		out->nlexems = lp;
+	});
 }
 
 void sp_lex_batch_free( sp_lex_batch_t* b)

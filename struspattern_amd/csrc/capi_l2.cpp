@@ -244,12 +244,15 @@ int sp_matcher_ctx_set_arena( sp_matcher_ctx_t* c, uint32_t max_rules, uint32_t 
 
 namespace {
 
-// Host copy of the device results of the last launch, regrouped by document (the device appends whole
-// documents in completion order), with the `exclusive` elimination of fetchResults applied on the way.
-void copyOutBatch( sp_matcher_ctx* c, size_t ndocs, const uint64_t* counters, sp_match_batch_t* out)
+// Host copy of the device results of the last launch for the documents [firstDoc, firstDoc+ndocs), regrouped
+// by document (the device appends whole documents in completion order), with the `exclusive`
+// elimination of fetchResults applied on the way.  The whole batch is copied in bulk; a sub-range
+// copies only the result and item blocks of its own documents.
+void copyOutBatch( sp_matcher_ctx* c, size_t firstDoc, size_t ndocs, const uint64_t* counters, sp_match_batch_t* out)
 {
+	const bool whole = (firstDoc == 0 && ndocs == c->lastNdocs);
 	std::vector<uint64_t> range( ndocs*2+2);
-	if (ndocs) HIP_CHECK( hipMemcpy( range.data(), c->dDocRange.ptr, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
+	if (ndocs) HIP_CHECK( hipMemcpy( range.data(), (const uint64_t*)c->dDocRange.ptr + 2*firstDoc, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
 	out->ndocs = ndocs;
 	out->doc_stats = (uint64_t*)std::malloc( (ndocs*4+1)*sizeof(uint64_t));
 	out->doc_status = (int32_t*)std::malloc( (ndocs+1)*sizeof(int32_t));
@@ -257,21 +260,60 @@ void copyOutBatch( sp_matcher_ctx* c, size_t ndocs, const uint64_t* counters, sp
 	if (!out->doc_stats || !out->doc_status || !out->doc_result_offsets) throw std::bad_alloc();
 	if (ndocs)
 	{
-		HIP_CHECK( hipMemcpy( out->doc_stats, c->dDocStats.ptr, ndocs*4*sizeof(uint64_t), hipMemcpyDeviceToHost));
-		HIP_CHECK( hipMemcpy( out->doc_status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+		HIP_CHECK( hipMemcpy( out->doc_stats, (const uint64_t*)c->dDocStats.ptr + 4*firstDoc, ndocs*4*sizeof(uint64_t), hipMemcpyDeviceToHost));
+		HIP_CHECK( hipMemcpy( out->doc_status, (const int32_t*)c->dDocStatus.ptr + firstDoc, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
 	}
-	uint64_t nres = counters[ SPC_RESULTS] < c->resultCapacity ? counters[ SPC_RESULTS] : c->resultCapacity;
-	uint64_t nitems = counters[ SPC_ITEMS] < c->itemCapacity ? counters[ SPC_ITEMS] : c->itemCapacity;
-	std::vector<sp_result_t> raw( nres+1);
-	std::vector<sp_result_item_t> rawitems( nitems+1);
-	if (nres) HIP_CHECK( hipMemcpy( raw.data(), c->dResults.ptr, nres*sizeof(sp_result_t), hipMemcpyDeviceToHost));
-	if (nitems) HIP_CHECK( hipMemcpy( rawitems.data(), c->dItems.ptr, nitems*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
+	const uint64_t devResults = counters[ SPC_RESULTS] < c->resultCapacity ? counters[ SPC_RESULTS] : c->resultCapacity;
+	const uint64_t devItems = counters[ SPC_ITEMS] < c->itemCapacity ? counters[ SPC_ITEMS] : c->itemCapacity;
+	std::vector<sp_result_t> raw;
+	std::vector<sp_result_item_t> rawitems;
 	std::vector<uint32_t> rawrf, rawif;
-	if (c->withFormats)
+	if (whole)
 	{
-		rawrf.resize( nres+1); rawif.resize( 2*nitems+2);
-		if (nres) HIP_CHECK( hipMemcpy( rawrf.data(), c->dResultFormat.ptr, nres*sizeof(uint32_t), hipMemcpyDeviceToHost));
-		if (nitems) HIP_CHECK( hipMemcpy( rawif.data(), c->dItemFormat.ptr, 2*nitems*sizeof(uint32_t), hipMemcpyDeviceToHost));
+		raw.resize( devResults+1); rawitems.resize( devItems+1);
+		if (devResults) HIP_CHECK( hipMemcpy( raw.data(), c->dResults.ptr, devResults*sizeof(sp_result_t), hipMemcpyDeviceToHost));
+		if (devItems) HIP_CHECK( hipMemcpy( rawitems.data(), c->dItems.ptr, devItems*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
+		if (c->withFormats)
+		{
+			rawrf.resize( devResults+1); rawif.resize( 2*devItems+2);
+			if (devResults) HIP_CHECK( hipMemcpy( rawrf.data(), c->dResultFormat.ptr, devResults*sizeof(uint32_t), hipMemcpyDeviceToHost));
+			if (devItems) HIP_CHECK( hipMemcpy( rawif.data(), c->dItemFormat.ptr, 2*devItems*sizeof(uint32_t), hipMemcpyDeviceToHost));
+		}
+	}
+	else
+	{
+		// the blocks of the wanted documents only, packed one after the other; ranges and item indices are rebased
+		uint64_t nres = 0;
+		for (size_t di=0; di<ndocs; ++di) if (out->doc_status[ di] == 0 && range[ 2*di] + range[ 2*di+1] <= devResults) nres += range[ 2*di+1];
+		raw.resize( nres+1);
+		if (c->withFormats) rawrf.resize( nres+1);
+		uint64_t rp0 = 0;
+		for (size_t di=0; di<ndocs; ++di)
+		{
+			const uint64_t b = range[ 2*di], n = range[ 2*di+1];
+			if (out->doc_status[ di] != 0 || b + n > devResults) { range[ 2*di+1] = 0; continue; }
+			if (n) HIP_CHECK( hipMemcpy( raw.data() + rp0, (const sp_result_t*)c->dResults.ptr + b, n*sizeof(sp_result_t), hipMemcpyDeviceToHost));
+			if (n && c->withFormats) HIP_CHECK( hipMemcpy( rawrf.data() + rp0, (const uint32_t*)c->dResultFormat.ptr + b, n*sizeof(uint32_t), hipMemcpyDeviceToHost));
+			range[ 2*di] = rp0; rp0 += n;
+		}
+		uint64_t nitems = 0;
+		for (uint64_t ri=0; ri<nres; ++ri) nitems += raw[ ri].item_count;
+		rawitems.resize( nitems+1);
+		if (c->withFormats) rawif.resize( 2*nitems+2);
+		uint64_t ip0 = 0;
+		for (size_t di=0; di<ndocs; ++di)
+		{
+			// the items of one document are one block, in result order
+			const uint64_t b = range[ 2*di], n = range[ 2*di+1];
+			uint64_t first = 0, cnt = 0;
+			for (uint64_t ri=0; ri<n; ++ri) if (raw[ b+ri].item_count) { if (!cnt) first = raw[ b+ri].item_begin; cnt += raw[ b+ri].item_count; }
+			if (!cnt) continue;
+			if (first + cnt > devItems) throw std::runtime_error( "item block of a document lies outside the device buffer");
+			HIP_CHECK( hipMemcpy( rawitems.data() + ip0, (const sp_result_item_t*)c->dItems.ptr + first, cnt*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
+			if (c->withFormats) HIP_CHECK( hipMemcpy( rawif.data() + 2*ip0, (const uint32_t*)c->dItemFormat.ptr + 2*first, 2*cnt*sizeof(uint32_t), hipMemcpyDeviceToHost));
+			for (uint64_t ri=0; ri<n; ++ri) if (raw[ b+ri].item_count) raw[ b+ri].item_begin = (uint32_t)(raw[ b+ri].item_begin - first + ip0);
+			ip0 += cnt;
+		}
 	}
 	// regroup by document (the device appends whole documents in completion order)
 	uint64_t total = 0, totalItems = 0;
@@ -348,7 +390,21 @@ int sp_matcher_ctx_batch_fetch( sp_matcher_ctx_t* c, sp_match_batch_t* out)
 		size_t ndocs = c->lastNdocs;
 		uint64_t counters[ SPC_COUNT];
 		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
-		copyOutBatch( c, ndocs, counters, out);
+		copyOutBatch( c, 0, ndocs, counters, out);
+	});
+}
+
+// the same for the documents [first_doc, first_doc+ndocs) of the last batch only
+int sp_matcher_ctx_batch_fetch_docs( sp_matcher_ctx_t* c, size_t first_doc, size_t ndocs, sp_match_batch_t* out)
+{
+	std::memset( out, 0, sizeof(*out));
+	return guardedCall( c->lasterror, SP_ERR_DEVICE, [&]{
+		HIP_CHECK( hipSetDevice( c->device));
+		HIP_CHECK( hipStreamSynchronize( c->lastStream));
+		if (first_doc > c->lastNdocs || ndocs > c->lastNdocs - first_doc) throw std::runtime_error( "document range outside the last batch");
+		uint64_t counters[ SPC_COUNT];
+		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
+		copyOutBatch( c, first_doc, ndocs, counters, out);
 	});
 }
 
@@ -410,21 +466,27 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		size_t full = (size_t)c->numCUs*SPA_L2_WAVES_PER_CU;
 		if (full * perWave > ((size_t)48 << 30)) full = ((size_t)48 << 30) / perWave;
 		unsigned alloc = nwaves < full ? (unsigned)full : nwaves;	// allocate for the full machine once
+		c->arenaWaves = 0;
 		c->dArena.alloc( (size_t)alloc * perWave);
 		c->arenaWaves = alloc;
 	}
 	// output capacity: results are bounded by what fits; sized from the input, grown by the caller on SP_DOC_ERR_ARENA
 	uint64_t wantResults = (uint64_t)nlexems*2 + 1024;
 	if (wantResults < c->minResultCapacity) wantResults = c->minResultCapacity;
+	// item indices in a result record are 32 bit: a batch that needs more fails with SP_DOC_ERR_OUTPUT instead of wrapping
+	if (wantResults > 0xFFFFFFFFull) wantResults = 0xFFFFFFFFull;
 	if (c->resultCapacity < wantResults)
 	{
+		c->resultCapacity = 0;		// the capacity follows the buffer: a failed allocation leaves {NULL, 0}, never {NULL, old capacity}
 		c->dResults.alloc( wantResults*sizeof(sp_result_t));
 		c->resultCapacity = wantResults;
 	}
 	uint64_t wantItems = (uint64_t)nlexems*6 + 1024;
 	if (wantItems < c->minItemCapacity) wantItems = c->minItemCapacity;
+	if (wantItems > 0xFFFFFFFFull) wantItems = 0xFFFFFFFFull;
 	if (c->itemCapacity < wantItems)
 	{
+		c->itemCapacity = 0;
 		c->dItems.alloc( wantItems*sizeof(sp_result_item_t));
 		c->itemCapacity = wantItems;
 	}
@@ -566,6 +628,7 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 {
 	std::memset( out, 0, sizeof(*out));
 	return guardedCall( c->lasterror, SP_ERR_INVALID, [&]{
+		if (ndocs >= 0xFFFFFFFFull) throw std::runtime_error( "too many documents in one batch");
 		HIP_CHECK( hipSetDevice( c->device));
 		size_t nlex = ndocs ? (size_t)doc_offsets[ ndocs] : 0;
 		c->dLexems.reserve( (nlex+1)*sizeof(sp_lexem_t));
@@ -601,7 +664,7 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 			}
 			if (!grow || attempt >= 12) break;
 		}
-		copyOutBatch( c, ndocs, counters, out);
+		copyOutBatch( c, 0, ndocs, counters, out);
 		if (counters[ SPC_FAILED])
 		{
 			size_t bad = 0;

@@ -5,6 +5,7 @@
 #include <stdexcept>
 #include <string>
 #include <cstddef>
+#include <cstdlib>
 
 namespace spa {
 
@@ -28,6 +29,8 @@ struct DeviceBuffer
 	{
 		release();
 		if (n == 0) n = 16;
+		// test hook (tests/test_l2_gpu.py): allocations of at least this many bytes fail like an out-of-memory hipMalloc
+		if (const char* lim = std::getenv( "SPA_TEST_FAIL_ALLOC_ABOVE")) { if (n >= std::strtoull( lim, 0, 10)) throw HipError( "HIP error: out of memory (injected by SPA_TEST_FAIL_ALLOC_ABOVE) in hipMalloc"); }
 		HIP_CHECK( hipMalloc( &ptr, n));
 		bytes = n;
 	}

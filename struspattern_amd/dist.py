@@ -23,13 +23,27 @@ def shard_documents(doc_offsets, rank, world):
 
 
 def reduce_counters(counters, device=None):
-    """all-reduce(sum) of a dict of integer counters over the default process group; identity when
-    torch.distributed is not initialised (single GPU)."""
+    """all-reduce(sum) of a dict of integer counters over the default process group (int64: exact);
+    identity when torch.distributed is not initialised (single GPU)."""
     import torch
     import torch.distributed as dist
     keys = sorted(counters)
     if not (dist.is_available() and dist.is_initialized()):
-        return dict(counters)
-    t = torch.tensor([float(counters[k]) for k in keys], dtype=torch.float64, device=device)
+        return {k: int(counters[k]) for k in keys}
+    t = torch.tensor([int(counters[k]) for k in keys], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return {k: int(v) for k, v in zip(keys, t.tolist())}
+
+
+def reduce_step(counters, seconds, device=None):
+    """What bench.py does at the end of the timed region: the job's counters are the sums over the
+    ranks (the path's only collective), the job's time is the slowest rank's.
+    Returns (summed counters, max seconds)."""
+    import torch
+    import torch.distributed as dist
+    tot = reduce_counters(counters, device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return tot, float(seconds)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return tot, float(t[0])

@@ -265,11 +265,12 @@ public:
 			catch (const std::bad_alloc&) { m_errorhnd->report( ErrorCodeOutOfMem, "memory allocation error in %s", "strus pattern"); return; }
 			if (!fmt) return;
 		}
-		if (check( sp_matcher_define_pattern( m_h, name_.c_str(), formatstring.c_str(), visible ? 1 : 0), "failed to close pattern definition on the pattern match expression stack: %s")
-		&&  !formatstring.empty())
-		{
-			m_resultFormatHandles.push_back( fmt);
-		}
+		// A failing definePattern may or may not have taken a format handle (the reference pushes it before the check of
+		// src/patternMatcher.cpp:576-579 but after the one of :549-552): the compiler behind the C-ABI says which, so
+		// that this list and its list of format strings stay in step whatever the outcome.
+		const uint32_t before = sp_matcher_format_count( m_h);
+		check( sp_matcher_define_pattern( m_h, name_.c_str(), formatstring.c_str(), visible ? 1 : 0), "failed to close pattern definition on the pattern match expression stack: %s");
+		if (sp_matcher_format_count( m_h) > before) m_resultFormatHandles.push_back( fmt);
 	}
 	virtual PatternMatcherContextInterface* createContext() const
 	{

@@ -1,9 +1,4 @@
 #!/bin/bash
-# occupancy / register budget sweep of the L2 kernel (run on the GPU box)
-set -e
-for w in 2 3 4; do
-  rm -f struspattern_amd/_build/obj/l2_kernel.hip.o struspattern_amd/_build/obj/capi_l2*.o
-  make -s -C struspattern_amd/csrc EXTRA="-DSPA_L2_WAVES_PER_EU=$w -DSPA_L2_WAVES_PER_CU=$((4*w))" > /dev/null 2>&1
-  echo "== waves/SIMD $w"
-  timeout -k 10 200 python tests/micro/perf_l2.py 12288 2>&1 | grep "op="
-done
+# occupancy / register budget sweep of the arena (general) L2 kernel, variants built out of tree (GPU box)
+exec tests/micro/ab.sh "python3 tests/micro/perf_l2.py 12288" \
+  w2:"-DSPA_L2_WAVES_PER_EU=2 -DSPA_L2_WAVES_PER_CU=8" w3:"-DSPA_L2_WAVES_PER_EU=3 -DSPA_L2_WAVES_PER_CU=12" w4:"-DSPA_L2_WAVES_PER_EU=4 -DSPA_L2_WAVES_PER_CU=16"

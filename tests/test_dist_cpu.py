@@ -35,6 +35,9 @@ def _worker(rank, world, port, out):
         a, b = spdist.shard_documents(offs, rank, world)
         local = {"bytes": int(offs[b] - offs[a]), "lexems": (b - a) * 3, "matches": rank + 1}
         tot = spdist.reduce_counters(local)
+        # bench.py's end of the timed region: counters summed (exact above 2^53 too), time maxed
+        big, dt = spdist.reduce_step({"bytes": (1 << 60) + rank, "results": 7 * (rank + 1)}, 1.5 + rank)
+        assert big == {"bytes": (1 << 61) + 1, "results": 21} and dt == 2.5
         out.put((rank, a, b, tot))
     finally:
         dist.destroy_process_group()

@@ -258,3 +258,26 @@ def test_single_document_interface():
     ctx.reset()
     res, items = ctx.fetchResults()
     assert len(res) == 0
+
+
+def test_failed_allocation_leaves_no_stale_capacity():
+    """A hipMalloc that fails while the output buffers grow must not leave the old capacity next to a
+    released buffer: the next launch reallocates (or reports an error), it never writes through NULL."""
+    import os
+    rules = synth.random_rules(300, 40, 91)
+    lex, offs = synth.random_documents(20, 200, 40, 92)
+    m = spa.PatternMatcherInstance()
+    o = oracle.L2Matcher()
+    synth.apply_rules(m, rules)
+    synth.apply_rules(o, rules)
+    ref = o.run(synth.lexems5(lex), offs)
+    ctx = m.createContext()
+    _compare(ctx.matchDocs(lex, offs), ref, 20)           # buffers exist, capacities > 0
+    ctx.reserveOutput(12000000, 12000000)                  # the next launch has to grow both output buffers
+    os.environ["SPA_TEST_FAIL_ALLOC_ABOVE"] = str(64 << 20)
+    try:
+        with pytest.raises(spa.PatternError):
+            ctx.matchDocs(lex, offs)
+    finally:
+        del os.environ["SPA_TEST_FAIL_ALLOC_ABOVE"]
+    _compare(ctx.matchDocs(lex, offs), ref, 20)           # reallocated: same results as before

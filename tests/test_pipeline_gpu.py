@@ -1,5 +1,7 @@
 """GPU parity of the fused pipeline: text -> lexer kernel -> (lexems stay in HBM) -> rule automaton
 kernel, against oracle lexer -> oracle automaton on the same documents."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,12 +12,11 @@ from struspattern_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("npat,nrules,ndocs,docbytes,seed", [(200, 500, 24, 3000, 1), (600, 2000, 12, 4000, 2)])
-def test_pipeline_parity(npat, nrules, ndocs, docbytes, seed):
+def _device_pipeline(pats, rules, text, offs):
+    """text -> lexer kernel -> lexems stay in HBM -> rule automaton kernel (the path bench.py times);
+    returns (lexer counters, fetched matcher batch)."""
     import torch
-    vocab = synth.vocabulary(2000, 5)
-    pats, rules = synth.pipeline_workload(npat, nrules, vocab, seed)
-    text, offs = synth.text_documents(ndocs, docbytes, vocab, 50 + seed)
+    ndocs = len(offs) - 1
     lx = spa.PatternLexerInstance()
     synth.apply_lexer_patterns(lx, pats)
     m = spa.PatternMatcherInstance()
@@ -24,7 +25,8 @@ def test_pipeline_parity(npat, nrules, ndocs, docbytes, seed):
     d_text = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
     d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    for _ in range(6):
+    lc = mc = None
+    for _ in range(8):
         lo = lctx.matchDocsDevice(d_text.data_ptr(), d_offs.data_ptr(), ndocs, len(text), stream)
         lc = lctx.batchCounters()
         if lc["failed_docs"]:
@@ -39,20 +41,54 @@ def test_pipeline_parity(npat, nrules, ndocs, docbytes, seed):
             break
         mctx.reserveOutput(int(mc["results"] * 1.2) + 1024, int(mc["items"] * 1.2) + 1024)
         mctx.growArena()
-    assert lc["failed_docs"] == 0 and mc["failed_docs"] == 0
-    gpu = mctx.batchFetch()
+    assert lc["failed_docs"] == 0 and mc is not None and mc["failed_docs"] == 0
+    return lc, mctx.batchFetch()
 
+
+def _oracle_pipeline(pats, rules, text, offs, nthreads=8):
     ol = oracle.L1Lexer()
     synth.apply_lexer_patterns(ol, pats)
     om = oracle.L2Matcher()
     synth.apply_rules(om, rules)
-    lex, loffs = ol.matchDocs(text, offs, nthreads=8)
-    ref = om.run(synth.lexems5(lex), loffs)
-    assert len(lex) == lc["lexems"] and len(ref.results) > 0
+    lex, loffs = ol.matchDocs(text, offs, nthreads=nthreads)
+    return lex, om.run(synth.lexems5(lex), loffs, nthreads=nthreads)
+
+
+def _assert_same(gpu, ref):
     assert np.array_equal(gpu.doc_offsets, ref.doc_offsets)
     assert np.array_equal(gpu.results[:, :7], ref.results[:, :7])
+    assert np.array_equal(gpu.results[:, 8], ref.results[:, 8])
     assert np.array_equal(gpu.items, ref.items)
     assert np.array_equal(gpu.stats, ref.stats)
+
+
+@pytest.mark.parametrize("npat,nrules,ndocs,docbytes,seed", [(200, 500, 24, 3000, 1), (600, 2000, 12, 4000, 2)])
+def test_pipeline_parity(npat, nrules, ndocs, docbytes, seed):
+    vocab = synth.vocabulary(2000, 5)
+    pats, rules = synth.pipeline_workload(npat, nrules, vocab, seed)
+    text, offs = synth.text_documents(ndocs, docbytes, vocab, 50 + seed)
+    lc, gpu = _device_pipeline(pats, rules, text, offs)
+    lex, ref = _oracle_pipeline(pats, rules, text, offs)
+    assert len(lex) == lc["lexems"] and len(ref.results) > 0
+    _assert_same(gpu, ref)
+
+
+def test_headline_workload_parity():
+    """BASELINE.json configs[4] as a whole: the exact tables bench.py builds (10 000 regexes + sentence
+    delimiter, 10 000 token rules, vocabulary and seeds of bench.py) over UTF-8 documents of both
+    document shapes the bench reports (16 KiB and the survey's 64 KiB): lexems, results in firing order,
+    items and statistics of the fused device pipeline equal the oracle's."""
+    ncores = min(16, len(os.sched_getaffinity(0)))
+    vocab = synth.vocabulary(30000, 1)
+    pats, rules = synth.pipeline_workload(10000, 10000, vocab, seed=4)
+    t16, o16 = synth.text_documents(40, 16384, vocab, seed=1000, utf8=True)
+    t64, o64 = synth.text_documents(6, 65536, vocab, seed=1001, utf8=True)
+    text = t16 + t64
+    offs = np.concatenate([o16, o64[1:] + o16[-1]]).astype(np.uint64)
+    lc, gpu = _device_pipeline(pats, rules, text, offs)
+    lex, ref = _oracle_pipeline(pats, rules, text, offs, nthreads=ncores)
+    assert len(lex) == lc["lexems"] and len(ref.results) > len(lex)
+    _assert_same(gpu, ref)
 
 
 def test_one_long_document_among_short_ones():
