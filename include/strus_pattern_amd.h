@@ -127,6 +127,11 @@ uint32_t sp_matcher_variable_id(const sp_matcher_t* m, const char* name);
 const char* sp_matcher_variable_name(const sp_matcher_t* m, uint32_t variable);
 /* canonical dump of the compiled ProgramTable (test hook; format in csrc/l2_compile.hpp) */
 size_t sp_matcher_dump_table(const sp_matcher_t* m, uint32_t** out);
+/* which kernel a context of this matcher runs on (test / diagnostics hook): 1 = the rule set is flat (every program
+ * has at most 3 triggers over input terms, position range <= 63, no rule listens to another rule's result) and its
+ * documents run with their whole hot state in LDS; 0 = general kernel, `why` says what disqualifies it.
+ * Both kernels produce the reference's results (src/ruleMatcherAutomaton.cpp:772-1334); the choice is not observable. */
+int sp_matcher_fast_tier(const sp_matcher_t* m, char* why, size_t whysize);
 
 /* ---- result format strings (definePattern's formatstring, src/patternMatcher.cpp:561-566, :172-181, :253-262).
  * The device does not build strings: it reports which format applies and what its arguments are.
@@ -210,7 +215,8 @@ int sp_matcher_ctx_batch_fetch(sp_matcher_ctx_t* c, sp_match_batch_t* out);
 /* the same for the documents [first_doc, first_doc+ndocs) of the last device batch only (a caller that checks a
  * sample, or picks up the documents of one shard, does not move the whole batch over PCIe) */
 int sp_matcher_ctx_batch_fetch_docs(sp_matcher_ctx_t* c, size_t first_doc, size_t ndocs, sp_match_batch_t* out);
-/* waits for the stream and returns counters[0..7] = {results, items, events, failed docs, 0..} */
+/* waits for the stream and returns counters[0..7] = {results, items, events, failed docs, documents the LDS-resident
+ * kernel handed over to the general one (diagnostics), 0..} */
 int sp_matcher_ctx_batch_counters(sp_matcher_ctx_t* c, uint64_t counters[8]);
 /* duration of the last rule-automaton kernel in milliseconds (HIP events on the launch stream) */
 double sp_matcher_ctx_last_kernel_ms(sp_matcher_ctx_t* c);

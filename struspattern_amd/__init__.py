@@ -188,7 +188,7 @@ class PatternMatcherContext:
         rc = self._L.sp_matcher_ctx_batch_counters(self._h, arr)
         if rc != 0:
             raise PatternError("reading batch counters failed: " + self._err())
-        return {"results": arr[0], "items": arr[1], "events": arr[2], "failed_docs": arr[3], "prof": [arr[4], arr[5], arr[6], arr[7]]}
+        return {"results": arr[0], "items": arr[1], "events": arr[2], "failed_docs": arr[3], "handed_over": arr[4], "prof": [arr[4], arr[5], arr[6], arr[7]]}
 
     def batchStatus(self, ndocs):
         st = np.zeros(ndocs, np.int32)
@@ -276,6 +276,12 @@ class PatternMatcherInstance:
     def formatString(self, handle):
         s = self._L.sp_matcher_format_string(self._h, handle)
         return s.decode() if s else None
+
+    def fastTier(self):
+        """(True, "") when the rule set is flat and runs on the LDS-resident kernel, else (False, reason)."""
+        buf = ctypes.create_string_buffer(256)
+        ok = self._L.sp_matcher_fast_tier(self._h, buf, 256)
+        return bool(ok), buf.value.decode()
 
     def dumpTable(self):
         p = ctypes.POINTER(ctypes.c_uint32)()

@@ -3,6 +3,7 @@
 #include "../../include/strus_pattern_amd.h"
 #include "l2_compile.hpp"
 #include "l2_device.h"
+#include "l2_fast.h"
 #include "hip_util.hpp"
 #include <hip/hip_runtime_api.h>
 #include <cstdlib>
@@ -16,6 +17,10 @@
 
 namespace spa {
 hipError_t launchL2Match( const L2Params& P, unsigned nblocks, hipStream_t stream);
+hipError_t launchL2Fast( const FastParams& P, unsigned nblocks, hipStream_t stream);
+int fastBlocksPerCU( unsigned ldsBytes);
+std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out);
+void layoutFast( FastLdsLayout& L, FastSpillLayout& S, uint32_t R, uint32_t T, uint32_t nofStopWords, uint32_t maxRules, uint32_t maxStaged);
 }
 
 using namespace spa;
@@ -85,6 +90,13 @@ struct sp_matcher_ctx
 	// device tables
 	DeviceBuffer dPrograms, dTrigdefs, dKeytab, dKeylist;
 	uint32_t keymask, nofStopWords;
+	// fast tier (l2_fast.h): flat rule sets run with their hot state in LDS; the general kernel takes what it hands over
+	bool fast;
+	std::string whyNotFast;
+	DeviceBuffer dKeyinst, dSpill, dFallbackList;
+	FastLdsLayout fastLds; FastSpillLayout fastSpill;
+	unsigned fastWaves, fastBlocksPerCU;
+	uint32_t fastR, fastT, fastMaxRules, fastMaxStaged;
 	// working memory
 	ArenaLayout arena;
 	DeviceBuffer dArena; unsigned arenaWaves;
@@ -105,10 +117,11 @@ struct sp_matcher_ctx
 	std::vector<uint32_t> curOrigseg; bool curHasSeg;
 	sp_matcher_stats_t lastStats;
 
-	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
+	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),fast(false),fastWaves(0),fastBlocksPerCU(0),fastR(320),fastT(512),fastMaxRules(2048),fastMaxStaged(32768),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
 		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
+		std::memset( &fastLds, 0, sizeof(fastLds)); std::memset( &fastSpill, 0, sizeof(fastSpill));
 		std::memset( &lastStats, 0, sizeof(lastStats));
 		// small defaults (a document's hot state should stay cache and TLB friendly); every capacity
 		// doubles automatically when a document overflows it (SP_DOC_ERR_ARENA -> grow -> rerun)
@@ -166,6 +179,25 @@ const char* sp_matcher_variable_name( const sp_matcher_t* m, uint32_t variable) 
 uint32_t sp_matcher_format_count( const sp_matcher_t* m) { return m->compiler.formatCount(); }
 const char* sp_matcher_format_string( const sp_matcher_t* m, uint32_t format_handle) { return m->compiler.formatString( format_handle); }
 
+// 1 when the compiled rule set is flat (l2_fast.h) and runs on the LDS-resident kernel, else 0 with the reason
+int sp_matcher_fast_tier( const sp_matcher_t* m, char* why, size_t whysize)
+{
+	try
+	{
+		FlatTables ft;
+		m->compiler.flatten( ft);
+		std::vector<FastKeyInst> ki;
+		const std::string reason = buildFastTables( ft, ki);
+		if (why && whysize) { std::strncpy( why, reason.c_str(), whysize-1); why[ whysize-1] = 0; }
+		return reason.empty() ? 1 : 0;
+	}
+	catch (const std::exception& e)
+	{
+		if (why && whysize) { std::strncpy( why, e.what(), whysize-1); why[ whysize-1] = 0; }
+		return 0;
+	}
+}
+
 size_t sp_matcher_dump_table( const sp_matcher_t* m, uint32_t** out)
 {
 	std::vector<uint32_t> buf = m->compiler.dump();
@@ -205,7 +237,29 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 		c->nofStopWords = ft.nofStopWords;
 		c->arena.nStop = ft.nofStopWords;
 		c->withFormats = m->compiler.formatCount() != 0;
-		c->dCursor.alloc( 64);
+		{
+			// fast tier: eligible rule sets get the one-line-per-install table (SPA_L2_FAST=0 keeps everything on the general kernel)
+			std::vector<FastKeyInst> ki;
+			c->whyNotFast = buildFastTables( ft, ki);
+			const char* sw = getenv( "SPA_L2_FAST");
+			if (sw && sw[0] == '0') c->whyNotFast = "disabled by SPA_L2_FAST=0";
+			c->fast = c->whyNotFast.empty();
+			if (c->fast)
+			{
+				if (ki.empty()) ki.resize( 1);
+				c->dKeyinst.upload( ki.data(), ki.size()*sizeof(FastKeyInst));
+				if (const char* e = getenv( "SPA_L2_FAST_R")) c->fastR = (uint32_t)atoi( e);
+				if (const char* e = getenv( "SPA_L2_FAST_T")) c->fastT = (uint32_t)atoi( e);
+				if (const char* e = getenv( "SPA_L2_FAST_MAXRULES")) c->fastMaxRules = (uint32_t)atoi( e);
+				if (const char* e = getenv( "SPA_L2_FAST_MAXSTAGED")) c->fastMaxStaged = (uint32_t)atoi( e);
+				if (c->fastMaxRules > 4095) c->fastMaxRules = 4095;		// trigger ids are 14 bits (rule << 2 | slot)
+				if (c->fastMaxRules < 8) c->fastMaxRules = 8;
+				if (c->fastR < 4) c->fastR = 4;
+				if (c->fastT < 16) c->fastT = 16;
+			}
+			if (getenv( "SPA_L2_VERBOSE")) fprintf( stderr, "[spa] fast tier: %s\n", c->fast ? "on" : c->whyNotFast.c_str());
+		}
+		c->dCursor.alloc( 256);		// u32: [0] fast cursor, [1] general cursor (list mode), [2] hand-over count, [16..31] hand-over reasons, [32..47] phase profile (u64 x 8)
 		c->dCounters.alloc( SPC_COUNT*sizeof(uint64_t));
 		HIP_CHECK( hipEventCreate( &c->evStart));
 		HIP_CHECK( hipEventCreate( &c->evStop));
@@ -499,7 +553,7 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	c->dDocStats.reserve( (ndocs+1)*4*sizeof(uint64_t));
 	c->dDocStatus.reserve( (ndocs+1)*sizeof(int32_t));
 
-	HIP_CHECK( hipMemsetAsync( c->dCursor.ptr, 0, 64, stream));
+	HIP_CHECK( hipMemsetAsync( c->dCursor.ptr, 0, 256, stream));
 	HIP_CHECK( hipMemsetAsync( c->dCounters.ptr, 0, SPC_COUNT*sizeof(uint64_t), stream));
 
 	L2Params P;
@@ -542,7 +596,46 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	P.trace = (uint32_t*)traceDev;
 #endif
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
-	HIP_CHECK( launchL2Match( P, nblocks, stream));
+	if (c->fast)
+	{
+		// flat rule set: the LDS-resident kernel first; the documents it hands over (fallbackList) go through the
+		// general kernel in list mode right behind it on the same stream (an empty list costs one short launch)
+		layoutFast( c->fastLds, c->fastSpill, c->fastR, c->fastT, c->nofStopWords, c->fastMaxRules, c->fastMaxStaged);
+		if (!c->fastBlocksPerCU) c->fastBlocksPerCU = (unsigned)fastBlocksPerCU( c->fastLds.totalBytes);
+		size_t fslots = (size_t)c->numCUs * c->fastBlocksPerCU;
+		unsigned fblocks = (unsigned)(ndocs < fslots ? ndocs : fslots);
+		if (fblocks == 0) fblocks = 1;
+		if (c->fastWaves < fblocks)
+		{
+			c->fastWaves = 0;
+			c->dSpill.alloc( fslots * (size_t)c->fastSpill.totalWords * sizeof(uint32_t));
+			c->fastWaves = (unsigned)fslots;
+			if (getenv( "SPA_L2_VERBOSE")) fprintf( stderr, "[spa] fast tier: %u waves/CU, LDS %u B (R %u, T %u), spill %.2f MB per wave\n", c->fastBlocksPerCU, c->fastLds.totalBytes, c->fastLds.R, c->fastLds.T, c->fastSpill.totalWords*4/1e6);
+		}
+		c->dFallbackList.reserve( (ndocs+1)*sizeof(uint32_t));
+		FastParams F;
+		std::memset( &F, 0, sizeof(F));
+		F.keyinst = (const FastKeyInst*)c->dKeyinst.ptr; F.keytab = (const FastKeyEntry*)c->dKeytab.ptr;
+		F.keymask = c->keymask; F.nofStopWords = c->nofStopWords;
+		F.lexems = P.lexems; F.origseg = P.origseg; F.docOffsets = P.docOffsets; F.docRangesIn = P.docRangesIn;
+		F.ndocs = P.ndocs; F.withItems = P.withItems;
+		F.lds = c->fastLds; F.spill = c->fastSpill; F.spillBase = (uint32_t*)c->dSpill.ptr;
+		F.docCursor = (uint32_t*)c->dCursor.ptr;
+		F.counters = P.counters; F.results = P.results; F.resultCapacity = P.resultCapacity; F.items = P.items; F.itemCapacity = P.itemCapacity;
+		F.docRange = P.docRange; F.docStats = P.docStats; F.docStatus = P.docStatus;
+		F.withFormats = P.withFormats; F.resultFormat = P.resultFormat; F.itemFormat = P.itemFormat;
+		F.fallbackList = (uint32_t*)c->dFallbackList.ptr; F.fallbackCount = (uint32_t*)c->dCursor.ptr + 2;
+		F.diag = (uint32_t*)c->dCursor.ptr + 16; F.prof = (uint64_t*)((uint32_t*)c->dCursor.ptr + 32);
+		HIP_CHECK( launchL2Fast( F, fblocks, stream));
+		P.docList = F.fallbackList; P.docListCount = F.fallbackCount;
+		P.docCursor = (uint32_t*)c->dCursor.ptr + 1;
+		const unsigned listBlocks = nblocks < 2*c->numCUs ? nblocks : 2*c->numCUs;
+		HIP_CHECK( launchL2Match( P, listBlocks, stream));
+	}
+	else
+	{
+		HIP_CHECK( launchL2Match( P, nblocks, stream));
+	}
 	HIP_CHECK( hipEventRecord( c->evStop, stream));
 #if defined(SPA_TRACE) || defined(SPA_POLL)
 	static uint32_t traceDummy[16];
@@ -611,6 +704,25 @@ int sp_matcher_ctx_batch_counters( sp_matcher_ctx_t* c, uint64_t counters[8])
 		HIP_CHECK( hipSetDevice( c->device));
 		HIP_CHECK( hipStreamSynchronize( c->lastStream));
 		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, SPC_COUNT*sizeof(uint64_t), hipMemcpyDeviceToHost));
+		if (c->fast && getenv( "SPA_L2_VERBOSE"))
+		{
+			uint32_t diag[ 16];
+			HIP_CHECK( hipMemcpy( diag, (const uint32_t*)c->dCursor.ptr + 16, sizeof(diag), hipMemcpyDeviceToHost));
+#ifdef SPA_PROF
+			uint64_t prof[ 12];
+			HIP_CHECK( hipMemcpy( prof, (const uint32_t*)c->dCursor.ptr + 32, sizeof(prof), hipMemcpyDeviceToHost));
+			double tot = 0; for (int i=0; i<8; ++i) tot += (double)prof[ i];
+			tot -= (double)prof[ 6] + (double)prof[ 7];
+			fprintf( stderr, "[spa] fast tier phases (share of wave cycles): scan+fire %.1f%% install %.1f%% deactivate %.1f%% expiry %.1f%% results %.1f%% fetch %.1f%% | inside: list walk %.1f%% removal rounds %.1f%% (%u rounds, %u batches, %u rules); %.0f cycles per event\n",
+				100*prof[0]/tot, 100*prof[1]/tot, 100*prof[2]/tot, 100*prof[3]/tot, 100*prof[4]/tot, 100*prof[5]/tot, 100*prof[6]/tot, 100*prof[7]/tot, (unsigned)prof[ 8], (unsigned)prof[ 9], (unsigned)prof[ 10], tot / (double)(counters[ SPC_EVENTS] ? counters[ SPC_EVENTS] : 1));
+#endif
+			if (diag[ 0])
+			{
+				fprintf( stderr, "[spa] fast tier handed %u of %zu documents to the general kernel; by reason:", diag[ 0], c->lastNdocs);
+				for (int i=1; i<16; ++i) if (diag[ i]) fprintf( stderr, " [%d]=%u", i, diag[ i]);
+				fprintf( stderr, "\n");
+			}
+		}
 	});
 }
 

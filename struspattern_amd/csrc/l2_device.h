@@ -9,7 +9,7 @@ namespace spa {
 // per-document status codes (= SP_DOC_* of include/strus_pattern_amd.h)
 enum {SPD_OK=0, SPD_ERR_ORDER=1, SPD_ERR_ARENA=2, SPD_ERR_KEYTRIGGERS=3, SPD_ERR_PASTFOLLOW=4, SPD_ERR_RANGE=5, SPD_ERR_DATAREF=6, SPD_ERR_LEXEMSIZE=7, SPD_ERR_INTERNAL=8, SPD_ERR_OUTPUT=9};
 // counters[]
-enum {SPC_RESULTS=0, SPC_ITEMS=1, SPC_EVENTS=2, SPC_FAILED=3, SPC_COUNT=8};
+enum {SPC_RESULTS=0, SPC_ITEMS=1, SPC_EVENTS=2, SPC_FAILED=3, SPC_HANDOVER=4 /*documents the fast tier handed to the general kernel*/, SPC_COUNT=8};
 
 // Per-wave arena: mutable state of the document a wavefront is working on.  Capacities in
 // records, offsets in u32 words from the arena base.  Record sizes: rule 12 words, trigger 8,
@@ -55,6 +55,10 @@ struct L2Params
 	uint32_t* resultFormat;		// [resultCapacity] format handle of the result (0 = none)
 	uint32_t* itemFormat;		// [itemCapacity] x {format handle, records of the item's subtree that follow it}
 	uint32_t* trace;		// debug builds only (host-mapped), else NULL
+	// list mode: the documents docList[0 .. *docListCount) instead of 0..ndocs (documents the fast tier handed
+	// over, l2_fast.h); the output counters continue where the fast kernel left them
+	const uint32_t* docList;
+	const uint32_t* docListCount;
 };
 
 } // namespace

@@ -1,0 +1,124 @@
+// Compact ("fast") tier of the level-2 automaton: tables and launch parameters shared by the host
+// (l2_fast_tables.cpp, capi_l2.cpp) and the kernel (l2_fast_kernel.hip).
+//
+// The general kernel (l2_kernel.hip) keeps every record of a document's StateMachine in an HBM arena
+// and handles every program shape the reference accepts.  Rule sets whose programs are all FLAT --
+// terms only, no sub-expression feeding another rule -- need far less state per rule instance: the
+// events a rule can take are input lexems, so a captured item or the start of a match is an index into
+// the document's lexem array, nothing is reference counted, nothing is joined.  For such rule sets
+// (the reference's own benchmark shape, tests/randomTokenPatternMatch, and the token-rule stage of the
+// pipeline) the whole hot state of a document -- rule words, trigger buckets, expiry lists, stop-word
+// log -- fits a few KB and lives in LDS; HBM sees the lexems once, a 16-byte write-once record per rule
+// instance and the results.
+#ifndef SPA_L2_FAST_H
+#define SPA_L2_FAST_H
+#include <stdint.h>
+#include "l2_tables.h"
+
+namespace spa {
+
+// ---- compiled tables of the fast tier (read only, HBM/L2) ----
+// One record per (key event, program keyed by it), in the reference's visiting order of the key
+// event's program list (src/ruleMatcherAutomaton.cpp:1137-1157): everything installProgram
+// (cpp:1168-1270) needs, in one 64-byte line -- no second or third dependent table read.
+struct FastKeyInst			// 64 B
+{
+	uint32_t resultHandle;		// 0: a match emits nothing
+	uint32_t formatHandle;
+	uint32_t pastEvent;		// original key event of an alternative-keyed program (cpp:1253-1258), 0 = none
+	uint32_t meta;			// initvalue(4) | initcount(5)<<4 | range(6)<<9 | ntrig(2)<<15 | pastStopIdx(8)<<17
+	struct { uint32_t event; uint32_t info; } trig[ 3];	// installation order (= last expression argument first)
+					// info: sigval(4) | sigtype(3)<<4 | install(1)<<7 | key(1)<<8 | bucket(4)<<9 | hasVar(1)<<13 | delStopIdx(8)<<14 | variable(8)<<24
+	uint32_t program;		// index into DevProgram[] (diagnostics)
+	uint32_t _pad[ 5];
+};
+enum {
+	FKI_VALUE_MASK=0xFu, FKI_COUNT_SHIFT=4, FKI_COUNT_MASK=0x1Fu, FKI_RANGE_SHIFT=9, FKI_RANGE_MASK=0x3Fu,
+	FKI_NTRIG_SHIFT=15, FKI_NTRIG_MASK=0x3u, FKI_PASTSTOP_SHIFT=17, FKI_PASTSTOP_MASK=0xFFu,
+	FTI_SIGVAL_MASK=0xFu, FTI_SIGTYPE_SHIFT=4, FTI_SIGTYPE_MASK=0x7u, FTI_INSTALL=1u<<7, FTI_KEY=1u<<8,
+	FTI_BUCKET_SHIFT=9, FTI_HASVAR=1u<<13, FTI_DELSTOP_SHIFT=14, FTI_DELSTOP_MASK=0xFFu, FTI_VAR_SHIFT=24
+};
+// hash table over key events and stop words (open addressing, keyHash of l2_tables.h)
+struct FastKeyEntry			// 16 B
+{
+	uint32_t event;
+	uint32_t kiBegin;		// FastKeyInst[kiBegin .. kiBegin+kiCount)
+	uint32_t kiCount;
+	uint32_t stopIdx;		// 1-based slot in the per-document stop-word log, 0 = not a stop word
+};
+
+// ---- per-wave LDS layout (byte offsets from the wave's slice; computed by the host) ----
+// R = rule instances whose hot state is in LDS, T = trigger-bucket entries in LDS (multiple of 16).
+// Rule ids >= R and bucket chunks >= T/16 live in the wave's spill area in HBM with the same record
+// shapes, so a burst (a frequent word that keys hundreds of programs) slows a document down instead
+// of failing it.
+struct FastLdsLayout
+{
+	uint32_t R, T;			// capacities in LDS
+	uint32_t oHot;			// u32[R]   rule word (see l2_fast_kernel.hip)
+	uint32_t oLink;			// u16[3R]  bucket<<12 | position of trigger slot j of rule r at [3r+j]
+	uint32_t oNext;			// u16[R]   next rule in the expiry list of its position (0xFFFF = end)
+	uint32_t oFree;			// u16[R]   stack of free rule ids < R
+	uint32_t oEv;			// u32[T]   bucket entries: event id
+	uint32_t oTs;			// u32[T]   bucket entries: trigger id | sigval/sigtype/hasVar byte << 16
+	uint32_t oChunkTab;		// u8[16][64] chunk ids of each bucket, in position order
+	uint32_t oChunkFree;		// u8[256]  stack of free chunk ids (LDS chunks and spill chunks)
+	uint32_t oBSize;		// u32[16]  bucket sizes
+	uint32_t oBChunks;		// u32[16]  chunks owned by each bucket
+	uint32_t oWin;			// u16[64]  heads of the expiry lists (0xFFFF = empty)
+	uint32_t oStop;			// {lexem index, ordpos, timestamp} u32[3] per stop word
+	uint32_t oList;			// u16[LISTCAP] rules to deactivate (dispose list / expiry list)
+	uint32_t oScalars;		// u32[32]
+	uint32_t totalBytes;
+};
+enum {FAST_LISTCAP=256, FAST_MAXCHUNKS=256, FAST_CHUNK=16, FAST_BUCKET_CHUNKS=64};
+
+struct FastSpillLayout			// per-wave spill + cold area in HBM, offsets in u32 words
+{
+	uint32_t maxRules;		// total rule ids (LDS + spill), <= 4096
+	uint32_t oCold;			// u32[8*maxRules]  {resultHandle, formatHandle, first taken lexem, item0, item1, item2, -, -}, item = lexem | variable<<24:
+					// written when the rule is installed / takes an event, read when it matches after its installation
+	uint32_t oHot, oLink, oNext;	// spill rules (ids R..maxRules): same shapes as in LDS (u32 per element here)
+	uint32_t oFree;			// u32[maxRules]  stack of free spill ids
+	uint32_t oEnt;			// {event, ts} per spill bucket entry, (FAST_MAXCHUNKS*16 - T) entries
+	uint32_t oStaged;		// staged results, 8 words each
+	uint32_t maxStaged;
+	uint32_t oList;			// u32[maxRules] long dispose / expiry lists
+	uint32_t totalWords;
+};
+
+// per-document status of the fast tier beyond SPD_* of l2_device.h: the document is handed to the general kernel
+enum {SPD_FAST_FALLBACK=100};
+
+struct FastParams
+{
+	const FastKeyInst* keyinst;
+	const FastKeyEntry* keytab;
+	uint32_t keymask;
+	uint32_t nofStopWords;
+	// input
+	const uint32_t* lexems;		// sp_lexem_t[]: id, ordpos, origpos, origsize
+	const uint32_t* origseg;	// optional
+	const uint64_t* docOffsets;	// ndocs+1 lexem indices, or NULL when docRangesIn is given
+	const uint64_t* docRangesIn;	// ndocs x (first lexem, count)
+	uint32_t ndocs;
+	uint32_t withItems;
+	// working memory
+	FastLdsLayout lds;
+	FastSpillLayout spill;
+	uint32_t* spillBase;		// per wave: spill.totalWords
+	uint32_t* docCursor;
+	// output (same buffers and formats as the general kernel)
+	uint64_t* counters;		// SPC_*
+	uint32_t* results; uint64_t resultCapacity;
+	uint32_t* items; uint64_t itemCapacity;
+	uint64_t* docRange; uint64_t* docStats; int32_t* docStatus;
+	uint32_t withFormats; uint32_t* resultFormat; uint32_t* itemFormat;
+	// documents the fast tier hands to the general kernel: fallbackList[ atomicAdd( fallbackCount)]
+	uint32_t* fallbackList; uint32_t* fallbackCount;
+	uint32_t* diag;			// [16] hand-overs in all / by reason (FB_* of l2_fast_kernel.hip), may be NULL
+	uint64_t* prof;			// [8] wave-cycles per phase (make PROF=1 builds), may be NULL
+};
+
+} // namespace
+#endif

@@ -1776,7 +1776,7 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 	KP P = kernelParams();
 	__shared__ __attribute__((aligned(16))) u32 ldsSlice[ 64 + 16 + 64 + 512 + 16*SCRLDS_CAP + EXPLIST_CAP];
 	const WSV w( (HWS*)ldsSlice, P.arenaBase + (u64)blockIdx.x * P.arena.totalWords);
-	const u32 ndocs = P.ndocs;
+	const u32 ndocs = P.docList ? ldu( P.docListCount) : P.ndocs;
 	const u32 waveSlot = blockIdx.x;
 	const u32 nWaveSlots = gridDim.x;
 
@@ -1793,6 +1793,7 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 			doc = nWaveSlots + bcast0( nx);
 		}
 		if (doc >= ndocs) break;
+		if (P.docList) doc = ldu( &P.docList[ doc]);
 		TRACE( 1, doc);
 		// per-document reset (lane-parallel)
 		if (LANE < 16) BSIZE[ LANE] = 0;

@@ -92,3 +92,41 @@ def test_context_requires_gpu_or_fails_loudly():
     m.definePattern("p")
     with pytest.raises(spa.PatternError):
         m.createContext()
+
+
+def test_fast_tier_eligibility():
+    """which compiled rule sets run on the LDS-resident kernel (struspattern_amd/csrc/l2_fast_tables.cpp)"""
+    import struspattern_amd as spa
+    from struspattern_amd import synth
+
+    def inst(build):
+        m = spa.PatternMatcherInstance()
+        build(m)
+        return m.fastTier()
+
+    assert inst(lambda m: synth.apply_rules(m, synth.random_rules(3000, 500, 7)))[0]
+    assert inst(lambda m: synth.apply_rules(m, synth.random_rules(300, 50, 8), compile=False))[0]
+
+    def nested(m):
+        m.pushTerm(1); m.pushTerm(2); m.pushExpression("sequence", 2, 3, 0)
+        m.pushTerm(3); m.pushExpression("within", 2, 5, 0); m.definePattern("b", "", True); m.compile()
+    ok, why = inst(nested)
+    assert not ok and "nested" in why
+
+    def conj(m):
+        m.pushTerm(1); m.pushTerm(2); m.pushExpression("and", 2, 3, 0); m.definePattern("a", "", True)
+    assert not inst(conj)[0]
+
+    def far(m):
+        m.pushTerm(1); m.pushTerm(2); m.pushExpression("sequence", 2, 64, 0); m.definePattern("a", "", True)
+    assert not inst(far)[0]
+
+    def wide(m):
+        for t in (1, 2, 3, 4):
+            m.pushTerm(t)
+        m.pushExpression("sequence", 4, 9, 0); m.definePattern("a", "", True)
+    assert not inst(wide)[0]
+
+    def near(m):
+        m.pushTerm(1); m.pushTerm(2); m.pushTerm(3); m.pushExpression("within", 3, 63, 0); m.definePattern("a", "", True)
+    assert inst(near)[0]
