@@ -17,10 +17,11 @@
 
 namespace spa {
 hipError_t launchL2Match( const L2Params& P, unsigned nblocks, hipStream_t stream);
-hipError_t launchL2Fast( const FastParams& P, unsigned nblocks, hipStream_t stream);
-int fastBlocksPerCU( unsigned ldsBytes);
+hipError_t launchL2Fast( const FastParams& P, unsigned variant, unsigned nblocks, hipStream_t stream);
+int fastBlocksPerCU( unsigned variant);
+void fastCapacities( unsigned variant, uint32_t& R, uint32_t& T);
 std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out);
-void layoutFast( FastLdsLayout& L, FastSpillLayout& S, uint32_t R, uint32_t T, uint32_t nofStopWords, uint32_t maxRules, uint32_t maxStaged);
+void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], const std::vector<FastKeyInst>& keyinst, uint32_t R, uint32_t T, uint32_t maxRules, uint32_t maxStaged);
 }
 
 using namespace spa;
@@ -94,9 +95,10 @@ struct sp_matcher_ctx
 	bool fast;
 	std::string whyNotFast;
 	DeviceBuffer dKeyinst, dSpill, dFallbackList;
-	FastLdsLayout fastLds; FastSpillLayout fastSpill;
-	unsigned fastWaves, fastBlocksPerCU;
-	uint32_t fastR, fastT, fastMaxRules, fastMaxStaged;
+	std::vector<FastKeyInst> fastKeyinst;
+	FastSpillLayout fastSpill; uint32_t fastBucketMeta[ 16];
+	unsigned fastWaves, fastBlocksPerCU, fastVariant;	// variant: kernel instance = LDS capacities (l2_fast_kernel.hip)
+	uint32_t fastMaxRules, fastMaxStaged;
 	// working memory
 	ArenaLayout arena;
 	DeviceBuffer dArena; unsigned arenaWaves;
@@ -117,11 +119,11 @@ struct sp_matcher_ctx
 	std::vector<uint32_t> curOrigseg; bool curHasSeg;
 	sp_matcher_stats_t lastStats;
 
-	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),fast(false),fastWaves(0),fastBlocksPerCU(0),fastR(320),fastT(512),fastMaxRules(2048),fastMaxStaged(32768),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
+	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),fast(false),fastWaves(0),fastBlocksPerCU(0),fastVariant(1),fastMaxRules(2048),fastMaxStaged(32768),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
 		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
-		std::memset( &fastLds, 0, sizeof(fastLds)); std::memset( &fastSpill, 0, sizeof(fastSpill));
+		std::memset( &fastSpill, 0, sizeof(fastSpill)); std::memset( fastBucketMeta, 0, sizeof(fastBucketMeta));
 		std::memset( &lastStats, 0, sizeof(lastStats));
 		// small defaults (a document's hot state should stay cache and TLB friendly); every capacity
 		// doubles automatically when a document overflows it (SP_DOC_ERR_ARENA -> grow -> rerun)
@@ -248,14 +250,12 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 			{
 				if (ki.empty()) ki.resize( 1);
 				c->dKeyinst.upload( ki.data(), ki.size()*sizeof(FastKeyInst));
-				if (const char* e = getenv( "SPA_L2_FAST_R")) c->fastR = (uint32_t)atoi( e);
-				if (const char* e = getenv( "SPA_L2_FAST_T")) c->fastT = (uint32_t)atoi( e);
+				c->fastKeyinst.swap( ki);
+				// SPA_L2_FAST_SIZE=s|m|l picks the kernel instance (LDS capacities; t = the tiny one of the tests); the spill area takes what does not fit
+				if (const char* e = getenv( "SPA_L2_FAST_SIZE")) c->fastVariant = (e[0] == 's') ? 0u : (e[0] == 'l') ? 2u : (e[0] == 't') ? 3u : 1u;
 				if (const char* e = getenv( "SPA_L2_FAST_MAXRULES")) c->fastMaxRules = (uint32_t)atoi( e);
 				if (const char* e = getenv( "SPA_L2_FAST_MAXSTAGED")) c->fastMaxStaged = (uint32_t)atoi( e);
 				if (c->fastMaxRules > 4095) c->fastMaxRules = 4095;		// trigger ids are 14 bits (rule << 2 | slot)
-				if (c->fastMaxRules < 8) c->fastMaxRules = 8;
-				if (c->fastR < 4) c->fastR = 4;
-				if (c->fastT < 16) c->fastT = 16;
 			}
 			if (getenv( "SPA_L2_VERBOSE")) fprintf( stderr, "[spa] fast tier: %s\n", c->fast ? "on" : c->whyNotFast.c_str());
 		}
@@ -600,8 +600,10 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	{
 		// flat rule set: the LDS-resident kernel first; the documents it hands over (fallbackList) go through the
 		// general kernel in list mode right behind it on the same stream (an empty list costs one short launch)
-		layoutFast( c->fastLds, c->fastSpill, c->fastR, c->fastT, c->nofStopWords, c->fastMaxRules, c->fastMaxStaged);
-		if (!c->fastBlocksPerCU) c->fastBlocksPerCU = (unsigned)fastBlocksPerCU( c->fastLds.totalBytes);
+		uint32_t fR = 0, fT = 0;
+		fastCapacities( c->fastVariant, fR, fT);
+		layoutFast( c->fastSpill, c->fastBucketMeta, c->fastKeyinst, fR, fT, c->fastMaxRules, c->fastMaxStaged);
+		if (!c->fastBlocksPerCU) c->fastBlocksPerCU = (unsigned)fastBlocksPerCU( c->fastVariant);
 		size_t fslots = (size_t)c->numCUs * c->fastBlocksPerCU;
 		unsigned fblocks = (unsigned)(ndocs < fslots ? ndocs : fslots);
 		if (fblocks == 0) fblocks = 1;
@@ -610,7 +612,7 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 			c->fastWaves = 0;
 			c->dSpill.alloc( fslots * (size_t)c->fastSpill.totalWords * sizeof(uint32_t));
 			c->fastWaves = (unsigned)fslots;
-			if (getenv( "SPA_L2_VERBOSE")) fprintf( stderr, "[spa] fast tier: %u waves/CU, LDS %u B (R %u, T %u), spill %.2f MB per wave\n", c->fastBlocksPerCU, c->fastLds.totalBytes, c->fastLds.R, c->fastLds.T, c->fastSpill.totalWords*4/1e6);
+			if (getenv( "SPA_L2_VERBOSE")) fprintf( stderr, "[spa] fast tier: %u waves/CU, LDS capacities R %u T %u, spill %.2f MB per wave\n", c->fastBlocksPerCU, fR, fT, c->fastSpill.totalWords*4/1e6);
 		}
 		c->dFallbackList.reserve( (ndocs+1)*sizeof(uint32_t));
 		FastParams F;
@@ -619,14 +621,15 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		F.keymask = c->keymask; F.nofStopWords = c->nofStopWords;
 		F.lexems = P.lexems; F.origseg = P.origseg; F.docOffsets = P.docOffsets; F.docRangesIn = P.docRangesIn;
 		F.ndocs = P.ndocs; F.withItems = P.withItems;
-		F.lds = c->fastLds; F.spill = c->fastSpill; F.spillBase = (uint32_t*)c->dSpill.ptr;
+		std::memcpy( F.bucketMeta, c->fastBucketMeta, sizeof(F.bucketMeta));
+		F.spill = c->fastSpill; F.spillBase = (uint32_t*)c->dSpill.ptr;
 		F.docCursor = (uint32_t*)c->dCursor.ptr;
 		F.counters = P.counters; F.results = P.results; F.resultCapacity = P.resultCapacity; F.items = P.items; F.itemCapacity = P.itemCapacity;
 		F.docRange = P.docRange; F.docStats = P.docStats; F.docStatus = P.docStatus;
 		F.withFormats = P.withFormats; F.resultFormat = P.resultFormat; F.itemFormat = P.itemFormat;
 		F.fallbackList = (uint32_t*)c->dFallbackList.ptr; F.fallbackCount = (uint32_t*)c->dCursor.ptr + 2;
 		F.diag = (uint32_t*)c->dCursor.ptr + 16; F.prof = (uint64_t*)((uint32_t*)c->dCursor.ptr + 32);
-		HIP_CHECK( launchL2Fast( F, fblocks, stream));
+		HIP_CHECK( launchL2Fast( F, c->fastVariant, fblocks, stream));
 		P.docList = F.fallbackList; P.docListCount = F.fallbackCount;
 		P.docCursor = (uint32_t*)c->dCursor.ptr + 1;
 		const unsigned listBlocks = nblocks < 2*c->numCUs ? nblocks : 2*c->numCUs;

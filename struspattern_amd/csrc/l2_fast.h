@@ -47,31 +47,11 @@ struct FastKeyEntry			// 16 B
 	uint32_t stopIdx;		// 1-based slot in the per-document stop-word log, 0 = not a stop word
 };
 
-// ---- per-wave LDS layout (byte offsets from the wave's slice; computed by the host) ----
-// R = rule instances whose hot state is in LDS, T = trigger-bucket entries in LDS (multiple of 16).
-// Rule ids >= R and bucket chunks >= T/16 live in the wave's spill area in HBM with the same record
-// shapes, so a burst (a frequent word that keys hundreds of programs) slows a document down instead
-// of failing it.
-struct FastLdsLayout
-{
-	uint32_t R, T;			// capacities in LDS
-	uint32_t oHot;			// u32[R]   rule word (see l2_fast_kernel.hip)
-	uint32_t oLink;			// u16[3R]  bucket<<12 | position of trigger slot j of rule r at [3r+j]
-	uint32_t oNext;			// u16[R]   next rule in the expiry list of its position (0xFFFF = end)
-	uint32_t oFree;			// u16[R]   stack of free rule ids < R
-	uint32_t oEv;			// u32[T]   bucket entries: event id
-	uint32_t oTs;			// u32[T]   bucket entries: trigger id | sigval/sigtype/hasVar byte << 16
-	uint32_t oChunkTab;		// u8[16][64] chunk ids of each bucket, in position order
-	uint32_t oChunkFree;		// u8[256]  stack of free chunk ids (LDS chunks and spill chunks)
-	uint32_t oBSize;		// u32[16]  bucket sizes
-	uint32_t oBChunks;		// u32[16]  chunks owned by each bucket
-	uint32_t oWin;			// u16[64]  heads of the expiry lists (0xFFFF = empty)
-	uint32_t oStop;			// {lexem index, ordpos, timestamp} u32[3] per stop word
-	uint32_t oList;			// u16[LISTCAP] rules to deactivate (dispose list / expiry list)
-	uint32_t oScalars;		// u32[32]
-	uint32_t totalBytes;
-};
-enum {FAST_LISTCAP=256, FAST_MAXCHUNKS=256, FAST_CHUNK=16, FAST_BUCKET_CHUNKS=64};
+// ---- per-wave LDS image: static layout inside the kernel (struct LdsDoc of l2_fast_kernel.hip), one kernel
+// instance per capacity pair.  R = rule instances whose hot state is in LDS, T = trigger-bucket entries in LDS.
+// Rule ids >= R and bucket positions beyond a bucket's LDS region live in the wave's spill area in HBM, so a
+// burst (a frequent word that keys hundreds of programs) slows a document down instead of failing it.
+enum {FAST_LISTCAP=512 /* >= R of every instance */, FAST_MAXSTOP=64, FAST_SPILL_BUCKET=1024, FAST_VARIANTS=4};
 
 struct FastSpillLayout			// per-wave spill + cold area in HBM, offsets in u32 words
 {
@@ -80,7 +60,7 @@ struct FastSpillLayout			// per-wave spill + cold area in HBM, offsets in u32 wo
 					// written when the rule is installed / takes an event, read when it matches after its installation
 	uint32_t oHot, oLink, oNext;	// spill rules (ids R..maxRules): same shapes as in LDS (u32 per element here)
 	uint32_t oFree;			// u32[maxRules]  stack of free spill ids
-	uint32_t oEnt;			// {event, ts} per spill bucket entry, (FAST_MAXCHUNKS*16 - T) entries
+	uint32_t oEnt;			// {event, ts} per spill bucket entry: 16 rows of FAST_SPILL_BUCKET
 	uint32_t oStaged;		// staged results, 8 words each
 	uint32_t maxStaged;
 	uint32_t oList;			// u32[maxRules] long dispose / expiry lists
@@ -104,7 +84,7 @@ struct FastParams
 	uint32_t ndocs;
 	uint32_t withItems;
 	// working memory
-	FastLdsLayout lds;
+	uint32_t bucketMeta[ 16];	// LDS region of each trigger bucket: first entry | capacity << 16 (sized from the rule set)
 	FastSpillLayout spill;
 	uint32_t* spillBase;		// per wave: spill.totalWords
 	uint32_t* docCursor;

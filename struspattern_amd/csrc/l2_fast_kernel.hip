@@ -11,15 +11,20 @@
 //
 // State of one document (per wave):
 //   LDS   rule word u32 per rule instance {value:4 count:5 end_ordpos:8+1 done active trigMask:3 nItems:2 hasStart},
-//         its FastKeyInst index, the bucket position of each of its <= 3 installed triggers (u16), its link in
-//         the expiry list of its position (u16); the 16 trigger buckets of the reference's EventTriggerTable
-//         (cpp:114-257) as {event, trigger id | signal byte} entries in 16-entry chunks from a shared pool, in
-//         exactly the reference's positions (append at the end, swap-with-last removal); the 64 expiry list
-//         heads; the stop-word log {lexem index, ordpos, timestamp}; the dispose list; ~20 scalars.
-//   HBM   per rule instance ONE write-once 16-byte record {first taken lexem, <= 3 captured items as lexem
-//         indices}, read only if the rule matches after its installation; staged results (32 B) expanded to
-//         sp_result_t / sp_result_item_t records at the document's end; a spill area with the same record
-//         shapes for rule ids / bucket chunks beyond the LDS capacities (bursts).
+//         the bucket position of each of its <= 3 installed triggers (u16), its link in the expiry list of its
+//         position (u16); the 16 trigger buckets of the reference's EventTriggerTable (cpp:114-257) as
+//         {event, trigger id | signal byte | variable} entries, each bucket a fixed region sized by the host from
+//         the rule set, in exactly the reference's positions (append at the end, swap-with-last removal); the 64
+//         expiry list heads; the stop-word log {lexem index, ordpos, timestamp}; the dispose list.
+//         The layout is static (one kernel instance per capacity pair): every access is a ds instruction with an
+//         immediate offset.
+//   HBM   per rule instance ONE write-once 32-byte record {result handle, format, first taken lexem, <= 3 captured
+//         items as lexem index | variable}, read only if the rule matches after its installation; staged results
+//         (32 B) expanded to sp_result_t / sp_result_item_t records at the document's end; a spill area for rule
+//         ids and bucket positions beyond the LDS capacities.
+// Two instances of every step: the normal one touches LDS only; while a burst (a frequent word that keys
+// hundreds of programs) has rule ids or bucket entries in the spill area the document runs the instance whose
+// accessors look at both places (wave-uniform switch, checked when the position advances).
 // A rule's end_ordpos is kept modulo 256: it lies within 63 positions of the current one.
 //
 // Integer only, no MFMA.  Control flow is wave-uniform; lanes are workers where the algorithm has width:
@@ -43,10 +48,6 @@ typedef uint16_t u16;
 typedef uint8_t u8;
 
 #define LANE ((u32)(threadIdx.x & 63u))
-#define LDSQ __attribute__((address_space(3)))
-typedef LDSQ u32 lu32;
-typedef LDSQ u16 lu16;
-typedef LDSQ u8 lu8;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 typedef const __attribute__((address_space(4))) FastParams& KP;
@@ -85,9 +86,6 @@ __device__ __forceinline__ u32 evhash( u32 a)		// src/ruleMatcherAutomaton.cpp:3
 __device__ __forceinline__ uint4 ld4( const void* p) { const u32x4 v = *(const u32x4*)p; return make_uint4( v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void st4( void* p, u32 a, u32 b, u32 c, u32 d) { u32x4 v; v.x = a; v.y = b; v.z = c; v.w = d; *(u32x4*)p = v; }
 __device__ __forceinline__ u32 ldu( const u32* p) { return __builtin_amdgcn_readfirstlane( *p); }
-__device__ __forceinline__ u32 ldu( const lu32* p) { return __builtin_amdgcn_readfirstlane( *p); }
-__device__ __forceinline__ u32 ldu( const lu16* p) { return __builtin_amdgcn_readfirstlane( (u32)*p); }
-__device__ __forceinline__ u32 ldu( const lu8* p) { return __builtin_amdgcn_readfirstlane( (u32)*p); }
 __device__ __forceinline__ uint4 ldu4( const void* p)
 {
 	uint4 v = ld4( p);
@@ -117,64 +115,149 @@ __device__ __forceinline__ u32 byteField( u32 c0, u32 c1, u32 c2, u32 c3, u32 h)
 }
 __device__ __forceinline__ void byteInc( u32& c0, u32& c1, u32& c2, u32& c3, u32 h)
 {
+	// (selects, not an if-chain: the compiler turns the chain into an indexed array in scratch memory)
 	const u32 inc = 1u << ((h & 3u)*8), ws = h >> 2;
-	if (ws == 0) c0 += inc; else if (ws == 1) c1 += inc; else if (ws == 2) c2 += inc; else c3 += inc;
+	c0 += ws == 0 ? inc : 0u; c1 += ws == 1 ? inc : 0u; c2 += ws == 2 ? inc : 0u; c3 += ws == 3 ? inc : 0u;
 }
-
-// ---------------------------------------------------------------- the wave's view of its state
-struct Wave
-{
-	// LDS arrays
-	lu32* sc; lu32* hot; lu16* link; lu16* next; lu16* freeS; lu32* ev; lu32* ts;
-	lu8* ctab; lu8* cfree; lu32* bsize; lu32* bchunks; lu16* win; lu32* stop; lu16* list;
-	u32* sp;		// spill + cold area in HBM
-	u32 R, T;		// LDS capacities (rules, bucket entries)
-	// per-document scalars (wave-uniform registers)
-	u32 curpos, timestamp, nInstalled, nAlt, nSignals, nTrig, openLo, openHi;
-	u32 freeN, usedL, sFreeN, usedS;	// rule ids: LDS free stack / bump, spill free stack / bump
-	u32 cFreeN, cUsed;			// bucket chunks: free stack / bump
-	u32 nDispose, nStaged, nStagedItems, err;
-	u32 lbase;				// lexem index of the event being processed, relative to the document
-	u32 why;				// reason of a hand-over (diagnostics)
-#ifdef SPA_PROF
-	u64 prof[ 12];
-#endif
-};
-
-// ---- rule fields: ids < R in LDS, others in the spill area (same shapes)
-__device__ __forceinline__ u32 ldHot( const Wave& w, KP P, u32 r) { return r < w.R ? w.hot[ r] : w.sp[ P.spill.oHot + (r - w.R)]; }
-__device__ __forceinline__ void stHot( const Wave& w, KP P, u32 r, u32 v) { if (r < w.R) w.hot[ r] = v; else w.sp[ P.spill.oHot + (r - w.R)] = v; }
-__device__ __forceinline__ u32 ldLink( const Wave& w, KP P, u32 r, u32 j) { return r < w.R ? (u32)w.link[ 3*r + j] : w.sp[ P.spill.oLink + 3*(r - w.R) + j]; }
-__device__ __forceinline__ void stLink( const Wave& w, KP P, u32 r, u32 j, u32 v) { if (r < w.R) w.link[ 3*r + j] = (u16)v; else w.sp[ P.spill.oLink + 3*(r - w.R) + j] = v; }
-__device__ __forceinline__ u32 ldNext( const Wave& w, KP P, u32 r) { return r < w.R ? (u32)w.next[ r] : w.sp[ P.spill.oNext + (r - w.R)]; }
-__device__ __forceinline__ void stNext( const Wave& w, KP P, u32 r, u32 v) { if (r < w.R) w.next[ r] = (u16)v; else w.sp[ P.spill.oNext + (r - w.R)] = v; }
-// ---- bucket entries: entry index = chunk id * 16 + offset; chunks < T/16 in LDS
-__device__ __forceinline__ u32 entryIndex( const Wave& w, u32 h, u32 pos) { return (u32)w.ctab[ h*FAST_BUCKET_CHUNKS + (pos >> 4)]*FAST_CHUNK + (pos & 15u); }
-__device__ __forceinline__ u32 ldEv( const Wave& w, KP P, u32 idx) { return idx < w.T ? w.ev[ idx] : w.sp[ P.spill.oEnt + 2*(idx - w.T)]; }
-__device__ __forceinline__ u32 ldTs( const Wave& w, KP P, u32 idx) { return idx < w.T ? w.ts[ idx] : w.sp[ P.spill.oEnt + 2*(idx - w.T) + 1]; }
-__device__ __forceinline__ void stEnt( const Wave& w, KP P, u32 idx, u32 e, u32 t)
-{
-	if (idx < w.T) { w.ev[ idx] = e; w.ts[ idx] = t; }
-	else { *(uint2*)&w.sp[ P.spill.oEnt + 2*(idx - w.T)] = make_uint2( e, t); }
-}
-// ---- the list of rules to deactivate: first FAST_LISTCAP entries in LDS, the rest in the spill area
-__device__ __forceinline__ u32 ldList( const Wave& w, KP P, u32 i) { return i < (u32)FAST_LISTCAP ? (u32)w.list[ i] : w.sp[ P.spill.oList + i]; }
-__device__ __forceinline__ void stList( const Wave& w, KP P, u32 i, u32 r) { if (i < (u32)FAST_LISTCAP) w.list[ i] = (u16)r; else w.sp[ P.spill.oList + i] = r; }
 
 // the document leaves the fast tier (a capacity of the spill area, or a case the compact state cannot express)
 #define FALLBACK( WHY) do { w.err = SPD_FAST_FALLBACK; w.why = (WHY); } while (0)
-enum {FB_LEXEMS=1, FB_DISPOSE=2, FB_ITEM_AFTER_RESULT=3, FB_ITEMS=4, FB_STAGED=5, FB_BUCKET_CHUNKS=6, FB_CHUNKS=7, FB_RULES=8, FB_BUCKET_SIZE=9};
+enum {FB_LEXEMS=1, FB_DISPOSE=2, FB_ITEM_AFTER_RESULT=3, FB_ITEMS=4, FB_STAGED=5, FB_RULES=8, FB_BUCKET_SIZE=9};
 
-// ---------------------------------------------------------------- rule word helpers
 // end_ordpos <= pos (sequence / within guard) and == pos (sequence_imm), from the 8 low bits kept in the word;
 // the true value lies in [pos-63, pos+1]
 __device__ __forceinline__ bool endLE( u32 hw, u32 pos) { return (hw & H_ENDZERO) || ((hw >> H_END_SHIFT) & H_END_MASK) != ((pos + 1u) & 0xFFu); }
 __device__ __forceinline__ bool endEQ( u32 hw, u32 pos) { return (hw & H_ENDZERO) ? (pos == 0) : (((hw >> H_END_SHIFT) & H_END_MASK) == (pos & 0xFFu)); }
 __device__ __forceinline__ u32 withEnd( u32 hw, u32 end) { return (hw & ~((H_END_MASK << H_END_SHIFT) | H_ENDZERO)) | ((end & 0xFFu) << H_END_SHIFT); }
 
+// ---------------------------------------------------------------- a fresh slot while its program is being installed
+// (registers only: the alternative-key replay and the key triggers fire before anything is stored)
+enum {S_HASSTART=1u, S_DONE=2u, S_FIN=4u, S_DEL=8u, S_ODD=16u, S_RESULT=32u, S_HASLIST=64u};
+struct Sim
+{
+	u32 value, count, end, startLex, nItems, it0, it1, it2, nFires, flags;
+	// S_HASLIST: the result shares the rule's item list only if the list existed when the rule matched (cpp:941-953):
+	// items captured later join that list (and show in the result), or start a list the result never sees
+};
+__device__ __forceinline__ void fireLocal( Sim& s, u32 info, u32 esord, u32 elex, u32 withItems)
+{
+	const u32 sigtype = (info >> FTI_SIGTYPE_SHIFT) & FTI_SIGTYPE_MASK, sigval = info & FTI_SIGVAL_MASK;
+	u32 m = 0, f = 0, took = 0;
+	s.nFires += 1;
+	if (sigtype == SIG_ANY)
+	{
+		took = 1;
+		if (s.count > 0) { m = 1; s.count -= 1; f = (s.count == 0); if (s.end < esord+1) s.end = esord+1; }
+	}
+	else if (sigtype == SIG_SEQUENCE || sigtype == SIG_SEQUENCE_IMM)
+	{
+		if (sigval == s.value && (sigtype == SIG_SEQUENCE ? (s.end <= esord) : (s.end == esord)))
+		{
+			s.end = esord+1; s.value = sigval-1;
+			if (s.count > 0) { s.count -= 1; m = (s.count == 0); } else m = 1;
+			f = (s.value == 0); took = 1;
+		}
+	}
+	else if (sigtype == SIG_WITHIN)
+	{
+		if ((sigval & s.value) != 0 && s.end <= esord)
+		{
+			s.end = esord+1; s.value &= ~sigval;
+			if (s.count > 0) { s.count -= 1; m = (s.count == 0); } else m = 1;
+			took = 1;
+		}
+	}
+	else	// SIG_DEL: the rule goes to the dispose list, nothing else happens (cpp:868-876)
+	{
+		s.count = 0; s.value = 0; s.flags |= S_DEL;
+		return;
+	}
+	if (took)
+	{
+		if ((info & FTI_HASVAR) && withItems)
+		{
+			const u32 item = elex | ((info >> FTI_VAR_SHIFT) << 24);
+			if ((s.flags & S_DONE) && !(s.flags & S_HASLIST)) {}
+			else if (s.nItems == 0) { s.it0 = item; s.nItems = 1; }
+			else if (s.nItems == 1) { s.it1 = item; s.nItems = 2; }
+			else if (s.nItems == 2) { s.it2 = item; s.nItems = 3; }
+			else s.flags |= S_ODD;
+		}
+		if (!(s.flags & S_HASSTART)) { s.startLex = elex; if (esord) s.flags |= S_HASSTART; }
+	}
+	if (m)
+	{
+		if (!(s.flags & S_DONE)) { s.flags |= S_DONE | S_RESULT; if (s.nItems) s.flags |= S_HASLIST; }
+		if (f) s.flags |= S_FIN;
+	}
+}
+
+// ---------------------------------------------------------------- LDS image of a document (static layout)
+template <int R, int T>
+struct LdsDoc
+{
+	u32 hot[ R];			// rule word
+	u32 ev[ T];			// bucket entries: event id (bucket h owns [base_h, base_h + cap_h))
+	u32 ts[ T];			// bucket entries: trigger id (rule<<2 | slot) | signal byte << 16 | variable << 24
+	u32 bsize[ 16];			// bucket sizes
+	u32 bmeta[ 16];			// base_h | cap_h << 16
+	u32 stop[ 3*FAST_MAXSTOP];	// stop-word log {lexem index, ordpos, timestamp}
+	u16 link[ 3*R];			// bucket << 12 | position of trigger slot j of rule r at [3r+j]
+	u16 next[ R];			// next rule in the expiry list of its position
+	u16 freeS[ R];			// stack of free rule ids < R
+	u16 win[ 64];			// heads of the expiry lists
+	u16 list[ FAST_LISTCAP];	// rules to deactivate (dispose list / expiry list)
+};
+
+// per-document scalars (wave-uniform registers)
+struct Wave
+{
+	u32* sp;		// spill + cold area in HBM
+	u32 curpos, timestamp, nInstalled, nAlt, nSignals, nTrig, openLo, openHi;
+	u32 freeN, usedL, sFreeN, usedS;	// rule ids: LDS free stack / bump, spill free stack / bump
+	u32 nDispose, nStaged, nStagedItems, err;
+	u32 lbase;				// lexem index of the event being processed, relative to the document
+	u32 spill;				// something of this document lives in the spill area: the two-place accessors run
+	u32 why;				// reason of a hand-over (diagnostics)
+#ifdef SPA_PROF
+	u64 prof[ 12];
+#endif
+};
+
+template <int R, int T>
+struct Engine
+{
+typedef LdsDoc<R,T> Lds;
+typedef __attribute__((address_space(3))) Lds& LR;
+
+// ---- rule fields: ids < R in LDS, others in the spill area (same shapes).  SP=false: LDS only.
+template <bool SP> static __device__ __forceinline__ u32 ldHot( LR L, const Wave& w, KP P, u32 r) { if (!SP || r < (u32)R) return L.hot[ r]; return w.sp[ P.spill.oHot + (r - R)]; }
+template <bool SP> static __device__ __forceinline__ void stHot( LR L, const Wave& w, KP P, u32 r, u32 v) { if (!SP || r < (u32)R) L.hot[ r] = v; else w.sp[ P.spill.oHot + (r - R)] = v; }
+template <bool SP> static __device__ __forceinline__ u32 ldLink( LR L, const Wave& w, KP P, u32 r, u32 j) { if (!SP || r < (u32)R) return (u32)L.link[ 3*r + j]; return w.sp[ P.spill.oLink + 3*(r - R) + j]; }
+template <bool SP> static __device__ __forceinline__ void stLink( LR L, const Wave& w, KP P, u32 r, u32 j, u32 v) { if (!SP || r < (u32)R) L.link[ 3*r + j] = (u16)v; else w.sp[ P.spill.oLink + 3*(r - R) + j] = v; }
+template <bool SP> static __device__ __forceinline__ u32 ldNext( LR L, const Wave& w, KP P, u32 r) { if (!SP || r < (u32)R) return (u32)L.next[ r]; return w.sp[ P.spill.oNext + (r - R)]; }
+template <bool SP> static __device__ __forceinline__ void stNext( LR L, const Wave& w, KP P, u32 r, u32 v) { if (!SP || r < (u32)R) L.next[ r] = (u16)v; else w.sp[ P.spill.oNext + (r - R)] = v; }
+// ---- bucket entries: position p of bucket h sits at base_h + p while p < cap_h, else in the bucket's spill row
+template <bool SP> static __device__ __forceinline__ u32 ldEv( LR L, const Wave& w, KP P, u32 h, u32 meta, u32 pos)
+{ if (!SP || pos < (meta >> 16)) return L.ev[ (meta & 0xFFFFu) + pos]; return w.sp[ P.spill.oEnt + 2*(h*FAST_SPILL_BUCKET + pos - (meta >> 16))]; }
+template <bool SP> static __device__ __forceinline__ u32 ldTs( LR L, const Wave& w, KP P, u32 h, u32 meta, u32 pos)
+{ if (!SP || pos < (meta >> 16)) return L.ts[ (meta & 0xFFFFu) + pos]; return w.sp[ P.spill.oEnt + 2*(h*FAST_SPILL_BUCKET + pos - (meta >> 16)) + 1]; }
+template <bool SP> static __device__ __forceinline__ void stEnt( LR L, const Wave& w, KP P, u32 h, u32 meta, u32 pos, u32 e, u32 t)
+{
+	if (!SP || pos < (meta >> 16)) { L.ev[ (meta & 0xFFFFu) + pos] = e; L.ts[ (meta & 0xFFFFu) + pos] = t; }
+	else *(uint2*)&w.sp[ P.spill.oEnt + 2*(h*FAST_SPILL_BUCKET + pos - (meta >> 16))] = make_uint2( e, t);
+}
+// ---- the list of rules to deactivate: first FAST_LISTCAP entries in LDS, the rest in the spill area
+template <bool SP> static __device__ __forceinline__ u32 ldList( LR L, const Wave& w, KP P, u32 i) { if (!SP || i < (u32)FAST_LISTCAP) return (u32)L.list[ i]; return w.sp[ P.spill.oList + i]; }
+static __device__ __forceinline__ void pushList( LR L, Wave& w, KP P, u32 i, u32 r)	// uniform index, one lane stores
+{
+	if (i < (u32)FAST_LISTCAP) { if (LANE == 0) L.list[ i] = (u16)r; }
+	else { w.spill = 1; if (LANE == 0) w.sp[ P.spill.oList + i] = r; }
+}
+
 // ---------------------------------------------------------------- staged results
 // {resultHandle, formatHandle, first lexem, last lexem, nItems | var0<<8 | var1<<16 | var2<<24, item lexems x3} (items latest first)
-__device__ __forceinline__ void stageResult( Wave& w, KP P, u32 at, u32 handle, u32 fmt, u32 startLex, u32 endLex, u32 nItems, u32 vars, u32 i0, u32 i1, u32 i2)
+static __device__ __forceinline__ void stageResult( Wave& w, KP P, u32 at, u32 handle, u32 fmt, u32 startLex, u32 endLex, u32 nItems, u32 vars, u32 i0, u32 i1, u32 i2)
 {
 	u32* S = &w.sp[ P.spill.oStaged + 8*at];
 	st4( S, handle, fmt, startLex, endLex);
@@ -183,11 +266,12 @@ __device__ __forceinline__ void stageResult( Wave& w, KP P, u32 at, u32 handle, 
 
 // ---------------------------------------------------------------- fireSignal (cpp:772-979) on an installed trigger
 // uniform: every lane computes the same; stores by lane 0
-__device__ __forceinline__ void fireSignal( Wave& w, KP P, u32 tsv, u32 sord)
+template <bool SP>
+static __device__ __forceinline__ void fireSignal( LR L, Wave& w, KP P, u32 tsv, u32 sord)
 {
 	const u32 tid = tsv & 0xFFFFu, r = tid >> 2;
 	const u32 sigval = (tsv >> 16) & 0xFu, sigtype = (tsv >> 20) & 0x7u, hasVar = (tsv >> 23) & 1u, variable = tsv >> 24;
-	u32 hw = bcast0( ldHot( w, P, r));
+	u32 hw = bcast0( ldHot<SP>( L, w, P, r));
 	w.nSignals += 1;
 	u32 value = hw & H_VALUE_MASK, count = (hw >> H_COUNT_SHIFT) & H_COUNT_MASK;
 	bool match = false, take = false, fin = false;
@@ -216,8 +300,8 @@ __device__ __forceinline__ void fireSignal( Wave& w, KP P, u32 tsv, u32 sord)
 			break;
 		default: // SIG_DEL
 			hw &= ~(H_VALUE_MASK | (H_COUNT_MASK << H_COUNT_SHIFT));
-			if (LANE == 0) stHot( w, P, r, hw);
-			if (w.nDispose < P.spill.maxRules) { if (LANE == 0) stList( w, P, w.nDispose, r); w.nDispose += 1; } else FALLBACK( FB_DISPOSE);
+			if (LANE == 0) stHot<SP>( L, w, P, r, hw);
+			if (w.nDispose < P.spill.maxRules) { pushList( L, w, P, w.nDispose, r); w.nDispose += 1; } else FALLBACK( FB_DISPOSE);
 			return;
 	}
 	const bool done = (hw & H_DONE) != 0;
@@ -248,7 +332,7 @@ __device__ __forceinline__ void fireSignal( Wave& w, KP P, u32 tsv, u32 sord)
 	}
 	hw = (hw & ~(H_VALUE_MASK | (H_COUNT_MASK << H_COUNT_SHIFT) | (H_NITEMS_MASK << H_NITEMS_SHIFT))) | value | (count << H_COUNT_SHIFT) | (nItems << H_NITEMS_SHIFT);
 	if (match && !done) hw |= H_DONE;
-	if (LANE == 0) stHot( w, P, r, hw);
+	if (LANE == 0) stHot<SP>( L, w, P, r, hw);
 	if (match)
 	{
 		if (!done)
@@ -273,48 +357,9 @@ __device__ __forceinline__ void fireSignal( Wave& w, KP P, u32 tsv, u32 sord)
 		}
 		if (fin)
 		{
-			if (w.nDispose < P.spill.maxRules) { if (LANE == 0) stList( w, P, w.nDispose, r); w.nDispose += 1; } else FALLBACK( FB_DISPOSE);
+			if (w.nDispose < P.spill.maxRules) { pushList( L, w, P, w.nDispose, r); w.nDispose += 1; } else FALLBACK( FB_DISPOSE);
 		}
 	}
-}
-
-// ---------------------------------------------------------------- bucket chunks
-// make room for the new sizes of the buckets (lane b < 16 holds newSize of bucket b)
-__device__ __forceinline__ void reserveChunks( Wave& w, KP P, u32 newSize)
-{
-	u32 need = 0, have = 0;
-	if (LANE < 16u) { have = w.bchunks[ LANE]; const u32 want = (newSize + FAST_CHUNK-1) / FAST_CHUNK; need = want > have ? want - have : 0u; }
-	if (!__ballot( need != 0)) return;
-	const bool tooMany = have + need > (u32)FAST_BUCKET_CHUNKS;
-	u32 incl = waveScanAdd( need);
-	const u32 total = (u32)__builtin_amdgcn_readlane( incl, 63);
-	const u32 fromStack = w.cFreeN < total ? w.cFreeN : total;
-	if (__ballot( tooMany)) { FALLBACK( FB_BUCKET_CHUNKS); return; }
-	if (w.cUsed + (total - fromStack) > (u32)FAST_MAXCHUNKS) { FALLBACK( FB_CHUNKS); return; }
-	const u32 excl = incl - need;
-	for (u32 k=0; k<need; ++k)
-	{
-		const u32 q = excl + k;
-		const u32 c = q < fromStack ? (u32)w.cfree[ w.cFreeN - 1 - q] : w.cUsed + (q - fromStack);
-		w.ctab[ LANE*FAST_BUCKET_CHUNKS + have + k] = (u8)c;
-	}
-	if (need) w.bchunks[ LANE] = have + need;
-	w.cFreeN -= fromStack; w.cUsed += total - fromStack;
-	WAVE_FENCE();
-}
-// give back the chunks the buckets no longer need (called when the position advances)
-__device__ __forceinline__ void trimChunks( Wave& w, KP P)
-{
-	u32 extra = 0, have = 0, want = 0;
-	if (LANE < 16u) { have = w.bchunks[ LANE]; want = (w.bsize[ LANE] + FAST_CHUNK-1) / FAST_CHUNK; extra = have - want; }
-	if (!__ballot( extra != 0)) return;
-	u32 incl = waveScanAdd( extra);
-	const u32 total = (u32)__builtin_amdgcn_readlane( incl, 63);
-	const u32 excl = incl - extra;
-	for (u32 k=0; k<extra; ++k) w.cfree[ w.cFreeN + excl + k] = w.ctab[ LANE*FAST_BUCKET_CHUNKS + want + k];
-	if (extra) w.bchunks[ LANE] = want;
-	w.cFreeN += total;
-	WAVE_FENCE();
 }
 
 // ---------------------------------------------------------------- deactivation of a list of rules
@@ -323,14 +368,15 @@ __device__ __forceinline__ void trimChunks( Wave& w, KP P)
 // removals in different buckets do not interact, inside a bucket they must run in list order (rule by
 // rule, a rule's triggers last installed first).  Every lane takes a rule; in each round a lane removes
 // its next trigger if no lane before it still has a trigger in the same bucket.
-__device__ __forceinline__ void deactivateList( Wave& w, KP P, u32 n, bool freeIds, bool mayRepeat)
+template <bool SP>
+static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 n, bool freeIds, bool mayRepeat)
 {
 	for (u32 base=0; base<n && !w.err; base+=64)
 	{
 		const u32 nb = (n - base) < 64u ? (n - base) : 64u;
 		const bool have = LANE < nb;
 		u32 r = 0, hw = 0;
-		if (have) { r = ldList( w, P, base + LANE); hw = ldHot( w, P, r); }
+		if (have) { r = ldList<SP>( L, w, P, base + LANE); hw = ldHot<SP>( L, w, P, r); }
 		bool act = have && (hw & H_ACTIVE);
 		if (mayRepeat && nb > 1)
 		{
@@ -342,11 +388,11 @@ __device__ __forceinline__ void deactivateList( Wave& w, KP P, u32 n, bool freeI
 			}
 		}
 		u32 mask = act ? ((hw >> H_TMASK_SHIFT) & H_TMASK_MASK) : 0u;
-		if (act) stHot( w, P, r, hw & ~(H_ACTIVE | (H_TMASK_MASK << H_TMASK_SHIFT)));
+		if (act) stHot<SP>( L, w, P, r, hw & ~(H_ACTIVE | (H_TMASK_MASK << H_TMASK_SHIFT)));
 		// buckets of my triggers
 		u32 hj[ 3];
 #pragma unroll
-		for (int j=0; j<3; ++j) hj[ j] = ((mask >> j) & 1u) ? (ldLink( w, P, r, (u32)j) >> 12) : 16u;
+		for (int j=0; j<3; ++j) hj[ j] = ((mask >> j) & 1u) ? (ldLink<SP>( L, w, P, r, (u32)j) >> 12) : 16u;
 		u32 removed = 0;
 #ifdef SPA_PROF
 		const u64 prof_r0 = __builtin_amdgcn_s_memtime(); u32 prof_rounds = 0;
@@ -356,28 +402,28 @@ __device__ __forceinline__ void deactivateList( Wave& w, KP P, u32 n, bool freeI
 #ifdef SPA_PROF
 			++prof_rounds;
 #endif
+			if (!__ballot( mask != 0)) break;
 			// my next trigger: the highest remaining slot
 			const u32 j = mask ? (31u - (u32)__builtin_clz( mask)) : 0u;
 			const u32 h = mask ? (j == 2 ? hj[ 2] : j == 1 ? hj[ 1] : hj[ 0]) : 0u;
 			u32 pb = 0;
 #pragma unroll
 			for (int q=0; q<3; ++q) if ((mask >> q) & 1u) pb |= 1u << hj[ q];
-			if (!__ballot( mask != 0)) break;
 			const u32 before = fromLaneBelow( waveScanOr( pb));
 			const bool go = mask != 0 && !((before >> h) & 1u);
 			if (go)
 			{
 				// cpp:133-152: the bucket's last entry moves into the hole
-				const u32 pos = ldLink( w, P, r, j) & 0xFFFu;
-				const u32 last = w.bsize[ h] - 1u;
+				const u32 pos = ldLink<SP>( L, w, P, r, j) & 0xFFFu;
+				const u32 last = L.bsize[ h] - 1u;
 				if (pos != last)
 				{
-					const u32 li = entryIndex( w, h, last);
-					const u32 me = ldEv( w, P, li), mt = ldTs( w, P, li);
-					stEnt( w, P, entryIndex( w, h, pos), me, mt);
-					stLink( w, P, (mt & 0xFFFFu) >> 2, mt & 3u, (h << 12) | pos);
+					const u32 meta = L.bmeta[ h];
+					const u32 me = ldEv<SP>( L, w, P, h, meta, last), mt = ldTs<SP>( L, w, P, h, meta, last);
+					stEnt<SP>( L, w, P, h, meta, pos, me, mt);
+					stLink<SP>( L, w, P, (mt & 0xFFFFu) >> 2, mt & 3u, (h << 12) | pos);
 				}
-				w.bsize[ h] = last;
+				L.bsize[ h] = last;
 				mask &= ~(1u << j);
 				++removed;
 			}
@@ -393,62 +439,204 @@ __device__ __forceinline__ void deactivateList( Wave& w, KP P, u32 n, bool freeI
 		}
 		if (freeIds)
 		{
-			const u64 mL = __ballot( have && r < w.R), mS = __ballot( have && r >= w.R);
-			if (have)
+			const u64 mL = __ballot( have && r < (u32)R);
+			if (have && r < (u32)R) L.freeS[ w.freeN + (u32)__popcll( mL & lanesBelow())] = (u16)r;
+			w.freeN += (u32)__popcll( mL);
+			if (SP)
 			{
-				if (r < w.R) w.freeS[ w.freeN + (u32)__popcll( mL & lanesBelow())] = (u16)r;
-				else w.sp[ P.spill.oFree + w.sFreeN + (u32)__popcll( mS & lanesBelow())] = r - w.R;
+				const u64 mS = __ballot( have && r >= (u32)R);
+				if (have && r >= (u32)R) w.sp[ P.spill.oFree + w.sFreeN + (u32)__popcll( mS & lanesBelow())] = r - R;
+				w.sFreeN += (u32)__popcll( mS);
 			}
-			w.freeN += (u32)__popcll( mL); w.sFreeN += (u32)__popcll( mS);
 		}
 		WAVE_FENCE();
 	}
 }
 
 // ---------------------------------------------------------------- expiry (cpp:1084-1135, window part: ranges are <= 63)
-__device__ __forceinline__ void setCurrentPos( Wave& w, KP P, u32 pos)
+template <bool SP>
+static __device__ __forceinline__ void expireSlot( LR L, Wave& w, KP P, u32 slot, u32 r)
+{
+	// the rules of this position, last defined first (the list is LIFO like the reference's)
+	u32 n = 0;
+#ifdef SPA_PROF
+	const u64 prof_w0 = __builtin_amdgcn_s_memtime();
+#endif
+	for (; r != (u32)NIL16; ++n)
+	{
+		if (n >= P.spill.maxRules) { w.err = SPD_ERR_INTERNAL; return; }
+		if (SP) pushList( L, w, P, n, r);
+		else if (LANE == 0) L.list[ n] = (u16)r;		// (a list beyond FAST_LISTCAP entries only forms in spill mode: R <= FAST_LISTCAP)
+		r = bcast0( ldNext<SP>( L, w, P, r));
+	}
+#ifdef SPA_PROF
+	w.prof[ 6] += __builtin_amdgcn_s_memtime() - prof_w0;
+#endif
+	if (LANE == 0) L.win[ slot] = (u16)NIL16;
+	WAVE_FENCE();
+	deactivateList<SP>( L, w, P, n, true, false);
+}
+
+static __device__ __forceinline__ void setCurrentPos( LR L, Wave& w, KP P, u32 pos)
 {
 	if (w.curpos == pos) return;
 	u32 wcnt = 0;
 	for (; wcnt < 64u && w.curpos < pos && !w.err; ++wcnt, ++w.curpos)
 	{
 		const u32 slot = w.curpos & 63u;
-		u32 r = ldu( &w.win[ slot]);
+		const u32 r = bcast0( (u32)L.win[ slot]);
 		if (r != (u32)NIL16)
 		{
-			// the rules of this position, last defined first (the list is LIFO like the reference's)
-			u32 n = 0;
-#ifdef SPA_PROF
-			const u64 prof_w0 = __builtin_amdgcn_s_memtime();
-#endif
-			for (; r != (u32)NIL16; ++n)
-			{
-				if (n >= P.spill.maxRules) { w.err = SPD_ERR_INTERNAL; return; }
-				if (LANE == 0) stList( w, P, n, r);
-				r = bcast0( ldNext( w, P, r));
-			}
-#ifdef SPA_PROF
-			w.prof[ 6] += __builtin_amdgcn_s_memtime() - prof_w0;
-#endif
-			if (LANE == 0) w.win[ slot] = (u16)NIL16;
-			WAVE_FENCE();
-			deactivateList( w, P, n, true, false);
+			if (w.spill) expireSlot<true>( L, w, P, slot, r); else expireSlot<false>( L, w, P, slot, r);
 		}
 	}
 	if (w.curpos < pos) w.curpos = pos;
-	trimChunks( w, P);
+	if (w.spill)
+	{
+		// back to the LDS-only instance once nothing of the document is in the spill area any more
+		bool over = false;
+		if (LANE < 16u) over = L.bsize[ LANE] > (L.bmeta[ LANE] >> 16);
+		if (!__ballot( over) && w.sFreeN == w.usedS) { w.spill = 0; w.sFreeN = 0; w.usedS = 0; }
+	}
 }
 
 // ---------------------------------------------------------------- installEventPrograms (cpp:1137-1157), 64 programs at a time
 // Lane l instantiates program l of the key event's list.  Everything whose ORDER is observable lands where
 // the sequential loop would have put it: bucket positions, expiry lists, results and dispose entries all
 // advance in lane order through ballots and prefix sums.
-struct Local		// a lexem event as a fired trigger sees it
+template <bool SP>
+static __device__ __forceinline__ void installBatchT( LR L, Wave& w, KP P, u32 kb, u32 nb, u32 sord, u64 matMaskIn, u32 rIn,
+	const uint4 q0, const uint4 q1, const uint4 q2, const Sim sim)
 {
-	u32 sord, lex;
-};
+	const u32 value = sim.value, count = sim.count, end = sim.end, startLex = sim.startLex, nItems = sim.nItems, it0 = sim.it0, it1 = sim.it1, it2 = sim.it2;
+	const bool hasStart = (sim.flags & S_HASSTART) != 0, done = (sim.flags & S_DONE) != 0, fin = (sim.flags & S_FIN) != 0, del = (sim.flags & S_DEL) != 0, resultNow = (sim.flags & S_RESULT) != 0;
+	const bool have = LANE < nb;
+	const u32 handle = q0.x, fmt = q0.y, meta = q0.w;
+	const u32 tEv[ 3] = {q1.x, q1.z, q2.x};
+	const u32 tInfo[ 3] = {q1.y, q1.w, q2.y};
+	const u32 range = (meta >> FKI_RANGE_SHIFT) & FKI_RANGE_MASK;
+	const u64 matMask = matMaskIn;
+	const bool mat = (matMask >> LANE) & 1ull;
+	const u32 nmat = (u32)__popcll( matMask);
+	const u32 r = rIn;
+	// ---- expiry list of position sord+range (cpp:1066-1082): LIFO, the batch pushes in lane order
+	if (nmat)
+	{
+		const u32 slot = (sord + range) & 63u;
+		u64 same = matMask;
+#pragma unroll
+		for (int k=0; k<6; ++k)
+		{
+			const u64 bk = __ballot( mat && ((slot >> k) & 1u));
+			same &= ((slot >> k) & 1u) ? bk : ~bk;
+		}
+		const u64 lower = same & lanesBelow();
+		const u32 prevLane = lower ? (63u - (u32)__builtin_clzll( lower)) : 0u;
+		const u32 prevRule = (u32)__builtin_amdgcn_ds_bpermute( (int)(prevLane << 2), (int)r);
+		if (mat)
+		{
+			const u32 nx = lower ? prevRule : (u32)L.win[ slot];
+			stNext<SP>( L, w, P, r, nx);
+		}
+		WAVE_FENCE();
+		if (mat && !(same >> LANE >> 1)) L.win[ slot] = (u16)r;	// the last lane of a position becomes its head
+	}
+	// ---- triggers: bucket positions in (program, template) order (cpp:1204-1250 -> EventTriggerTable::add :114-131)
+	u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+	u32 hB[ 3]; bool inst[ 3];
+#pragma unroll
+	for (int j=0; j<3; ++j)
+	{
+		hB[ j] = (tInfo[ j] >> FTI_BUCKET_SHIFT) & 15u;
+		inst[ j] = mat && (tInfo[ j] & FTI_INSTALL);
+		if (inst[ j]) byteInc( c0, c1, c2, c3, hB[ j]);
+	}
+	u32 tmask = 0;
+	if (__ballot( inst[ 0] || inst[ 1] || inst[ 2]))
+	{
+		u32 i0 = waveScanAdd( c0), i1 = waveScanAdd( c1), i2 = waveScanAdd( c2), i3 = waveScanAdd( c3);	// fields stay < 256 (64 x 3)
+		const u32 e0 = i0 - c0, e1 = i1 - c1, e2 = i2 - c2, e3 = i3 - c3;
+		const u32 t0 = (u32)__builtin_amdgcn_readlane( i0, 63), t1 = (u32)__builtin_amdgcn_readlane( i1, 63);
+		const u32 t2 = (u32)__builtin_amdgcn_readlane( i2, 63), t3 = (u32)__builtin_amdgcn_readlane( i3, 63);
+		u32 oldSize = 0, add = 0;
+		if (LANE < 16u) { oldSize = L.bsize[ LANE]; add = byteField( t0, t1, t2, t3, LANE); }
+#pragma unroll
+		for (int j=0; j<3; ++j)
+		{
+			if (inst[ j])
+			{
+				const u32 h = hB[ j];
+				u32 sameB = 0;
+#pragma unroll
+				for (int jj=0; jj<j; ++jj) if (inst[ jj] && hB[ jj] == h) ++sameB;	// my own earlier templates
+				const u32 pos = L.bsize[ h] + byteField( e0, e1, e2, e3, h) + sameB;
+				const u32 sv = (tInfo[ j] & FTI_SIGVAL_MASK) | (((tInfo[ j] >> FTI_SIGTYPE_SHIFT) & FTI_SIGTYPE_MASK) << 4) | ((tInfo[ j] & FTI_HASVAR) ? 0x80u : 0u);
+				stEnt<SP>( L, w, P, h, L.bmeta[ h], pos, tEv[ j], (4*r + (u32)j) | (sv << 16) | ((tInfo[ j] >> FTI_VAR_SHIFT) << 24));
+				stLink<SP>( L, w, P, r, (u32)j, (h << 12) | pos);
+				tmask |= 1u << j;
+			}
+		}
+		WAVE_FENCE();
+		if (LANE < 16u && add) L.bsize[ LANE] = oldSize + add;
+		{
+			const u32 s = t0 + t1 + t2 + t3;
+			w.nTrig += (s & 0xFFu) + ((s >> 8) & 0xFFu) + ((s >> 16) & 0xFFu) + (s >> 24);	// (all fields together count <= 64 x 3 installs: no carries)
+		}
+	}
+	// ---- the rule itself
+	if (mat)
+	{
+		u32 hw = value | (count << H_COUNT_SHIFT) | H_ACTIVE | (tmask << H_TMASK_SHIFT) | (nItems << H_NITEMS_SHIFT);
+		hw |= end ? ((end & 0xFFu) << H_END_SHIFT) : (u32)H_ENDZERO;
+		if (done) hw |= H_DONE;
+		if (hasStart) hw |= H_HASSTART;
+		stHot<SP>( L, w, P, r, hw);
+		u32* cold = &w.sp[ P.spill.oCold + 8*r];
+		st4( cold, handle, fmt, startLex, it0);
+		*(uint2*)(cold + 4) = make_uint2( it1, it2);
+	}
+	// ---- results (cpp:954-965), in lane order; items latest first
+	{
+		const bool emit = have && resultNow && handle != 0;
+		const u64 rm = __ballot( emit);
+		if (rm)
+		{
+			const u32 nr = (u32)__popcll( rm);
+			if (w.nStaged + nr > P.spill.maxStaged) { FALLBACK( FB_STAGED); return; }
+			if (emit)
+			{
+				const u32 ia = nItems == 3 ? it2 : nItems == 2 ? it1 : it0;		// items latest first
+				const u32 ib = nItems == 3 ? it1 : it0;
+				const u32 ic = it0;
+				const u32 vars = nItems == 0 ? 0u : nItems == 1 ? (ia >> 24) : nItems == 2 ? ((ia >> 24) | ((ib >> 24) << 8)) : ((ia >> 24) | ((ib >> 24) << 8) | ((ic >> 24) << 16));
+				stageResult( w, P, w.nStaged + (u32)__popcll( rm & lanesBelow()), handle, fmt, startLex, w.lbase, nItems, vars, ia & 0xFFFFFFu, ib & 0xFFFFFFu, ic & 0xFFFFFFu);
+			}
+			w.nStaged += nr;
+			u32 incl = waveScanAdd( emit ? nItems : 0u);
+			w.nStagedItems += (u32)__builtin_amdgcn_readlane( incl, 63);
+		}
+	}
+	// ---- rules that finished or were deleted by their own key event: deactivated after the installs (cpp:1030-1034)
+	{
+		const bool wantDispose = mat && (del || fin);
+		const u64 dm = __ballot( wantDispose);
+		if (dm)
+		{
+			const u32 nd = (u32)__popcll( dm);
+			if (w.nDispose + nd > P.spill.maxRules) { FALLBACK( FB_DISPOSE); return; }
+			if (w.nDispose + nd > (u32)FAST_LISTCAP) w.spill = 1;
+			if (wantDispose)
+			{
+				const u32 at = w.nDispose + (u32)__popcll( dm & lanesBelow());
+				if (at < (u32)FAST_LISTCAP) L.list[ at] = (u16)r; else w.sp[ P.spill.oList + at] = r;
+			}
+			w.nDispose += nd;
+		}
+	}
+	WAVE_FENCE();
+}
 
-__device__ __forceinline__ void installBatch( Wave& w, KP P, u32 kb, u32 kc, u32 sord)
+static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb, u32 kc, u32 sord)
 {
 	for (u32 base=0; base<kc && !w.err; base+=64)
 	{
@@ -460,108 +648,59 @@ __device__ __forceinline__ void installBatch( Wave& w, KP P, u32 kb, u32 kc, u32
 			const FastKeyInst* K = &P.keyinst[ kb + base + LANE];
 			q0 = ld4( K); q1 = ld4( (const u32*)K + 4); q2 = ld4( (const u32*)K + 8);
 		}
-		const u32 handle = q0.x, fmt = q0.y, pastEvent = q0.z, meta = q0.w;
+		const u32 pastEvent = q0.z, meta = q0.w;
 		const u32 tEv[ 3] = {q1.x, q1.z, q2.x};
-		u32 tInfo[ 3] = {q1.y, q1.w, q2.y};
-		const u32 ntrig = (meta >> FKI_NTRIG_SHIFT) & FKI_NTRIG_MASK;
-#pragma unroll
-		for (int j=0; j<3; ++j) if ((u32)j >= ntrig) tInfo[ j] = 0;
+		const u32 tInfo[ 3] = {q1.y, q1.w, q2.y};		// (templates beyond the program's count are all zero)
 		const u32 range = (meta >> FKI_RANGE_SHIFT) & FKI_RANGE_MASK;
 		// ---- signals on the fresh slot, in registers: (1) an alternative-keyed program replays the logged
 		//      original key event (cpp:1253-1258 -> :1272-1334), (2) the key trigger(s) fire (cpp:1259-1269)
-		u32 value = meta & FKI_VALUE_MASK, count = (meta >> FKI_COUNT_SHIFT) & FKI_COUNT_MASK, end = 0;
-		u32 startLex = 0, nItems = 0, it0 = 0, it1 = 0, it2 = 0, nFires = 0;
-		bool hasStart = false, done = false, fin = false, del = false, odd = false, resultNow = false;
-		bool resultHasList = false;	// the result shares the rule's item list only if the list existed when the rule matched (cpp:941-953):
-						// items captured later join that list (and show in the result), or start a list the result never sees
-		auto fireLocal = [&]( u32 j, u32 info, const Local& e) {
-			const u32 sigtype = (info >> FTI_SIGTYPE_SHIFT) & FTI_SIGTYPE_MASK, sigval = info & FTI_SIGVAL_MASK;
-			bool m = false, f = false, took = false;
-			++nFires;
-			switch (sigtype)
-			{
-				case SIG_ANY:
-					took = true;
-					if (count > 0) { m = true; --count; f = (count == 0); if (end < e.sord+1) end = e.sord+1; }
-					break;
-				case SIG_SEQUENCE:
-				case SIG_SEQUENCE_IMM:
-					if (sigval == value && (sigtype == SIG_SEQUENCE ? (end <= e.sord) : (end == e.sord)))
-					{
-						end = e.sord+1; value = sigval-1;
-						if (count > 0) { --count; m = (count == 0); } else m = true;
-						f = (value == 0); took = true;
-					}
-					break;
-				case SIG_WITHIN:
-					if ((sigval & value) != 0 && end <= e.sord)
-					{
-						end = e.sord+1; value &= ~sigval;
-						if (count > 0) { --count; m = (count == 0); } else m = true;
-						took = true;
-					}
-					break;
-				default:	// SIG_DEL: the rule goes to the dispose list, nothing else happens (cpp:868-876)
-					count = 0; value = 0; del = true;
-					return;
-			}
-			if (took)
-			{
-				if ((info & FTI_HASVAR) && P.withItems)
-				{
-					if (done && !resultHasList) {}
-					else if (nItems == 0) { it0 = e.lex | ((info >> FTI_VAR_SHIFT) << 24); nItems = 1; }
-					else if (nItems == 1) { it1 = e.lex | ((info >> FTI_VAR_SHIFT) << 24); nItems = 2; }
-					else if (nItems == 2) { it2 = e.lex | ((info >> FTI_VAR_SHIFT) << 24); nItems = 3; }
-					else odd = true;
-				}
-				if (!hasStart) { startLex = e.lex; hasStart = (e.sord != 0); }
-			}
-			if (m) { if (!done) { done = true; resultNow = true; resultHasList = nItems != 0; } if (f) fin = true; }
-		};
+		Sim sim;
+		sim.value = meta & FKI_VALUE_MASK; sim.count = (meta >> FKI_COUNT_SHIFT) & FKI_COUNT_MASK; sim.end = 0;
+		sim.startLex = 0; sim.nItems = 0; sim.it0 = 0; sim.it1 = 0; sim.it2 = 0; sim.nFires = 0; sim.flags = 0;
 		bool dropped = false;		// deactivated by the replay: the rule never becomes visible to anything else
-		const u32 psi = (meta >> FKI_PASTSTOP_SHIFT) & FKI_PASTSTOP_MASK;
-		if (have && pastEvent && psi)
+		if (__ballot( have && pastEvent != 0))
 		{
-			const u32 plex = w.stop[ 3*(psi-1)], psord = w.stop[ 3*(psi-1)+1], pts = w.stop[ 3*(psi-1)+2];
-			if (pts && psord + range >= w.curpos)
+			const u32 psi = (meta >> FKI_PASTSTOP_SHIFT) & FKI_PASTSTOP_MASK;
+			if (have && pastEvent && psi)
 			{
-				Local pe; pe.sord = psord; pe.lex = plex;
-#pragma unroll
-				for (int j=2; j>=0; --j)		// the rule's trigger list: last installed first
+				const u32 plex = L.stop[ 3*(psi-1)], psord = L.stop[ 3*(psi-1)+1], pts = L.stop[ 3*(psi-1)+2];
+				if (pts && psord + range >= w.curpos)
 				{
-					if ((tInfo[ j] & FTI_INSTALL) && tEv[ j] == pastEvent) fireLocal( (u32)j, tInfo[ j], pe);
-				}
-				// a structure delimiter logged after the replayed event cancels the rule (cpp:1306-1321)
-				bool cancelled = false;
 #pragma unroll
-				for (int j=0; j<3; ++j)
-				{
-					if ((tInfo[ j] & FTI_INSTALL) && ((tInfo[ j] >> FTI_SIGTYPE_SHIFT) & FTI_SIGTYPE_MASK) == SIG_DEL)
+					for (int j=2; j>=0; --j)		// the rule's trigger list: last installed first
 					{
-						const u32 esi = (tInfo[ j] >> FTI_DELSTOP_SHIFT) & FTI_DELSTOP_MASK;
-						if (esi) { const u32 ts = w.stop[ 3*(esi-1)+2]; if (ts && ts > pts) cancelled = true; }
+						if ((tInfo[ j] & FTI_INSTALL) && tEv[ j] == pastEvent) fireLocal( sim, tInfo[ j], psord, plex, P.withItems);
 					}
+					// a structure delimiter logged after the replayed event cancels the rule (cpp:1306-1321)
+					bool cancelled = false;
+#pragma unroll
+					for (int j=0; j<3; ++j)
+					{
+						if ((tInfo[ j] & FTI_INSTALL) && ((tInfo[ j] >> FTI_SIGTYPE_SHIFT) & FTI_SIGTYPE_MASK) == SIG_DEL)
+						{
+							const u32 esi = (tInfo[ j] >> FTI_DELSTOP_SHIFT) & FTI_DELSTOP_MASK;
+							if (esi) { const u32 ts = L.stop[ 3*(esi-1)+2]; if (ts && ts > pts) cancelled = true; }
+						}
+					}
+					if (cancelled || (sim.flags & (S_DEL | S_FIN))) dropped = true;	// (replayPastEvent deactivates what its signals disposed, cpp:1322-1330)
 				}
-				if (cancelled || del || fin) dropped = true;	// (replayPastEvent deactivates what its signals disposed, cpp:1322-1330)
 			}
+			w.nAlt += (u32)__popcll( __ballot( have && pastEvent != 0));
 		}
 		if (have && !dropped)
 		{
-			Local ke; ke.sord = sord; ke.lex = w.lbase;
 #pragma unroll
-			for (int j=0; j<3; ++j) if (tInfo[ j] & FTI_KEY) fireLocal( (u32)j, tInfo[ j], ke);
+			for (int j=0; j<3; ++j) if (tInfo[ j] & FTI_KEY) fireLocal( sim, tInfo[ j], sord, w.lbase, P.withItems);
 		}
-		if (__ballot( odd)) { FALLBACK( FB_ITEMS); return; }
+		if (__ballot( (sim.flags & S_ODD) != 0)) { FALLBACK( FB_ITEMS); return; }
 		const bool mat = have && !dropped;
 		const u64 matMask = __ballot( mat);
 		const u32 nmat = (u32)__popcll( matMask);
 		const u32 rank = (u32)__popcll( matMask & lanesBelow());
-		// ---- statistics (cpp:1251, :1256, :780)
+		// ---- statistics (cpp:1251, :780)
 		w.nInstalled += nb;
-		w.nAlt += (u32)__popcll( __ballot( have && pastEvent != 0));
 		{
-			u32 incl = waveScanAdd( have ? nFires : 0u);
+			u32 incl = waveScanAdd( have ? sim.nFires : 0u);
 			w.nSignals += (u32)__builtin_amdgcn_readlane( incl, 63);
 		}
 		// ---- rule ids: LDS free stack, LDS bump, spill free stack, spill bump
@@ -569,154 +708,95 @@ __device__ __forceinline__ void installBatch( Wave& w, KP P, u32 kb, u32 kc, u32
 		if (nmat)
 		{
 			const u32 a = w.freeN < nmat ? w.freeN : nmat;
-			const u32 roomL = w.R - w.usedL;
+			const u32 roomL = (u32)R - w.usedL;
 			const u32 b = (nmat - a) < roomL ? (nmat - a) : roomL;
-			const u32 c = w.sFreeN < (nmat - a - b) ? w.sFreeN : (nmat - a - b);
-			const u32 d = nmat - a - b - c;
-			if (w.R + w.usedS + d > P.spill.maxRules) { FALLBACK( FB_RULES); return; }
+			const u32 rest = nmat - a - b;
+			if (rest)
+			{
+				const u32 c = w.sFreeN < rest ? w.sFreeN : rest;
+				const u32 d = rest - c;
+				if ((u32)R + w.usedS + d > P.spill.maxRules) { FALLBACK( FB_RULES); return; }
+				w.spill = 1;
+				if (mat && rank >= a+b)
+				{
+					if (rank < a+b+c) r = (u32)R + w.sp[ P.spill.oFree + w.sFreeN - 1 - (rank - a - b)];
+					else r = (u32)R + w.usedS + (rank - a - b - c);
+				}
+				w.sFreeN -= c; w.usedS += d;
+			}
 			if (mat)
 			{
-				if (rank < a) r = (u32)w.freeS[ w.freeN - 1 - rank];
+				if (rank < a) r = (u32)L.freeS[ w.freeN - 1 - rank];
 				else if (rank < a+b) r = w.usedL + (rank - a);
-				else if (rank < a+b+c) r = w.R + w.sp[ P.spill.oFree + w.sFreeN - 1 - (rank - a - b)];
-				else r = w.R + w.usedS + (rank - a - b - c);
 			}
-			w.freeN -= a; w.usedL += b; w.sFreeN -= c; w.usedS += d;
+			w.freeN -= a; w.usedL += b;
 		}
-		// ---- expiry list of position sord+range (cpp:1066-1082): LIFO, the batch pushes in lane order
-		if (nmat)
+		// ---- a bucket that outgrows its LDS region switches the document to the two-place accessors
 		{
-			const u32 slot = (sord + range) & 63u;
-			u64 same = matMask;
+			u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
-			for (int k=0; k<6; ++k)
+			for (int j=0; j<3; ++j) if (mat && (tInfo[ j] & FTI_INSTALL)) byteInc( c0, c1, c2, c3, (tInfo[ j] >> FTI_BUCKET_SHIFT) & 15u);
+			// upper bound without the scan: the batch adds at most nmat x 3 entries to a bucket
+			bool over = false, fail = false;
+			if (LANE < 16u)
 			{
-				const u64 bk = __ballot( mat && ((slot >> k) & 1u));
-				same &= ((slot >> k) & 1u) ? bk : ~bk;
+				const u32 sz = L.bsize[ LANE], cap = L.bmeta[ LANE] >> 16;
+				over = sz + 3*nmat > cap;
+				fail = sz + 3*nmat > cap + (u32)FAST_SPILL_BUCKET || sz + 3*nmat > 0xFFFu;
 			}
-			const u64 lower = same & lanesBelow();
-			const u32 prevLane = lower ? (63u - (u32)__builtin_clzll( lower)) : 0u;
-			const u32 prevRule = (u32)__builtin_amdgcn_ds_bpermute( (int)(prevLane << 2), (int)r);
-			if (mat)
+			if (__ballot( over))
 			{
-				const u32 nx = lower ? prevRule : (u32)w.win[ slot];
-				stNext( w, P, r, nx);
-			}
-			WAVE_FENCE();
-			if (mat && !(same >> LANE >> 1)) w.win[ slot] = (u16)r;	// the last lane of a position becomes its head
-		}
-		// ---- triggers: bucket positions in (program, template) order (cpp:1204-1250 -> EventTriggerTable::add :114-131)
-		u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-		u32 hB[ 3]; bool inst[ 3];
-#pragma unroll
-		for (int j=0; j<3; ++j)
-		{
-			hB[ j] = (tInfo[ j] >> FTI_BUCKET_SHIFT) & 15u;
-			inst[ j] = mat && (tInfo[ j] & FTI_INSTALL);
-			if (inst[ j]) byteInc( c0, c1, c2, c3, hB[ j]);
-		}
-		u32 tmask = 0;
-		if (__ballot( inst[ 0] || inst[ 1] || inst[ 2]))
-		{
-			u32 i0 = waveScanAdd( c0), i1 = waveScanAdd( c1), i2 = waveScanAdd( c2), i3 = waveScanAdd( c3);	// fields stay < 256 (64 x 3)
-			const u32 e0 = i0 - c0, e1 = i1 - c1, e2 = i2 - c2, e3 = i3 - c3;
-			const u32 t0 = (u32)__builtin_amdgcn_readlane( i0, 63), t1 = (u32)__builtin_amdgcn_readlane( i1, 63);
-			const u32 t2 = (u32)__builtin_amdgcn_readlane( i2, 63), t3 = (u32)__builtin_amdgcn_readlane( i3, 63);
-			u32 oldSize = 0, add = 0;
-			if (LANE < 16u) { oldSize = w.bsize[ LANE]; add = byteField( t0, t1, t2, t3, LANE); }
-			if (__ballot( oldSize + add > 0xFFFu)) { FALLBACK( FB_BUCKET_SIZE); return; }
-			reserveChunks( w, P, oldSize + add);
-			if (w.err) return;
-#pragma unroll
-			for (int j=0; j<3; ++j)
-			{
-				if (inst[ j])
+				// exact sizes
+				u32 i0 = waveScanAdd( c0), i1 = waveScanAdd( c1), i2 = waveScanAdd( c2), i3 = waveScanAdd( c3);
+				const u32 t0 = (u32)__builtin_amdgcn_readlane( i0, 63), t1 = (u32)__builtin_amdgcn_readlane( i1, 63);
+				const u32 t2 = (u32)__builtin_amdgcn_readlane( i2, 63), t3 = (u32)__builtin_amdgcn_readlane( i3, 63);
+				over = false; fail = false;
+				if (LANE < 16u)
 				{
-					const u32 h = hB[ j];
-					u32 sameB = 0;
-#pragma unroll
-					for (int jj=0; jj<j; ++jj) if (inst[ jj] && hB[ jj] == h) ++sameB;	// my own earlier templates
-					const u32 pos = w.bsize[ h] + byteField( e0, e1, e2, e3, h) + sameB;
-					const u32 sv = (tInfo[ j] & FTI_SIGVAL_MASK) | (((tInfo[ j] >> FTI_SIGTYPE_SHIFT) & FTI_SIGTYPE_MASK) << 4) | ((tInfo[ j] & FTI_HASVAR) ? 0x80u : 0u);
-					stEnt( w, P, entryIndex( w, h, pos), tEv[ j], (4*r + (u32)j) | (sv << 16) | ((tInfo[ j] >> FTI_VAR_SHIFT) << 24));
-					stLink( w, P, r, (u32)j, (h << 12) | pos);
-					tmask |= 1u << j;
+					const u32 sz = L.bsize[ LANE] + byteField( t0, t1, t2, t3, LANE), cap = L.bmeta[ LANE] >> 16;
+					over = sz > cap;
+					fail = sz > cap + (u32)FAST_SPILL_BUCKET || sz > 0xFFFu;
 				}
-			}
-			WAVE_FENCE();
-			if (LANE < 16u && add) w.bsize[ LANE] = oldSize + add;
-			{
-				const u32 s = t0 + t1 + t2 + t3;
-				w.nTrig += (s & 0xFFu) + ((s >> 8) & 0xFFu) + ((s >> 16) & 0xFFu) + (s >> 24);	// (all fields together count <= 64 x 3 installs: no carries)
+				if (__ballot( fail)) { FALLBACK( FB_BUCKET_SIZE); return; }
+				if (__ballot( over)) w.spill = 1;
 			}
 		}
-		// ---- the rule itself
-		if (mat)
-		{
-			u32 hw = value | (count << H_COUNT_SHIFT) | H_ACTIVE | (tmask << H_TMASK_SHIFT) | (nItems << H_NITEMS_SHIFT);
-			hw |= end ? ((end & 0xFFu) << H_END_SHIFT) : (u32)H_ENDZERO;
-			if (done) hw |= H_DONE;
-			if (hasStart) hw |= H_HASSTART;
-			stHot( w, P, r, hw);
-			u32* cold = &w.sp[ P.spill.oCold + 8*r];
-			st4( cold, handle, fmt, startLex, it0);
-			*(uint2*)(cold + 4) = make_uint2( it1, it2);
-		}
-		// ---- results (cpp:954-965), in lane order; items latest first
-		{
-			const bool emit = have && resultNow && handle != 0;
-			const u64 rm = __ballot( emit);
-			if (rm)
-			{
-				const u32 nr = (u32)__popcll( rm);
-				if (w.nStaged + nr > P.spill.maxStaged) { FALLBACK( FB_STAGED); return; }
-				if (emit)
-				{
-					const u32 ia = nItems == 3 ? it2 : nItems == 2 ? it1 : it0;		// items latest first
-					const u32 ib = nItems == 3 ? it1 : it0;
-					const u32 ic = it0;
-					const u32 vars = nItems == 0 ? 0u : nItems == 1 ? (ia >> 24) : nItems == 2 ? ((ia >> 24) | ((ib >> 24) << 8)) : ((ia >> 24) | ((ib >> 24) << 8) | ((ic >> 24) << 16));
-					const u32 o0 = ia & 0xFFFFFFu, o1 = ib & 0xFFFFFFu, o2 = ic & 0xFFFFFFu;
-					stageResult( w, P, w.nStaged + (u32)__popcll( rm & lanesBelow()), handle, fmt, startLex, w.lbase, nItems, vars, o0, o1, o2);
-				}
-				w.nStaged += nr;
-				u32 incl = waveScanAdd( emit ? nItems : 0u);
-				w.nStagedItems += (u32)__builtin_amdgcn_readlane( incl, 63);
-			}
-		}
-		// ---- rules that finished or were deleted by their own key event: deactivated after the installs (cpp:1030-1034)
-		{
-			const bool wantDispose = mat && (del || fin);
-			const u64 dm = __ballot( wantDispose);
-			if (dm)
-			{
-				const u32 nd = (u32)__popcll( dm);
-				if (w.nDispose + nd > P.spill.maxRules) { FALLBACK( FB_DISPOSE); return; }
-				if (wantDispose) stList( w, P, w.nDispose + (u32)__popcll( dm & lanesBelow()), r);
-				w.nDispose += nd;
-			}
-		}
-		WAVE_FENCE();
+		if (w.spill) installBatchT<true>( L, w, P, kb, nb, sord, matMask, r, q0, q1, q2, sim);
+		else installBatchT<false>( L, w, P, kb, nb, sord, matMask, r, q0, q1, q2, sim);
 	}
 }
 
-} // anonymous namespace
+// ---------------------------------------------------------------- doTransition (cpp:981-1064) for an input term
+template <bool SP>
+static __device__ __forceinline__ void scanAndFire( LR L, Wave& w, KP P, u32 id, u32 ordpos)
+{
+	// fire the triggers waiting for this event: 64 bucket entries per step, one ballot
+	const u32 h = evhash( id) & 15u;
+	const u32 n = bcast0( L.bsize[ h]);
+	const u32 meta = bcast0( L.bmeta[ h]);
+	for (u32 base=0; base<n && !w.err; base+=64)
+	{
+		const u32 i = base + LANE;
+		u32 e = 0;
+		if (i < n) e = ldEv<SP>( L, w, P, h, meta, i);
+		u64 m = __ballot( i < n && e == id);
+		while (m && !w.err)
+		{
+			const u32 p = (u32)__builtin_ctzll( m);
+			m &= m-1;
+			const u32 tsv = bcast0( ldTs<SP>( L, w, P, h, meta, base + p));
+			fireSignal<SP>( L, w, P, tsv, ordpos);
+		}
+	}
+}
 
-// ================================================================== kernel
-extern "C" __global__ __launch_bounds__(64)
-void spa_l2_fast_kernel( FastParams kernelArgs)
+static __device__ __forceinline__ void runKernel()
 {
 	KP P = kernelParams();
-	extern __shared__ __attribute__((aligned(16))) u32 ldsRaw[];
-	LDSQ u8* lb = (LDSQ u8*)ldsRaw;
+	__shared__ Lds ldsDoc;
+	LR L = *(__attribute__((address_space(3))) Lds*)&ldsDoc;
 	Wave w;
-	w.sc = (lu32*)(lb + P.lds.oScalars); w.hot = (lu32*)(lb + P.lds.oHot);
-	w.link = (lu16*)(lb + P.lds.oLink); w.next = (lu16*)(lb + P.lds.oNext); w.freeS = (lu16*)(lb + P.lds.oFree);
-	w.ev = (lu32*)(lb + P.lds.oEv); w.ts = (lu32*)(lb + P.lds.oTs); w.ctab = (lu8*)(lb + P.lds.oChunkTab); w.cfree = (lu8*)(lb + P.lds.oChunkFree);
-	w.bsize = (lu32*)(lb + P.lds.oBSize); w.bchunks = (lu32*)(lb + P.lds.oBChunks); w.win = (lu16*)(lb + P.lds.oWin);
-	w.stop = (lu32*)(lb + P.lds.oStop); w.list = (lu16*)(lb + P.lds.oList);
 	w.sp = P.spillBase + (u64)blockIdx.x * P.spill.totalWords;
-	w.R = P.lds.R; w.T = P.lds.T;
 	const u32 ndocs = P.ndocs;
 	const u32 waveSlot = blockIdx.x, nWaveSlots = gridDim.x;
 
@@ -731,12 +811,12 @@ void spa_l2_fast_kernel( FastParams kernelArgs)
 		}
 		if (doc >= ndocs) break;
 		// per-document reset
-		if (LANE < 16u) { w.bsize[ LANE] = 0; w.bchunks[ LANE] = 0; }
-		w.win[ LANE] = (u16)NIL16;
-		for (u32 s=LANE; s<P.nofStopWords; s+=64) w.stop[ 3*s+2] = 0;
+		if (LANE < 16u) { L.bsize[ LANE] = 0; L.bmeta[ LANE] = P.bucketMeta[ LANE]; }
+		L.win[ LANE] = (u16)NIL16;
+		for (u32 s=LANE; s<P.nofStopWords; s+=64) L.stop[ 3*s+2] = 0;
 		w.curpos = 0; w.timestamp = 0; w.nInstalled = 0; w.nAlt = 0; w.nSignals = 0; w.nTrig = 0; w.openLo = 0; w.openHi = 0;
-		w.freeN = 0; w.usedL = 0; w.sFreeN = 0; w.usedS = 0; w.cFreeN = 0; w.cUsed = 0;
-		w.nDispose = 0; w.nStaged = 0; w.nStagedItems = 0; w.err = 0; w.lbase = 0; w.why = 0;
+		w.freeN = 0; w.usedL = 0; w.sFreeN = 0; w.usedS = 0;
+		w.nDispose = 0; w.nStaged = 0; w.nStagedItems = 0; w.err = 0; w.lbase = 0; w.why = 0; w.spill = 0;
 #ifdef SPA_PROF
 		for (int pi=0; pi<12; ++pi) w.prof[ pi] = 0;
 #endif
@@ -781,7 +861,9 @@ void spa_l2_fast_kernel( FastParams kernelArgs)
 				}
 			}
 			const u32 cnt = (lend - tile) < 64 ? (u32)(lend - tile) : 64u;
+#ifdef SPA_PROF
 			if (__ballot( kBegin == 0xFFFFFFFFu)) break;	// (the probes complete here)
+#endif
 			PROF_ADD( 5);
 			for (u32 k=0; k<cnt && !w.err; ++k)
 			{
@@ -790,7 +872,7 @@ void spa_l2_fast_kernel( FastParams kernelArgs)
 				const u32 origseg = __builtin_amdgcn_readlane( seg, k);
 				// PatternMatcherContext::putInput (patternMatcher.cpp:131-162)
 				if (curPosition > ordpos) { w.err = SPD_ERR_ORDER; break; }
-				else if (curPosition < ordpos) { curPosition = ordpos; setCurrentPos( w, P, ordpos); PROF_ADD( 3); if (w.err) break; }
+				else if (curPosition < ordpos) { curPosition = ordpos; setCurrentPos( L, w, P, ordpos); PROF_ADD( 3); if (w.err) break; }
 				else if (origsize >= 0x7FFFFFFFu || origseg >= 0x7FFFFFFFu || origpos >= 0x7FFFFFFFu) { w.err = SPD_ERR_RANGE; break; }
 				if (id >= (1u<<29)) { w.err = SPD_ERR_RANGE; break; }
 				w.lbase = (u32)(tile - lbeg) + k;
@@ -803,38 +885,25 @@ void spa_l2_fast_kernel( FastParams kernelArgs)
 				w.nDispose = 0;
 				if (id)
 				{
-					// fire the triggers waiting for this event: 64 bucket entries per step, one ballot
-					const u32 h = evhash( id) & 15u;
-					const u32 n = ldu( &w.bsize[ h]);
-					for (u32 base=0; base<n && !w.err; base+=64)
-					{
-						const u32 i = base + LANE;
-						u32 idx = 0, e = 0;
-						if (i < n) { idx = entryIndex( w, h, i); e = ldEv( w, P, idx); }
-						u64 m = __ballot( i < n && e == id);
-						while (m && !w.err)
-						{
-							const u32 p = (u32)__builtin_ctzll( m);
-							m &= m-1;
-							const u32 ip = (u32)__builtin_amdgcn_readlane( idx, p);
-							const u32 tsv = bcast0( ldTs( w, P, ip));
-							fireSignal( w, P, tsv, ordpos);
-						}
-					}
+					if (w.spill) scanAndFire<true>( L, w, P, id, ordpos); else scanAndFire<false>( L, w, P, id, ordpos);
 				}
 				PROF_ADD( 0);
 				if (w.err) break;
 				// install the programs keyed by this event
 				const u32 kb = __builtin_amdgcn_readlane( kBegin, k), kc = __builtin_amdgcn_readlane( kCount, k);
 				const u32 stopIdx = __builtin_amdgcn_readlane( kStop, k);
-				if (kc) installBatch( w, P, kb, kc, ordpos);
+				if (kc) installBatch( L, w, P, kb, kc, ordpos);
 				PROF_ADD( 1);
 				if (w.err) break;
 				// deactivate rules that finished or were deleted
-				if (w.nDispose) { WAVE_FENCE(); deactivateList( w, P, w.nDispose, false, true); }
+				if (w.nDispose)
+				{
+					WAVE_FENCE();
+					if (w.spill) deactivateList<true>( L, w, P, w.nDispose, false, true); else deactivateList<false>( L, w, P, w.nDispose, false, true);
+				}
 				if (stopIdx)
 				{
-					if (LANE == 0) { w.stop[ 3*(stopIdx-1)] = w.lbase; w.stop[ 3*(stopIdx-1)+1] = ordpos; w.stop[ 3*(stopIdx-1)+2] = w.timestamp + 1u; }
+					if (LANE == 0) { L.stop[ 3*(stopIdx-1)] = w.lbase; L.stop[ 3*(stopIdx-1)+1] = ordpos; L.stop[ 3*(stopIdx-1)+2] = w.timestamp + 1u; }
 					w.timestamp += 1;
 					WAVE_FENCE();
 				}
@@ -927,19 +996,41 @@ void spa_l2_fast_kernel( FastParams kernelArgs)
 		}
 	}
 }
+}; // Engine
+
+} // anonymous namespace
+
+// ================================================================== kernel instances (LDS capacities: rules, bucket entries)
+#define SPA_FAST_INSTANCE( NAME, RR, TT) \
+	extern "C" __global__ __launch_bounds__(64) void NAME( FastParams kernelArgs) { Engine<RR,TT>::runKernel(); }
+SPA_FAST_INSTANCE( spa_l2_fast_kernel_s, 192, 320)
+SPA_FAST_INSTANCE( spa_l2_fast_kernel_m, 320, 512)
+SPA_FAST_INSTANCE( spa_l2_fast_kernel_l, 512, 1024)
+SPA_FAST_INSTANCE( spa_l2_fast_kernel_t, 8, 128)		// tests: everything beyond a handful of rules runs through the spill area
 
 namespace spa {
-// resident single-wave workgroups per CU for a given LDS slice (registers and LDS both limit it)
-int fastBlocksPerCU( unsigned ldsBytes)
+static const void* fastInstance( unsigned variant)
+{
+	return variant == 0 ? (const void*)spa_l2_fast_kernel_s : variant == 1 ? (const void*)spa_l2_fast_kernel_m : variant == 2 ? (const void*)spa_l2_fast_kernel_l : (const void*)spa_l2_fast_kernel_t;
+}
+void fastCapacities( unsigned variant, uint32_t& R, uint32_t& T)
+{
+	if (variant == 0) { R = 192; T = 320; } else if (variant == 1) { R = 320; T = 512; } else if (variant == 2) { R = 512; T = 1024; } else { R = 8; T = 128; }
+}
+// resident single-wave workgroups per CU of a kernel instance (registers and LDS both limit it)
+int fastBlocksPerCU( unsigned variant)
 {
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor( &n, spa_l2_fast_kernel, 64, ldsBytes) != hipSuccess || n < 1) n = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor( &n, fastInstance( variant), 64, 0) != hipSuccess || n < 1) n = 1;
 	if (n > 32) n = 32;
 	return n;
 }
-hipError_t launchL2Fast( const FastParams& P, unsigned nblocks, hipStream_t stream)
+hipError_t launchL2Fast( const FastParams& P, unsigned variant, unsigned nblocks, hipStream_t stream)
 {
-	hipLaunchKernelGGL( spa_l2_fast_kernel, dim3( nblocks), dim3( 64), P.lds.totalBytes, stream, P);
+	if (variant == 0) hipLaunchKernelGGL( spa_l2_fast_kernel_s, dim3( nblocks), dim3( 64), 0, stream, P);
+	else if (variant == 1) hipLaunchKernelGGL( spa_l2_fast_kernel_m, dim3( nblocks), dim3( 64), 0, stream, P);
+	else if (variant == 2) hipLaunchKernelGGL( spa_l2_fast_kernel_l, dim3( nblocks), dim3( 64), 0, stream, P);
+	else hipLaunchKernelGGL( spa_l2_fast_kernel_t, dim3( nblocks), dim3( 64), 0, stream, P);
 	return hipGetLastError();
 }
 }

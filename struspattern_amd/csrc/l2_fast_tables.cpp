@@ -15,7 +15,7 @@ static_assert( sizeof(FastKeyEntry) == sizeof(DevKeyEntry), "the fast kernel rea
 std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out)
 {
 	out.clear();
-	if (ft.nofStopWords > 128) return "more than 128 stop words";
+	if (ft.nofStopWords > FAST_MAXSTOP) return "more than 64 stop words";
 	if (ft.keylist.size() >= (1u<<24)) return "more than 2^24 key list entries";
 	// events somebody waits for or is keyed by
 	std::set<uint32_t> listened;
@@ -105,31 +105,33 @@ std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out
 	return std::string();
 }
 
-// LDS and spill layouts for the capacities (R rules, T bucket entries in LDS; maxRules in all)
-void layoutFast( FastLdsLayout& L, FastSpillLayout& S, uint32_t R, uint32_t T, uint32_t nofStopWords, uint32_t maxRules, uint32_t maxStaged)
+// Spill layout and the LDS regions of the 16 trigger buckets for the capacities of a kernel instance (R rules,
+// T bucket entries in LDS; maxRules rule ids in all).  A bucket's share of T follows the number of trigger
+// templates the rule set can install into it (the bucket of the structure delimiter holds a Del trigger of
+// every *_struct rule instance); what does not fit spills per bucket.
+void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], const std::vector<FastKeyInst>& keyinst, uint32_t R, uint32_t T, uint32_t maxRules, uint32_t maxStaged)
 {
-	T = (T + FAST_CHUNK-1) / FAST_CHUNK * FAST_CHUNK;
-	if (T > FAST_MAXCHUNKS*FAST_CHUNK) T = FAST_MAXCHUNKS*FAST_CHUNK;
-	if (R > maxRules) R = maxRules;
-	uint32_t o = 0;
-	auto take = [&]( uint32_t bytes) { uint32_t at = o; o += (bytes + 15u) & ~15u; return at; };
-	L.R = R; L.T = T;
-	L.oScalars = take( 32*4);
-	L.oBSize = take( 16*4);
-	L.oBChunks = take( 16*4);
-	L.oWin = take( 64*2);
-	L.oHot = take( R*4);
-	L.oLink = take( 3*R*2);
-	L.oNext = take( R*2);
-	L.oFree = take( R*2);
-	L.oEv = take( T*4);
-	L.oTs = take( T*4);
-	L.oChunkTab = take( 16*FAST_BUCKET_CHUNKS);
-	L.oChunkFree = take( FAST_MAXCHUNKS);
-	L.oStop = take( (nofStopWords ? nofStopWords : 1)*12);
-	L.oList = take( FAST_LISTCAP*2);
-	L.totalBytes = o;
-
+	if (maxRules < R) maxRules = R;
+	uint64_t weight[ 16], total = 0;
+	for (int b=0; b<16; ++b) weight[ b] = 1;
+	for (size_t i=0; i<keyinst.size(); ++i)
+	{
+		for (int j=0; j<3; ++j)
+		{
+			const uint32_t info = keyinst[ i].trig[ j].info;
+			if (info & FTI_INSTALL) weight[ (info >> FTI_BUCKET_SHIFT) & 15u] += 1;
+		}
+	}
+	for (int b=0; b<16; ++b) total += weight[ b];
+	const uint32_t floorCap = 8;
+	uint32_t base = 0;
+	for (int b=0; b<16; ++b)
+	{
+		uint32_t cap = floorCap + (uint32_t)((uint64_t)(T - 16*floorCap) * weight[ b] / total);
+		if (cap > 0xFFFu) cap = 0xFFFu;
+		bucketMeta[ b] = base | (cap << 16);
+		base += cap;
+	}
 	uint32_t w = 0;
 	auto takeW = [&]( uint32_t words) { uint32_t at = w; w += (words + 3u) & ~3u; return at; };
 	const uint32_t spillRules = maxRules - R;
@@ -137,10 +139,10 @@ void layoutFast( FastLdsLayout& L, FastSpillLayout& S, uint32_t R, uint32_t T, u
 	S.oCold = takeW( 8*maxRules);
 	S.oHot = takeW( spillRules); S.oLink = takeW( 3*spillRules); S.oNext = takeW( spillRules);
 	S.oFree = takeW( spillRules);
-	S.oEnt = takeW( 2*(FAST_MAXCHUNKS*FAST_CHUNK - T));
+	S.oEnt = takeW( 2*16*FAST_SPILL_BUCKET);
 	S.maxStaged = maxStaged;
 	S.oStaged = takeW( 8*maxStaged);
-	S.oList = takeW( maxRules);
+	S.oList = takeW( maxRules > FAST_LISTCAP ? maxRules : FAST_LISTCAP);
 	S.totalWords = (w + 63u) & ~63u;
 }
 

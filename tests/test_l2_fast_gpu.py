@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 
 CONFIGS = {
     "default": {},
-    "spill": {"SPA_L2_FAST_R": "8", "SPA_L2_FAST_T": "16"},
-    "handover": {"SPA_L2_FAST_R": "8", "SPA_L2_FAST_T": "16", "SPA_L2_FAST_MAXRULES": "24", "SPA_L2_FAST_MAXSTAGED": "40"},
+    "spill": {"SPA_L2_FAST_SIZE": "t"},
+    "handover": {"SPA_L2_FAST_SIZE": "t", "SPA_L2_FAST_MAXRULES": "24", "SPA_L2_FAST_MAXSTAGED": "40"},
     "general": {"SPA_L2_FAST": "0"},
 }
 
