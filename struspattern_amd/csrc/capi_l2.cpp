@@ -21,7 +21,7 @@ hipError_t launchL2Fast( const FastParams& P, unsigned variant, unsigned nblocks
 int fastBlocksPerCU( unsigned variant);
 void fastCapacities( unsigned variant, uint32_t& R, uint32_t& T);
 std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out);
-void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], const std::vector<FastKeyInst>& keyinst, uint32_t R, uint32_t T, uint32_t maxRules, uint32_t maxStaged);
+void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], uint32_t& expShift, const std::vector<FastKeyInst>& keyinst, uint32_t R, uint32_t T, uint32_t maxRules, uint32_t maxStaged);
 }
 
 using namespace spa;
@@ -96,7 +96,7 @@ struct sp_matcher_ctx
 	std::string whyNotFast;
 	DeviceBuffer dKeyinst, dSpill, dFallbackList;
 	std::vector<FastKeyInst> fastKeyinst;
-	FastSpillLayout fastSpill; uint32_t fastBucketMeta[ 16];
+	FastSpillLayout fastSpill; uint32_t fastBucketMeta[ 16]; uint32_t fastExpShift;
 	unsigned fastWaves, fastBlocksPerCU, fastVariant;	// variant: kernel instance = LDS capacities (l2_fast_kernel.hip)
 	uint32_t fastMaxRules, fastMaxStaged;
 	// working memory
@@ -602,7 +602,7 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		// general kernel in list mode right behind it on the same stream (an empty list costs one short launch)
 		uint32_t fR = 0, fT = 0;
 		fastCapacities( c->fastVariant, fR, fT);
-		layoutFast( c->fastSpill, c->fastBucketMeta, c->fastKeyinst, fR, fT, c->fastMaxRules, c->fastMaxStaged);
+		layoutFast( c->fastSpill, c->fastBucketMeta, c->fastExpShift, c->fastKeyinst, fR, fT, c->fastMaxRules, c->fastMaxStaged);
 		if (!c->fastBlocksPerCU) c->fastBlocksPerCU = (unsigned)fastBlocksPerCU( c->fastVariant);
 		size_t fslots = (size_t)c->numCUs * c->fastBlocksPerCU;
 		unsigned fblocks = (unsigned)(ndocs < fslots ? ndocs : fslots);
@@ -621,7 +621,7 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		F.keymask = c->keymask; F.nofStopWords = c->nofStopWords;
 		F.lexems = P.lexems; F.origseg = P.origseg; F.docOffsets = P.docOffsets; F.docRangesIn = P.docRangesIn;
 		F.ndocs = P.ndocs; F.withItems = P.withItems;
-		std::memcpy( F.bucketMeta, c->fastBucketMeta, sizeof(F.bucketMeta));
+		std::memcpy( F.bucketMeta, c->fastBucketMeta, sizeof(F.bucketMeta)); F.expShift = c->fastExpShift;
 		F.spill = c->fastSpill; F.spillBase = (uint32_t*)c->dSpill.ptr;
 		F.docCursor = (uint32_t*)c->dCursor.ptr;
 		F.counters = P.counters; F.results = P.results; F.resultCapacity = P.resultCapacity; F.items = P.items; F.itemCapacity = P.itemCapacity;

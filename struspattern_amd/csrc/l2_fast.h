@@ -51,19 +51,20 @@ struct FastKeyEntry			// 16 B
 // instance per capacity pair.  R = rule instances whose hot state is in LDS, T = trigger-bucket entries in LDS.
 // Rule ids >= R and bucket positions beyond a bucket's LDS region live in the wave's spill area in HBM, so a
 // burst (a frequent word that keys hundreds of programs) slows a document down instead of failing it.
-enum {FAST_LISTCAP=512 /* >= R of every instance */, FAST_MAXSTOP=64, FAST_SPILL_BUCKET=1024, FAST_VARIANTS=4};
+enum {FAST_LISTCAP=128, FAST_EXPCAP=1024, FAST_MAXSTOP=64, FAST_SPILL_BUCKET=1024, FAST_VARIANTS=4};
 
 struct FastSpillLayout			// per-wave spill + cold area in HBM, offsets in u32 words
 {
 	uint32_t maxRules;		// total rule ids (LDS + spill), <= 4096
 	uint32_t oCold;			// u32[8*maxRules]  {resultHandle, formatHandle, first taken lexem, item0, item1, item2, -, -}, item = lexem | variable<<24:
 					// written when the rule is installed / takes an event, read when it matches after its installation
-	uint32_t oHot, oLink, oNext;	// spill rules (ids R..maxRules): same shapes as in LDS (u32 per element here)
+	uint32_t oHot, oLink;	// spill rules (ids R..maxRules): same shapes as in LDS (u32 per element here)
 	uint32_t oFree;			// u32[maxRules]  stack of free spill ids
 	uint32_t oEnt;			// {event, ts} per spill bucket entry: 16 rows of FAST_SPILL_BUCKET
 	uint32_t oStaged;		// staged results, 8 words each
 	uint32_t maxStaged;
-	uint32_t oList;			// u32[maxRules] long dispose / expiry lists
+	uint32_t oList;			// u32[maxRules] long dispose lists
+	uint32_t oExp;			// u32[W][maxRules] expiry rows beyond their LDS part (W = 1 << expShift)
 	uint32_t totalWords;
 };
 
@@ -84,6 +85,7 @@ struct FastParams
 	uint32_t ndocs;
 	uint32_t withItems;
 	// working memory
+	uint32_t expShift;		// W = 1 << expShift expiry rows: the smallest power of two above the largest position range
 	uint32_t bucketMeta[ 16];	// LDS region of each trigger bucket: first entry | capacity << 16 (sized from the rule set)
 	FastSpillLayout spill;
 	uint32_t* spillBase;		// per wave: spill.totalWords

@@ -197,16 +197,15 @@ template <int R, int T>
 struct LdsDoc
 {
 	u32 hot[ R];			// rule word
-	u32 ev[ T];			// bucket entries: event id (bucket h owns [base_h, base_h + cap_h))
-	u32 ts[ T];			// bucket entries: trigger id (rule<<2 | slot) | signal byte << 16 | variable << 24
+	u64 ent[ T];			// bucket entries: event id | (trigger id (rule<<2 | slot) | signal byte << 16 | variable << 24) << 32; bucket h owns [base_h, base_h + cap_h)
 	u32 bsize[ 16];			// bucket sizes
 	u32 bmeta[ 16];			// base_h | cap_h << 16
 	u32 stop[ 3*FAST_MAXSTOP];	// stop-word log {lexem index, ordpos, timestamp}
 	u16 link[ 3*R];			// bucket << 12 | position of trigger slot j of rule r at [3r+j]
-	u16 next[ R];			// next rule in the expiry list of its position
 	u16 freeS[ R];			// stack of free rule ids < R
-	u16 win[ 64];			// heads of the expiry lists
-	u16 list[ FAST_LISTCAP];	// rules to deactivate (dispose list / expiry list)
+	u16 exp[ FAST_EXPCAP];		// expiry lists: row (position & (W-1)) holds the rules that expire at that position, in definition order
+	u16 expCnt[ 64];		// their lengths
+	u16 list[ FAST_LISTCAP];	// dispose list of the current transition
 };
 
 // per-document scalars (wave-uniform registers)
@@ -235,19 +234,23 @@ template <bool SP> static __device__ __forceinline__ u32 ldHot( LR L, const Wave
 template <bool SP> static __device__ __forceinline__ void stHot( LR L, const Wave& w, KP P, u32 r, u32 v) { if (!SP || r < (u32)R) L.hot[ r] = v; else w.sp[ P.spill.oHot + (r - R)] = v; }
 template <bool SP> static __device__ __forceinline__ u32 ldLink( LR L, const Wave& w, KP P, u32 r, u32 j) { if (!SP || r < (u32)R) return (u32)L.link[ 3*r + j]; return w.sp[ P.spill.oLink + 3*(r - R) + j]; }
 template <bool SP> static __device__ __forceinline__ void stLink( LR L, const Wave& w, KP P, u32 r, u32 j, u32 v) { if (!SP || r < (u32)R) L.link[ 3*r + j] = (u16)v; else w.sp[ P.spill.oLink + 3*(r - R) + j] = v; }
-template <bool SP> static __device__ __forceinline__ u32 ldNext( LR L, const Wave& w, KP P, u32 r) { if (!SP || r < (u32)R) return (u32)L.next[ r]; return w.sp[ P.spill.oNext + (r - R)]; }
-template <bool SP> static __device__ __forceinline__ void stNext( LR L, const Wave& w, KP P, u32 r, u32 v) { if (!SP || r < (u32)R) L.next[ r] = (u16)v; else w.sp[ P.spill.oNext + (r - R)] = v; }
+// ---- expiry rows: entry i of row `row` sits in LDS while i < C = FAST_EXPCAP >> expShift, else in the row's spill part
+template <bool SP> static __device__ __forceinline__ u32 ldExp( LR L, const Wave& w, KP P, u32 row, u32 i)
+{ const u32 C = (u32)FAST_EXPCAP >> P.expShift; if (!SP || i < C) return (u32)L.exp[ row*C + i]; return w.sp[ P.spill.oExp + row*P.spill.maxRules + (i - C)]; }
+template <bool SP> static __device__ __forceinline__ void stExp( LR L, const Wave& w, KP P, u32 row, u32 i, u32 r)
+{ const u32 C = (u32)FAST_EXPCAP >> P.expShift; if (!SP || i < C) L.exp[ row*C + i] = (u16)r; else w.sp[ P.spill.oExp + row*P.spill.maxRules + (i - C)] = r; }
 // ---- bucket entries: position p of bucket h sits at base_h + p while p < cap_h, else in the bucket's spill row
 template <bool SP> static __device__ __forceinline__ u32 ldEv( LR L, const Wave& w, KP P, u32 h, u32 meta, u32 pos)
-{ if (!SP || pos < (meta >> 16)) return L.ev[ (meta & 0xFFFFu) + pos]; return w.sp[ P.spill.oEnt + 2*(h*FAST_SPILL_BUCKET + pos - (meta >> 16))]; }
-template <bool SP> static __device__ __forceinline__ u32 ldTs( LR L, const Wave& w, KP P, u32 h, u32 meta, u32 pos)
-{ if (!SP || pos < (meta >> 16)) return L.ts[ (meta & 0xFFFFu) + pos]; return w.sp[ P.spill.oEnt + 2*(h*FAST_SPILL_BUCKET + pos - (meta >> 16)) + 1]; }
+{ if (!SP || pos < (meta >> 16)) return (u32)L.ent[ (meta & 0xFFFFu) + pos]; return w.sp[ P.spill.oEnt + 2*(h*FAST_SPILL_BUCKET + pos - (meta >> 16))]; }
+template <bool SP> static __device__ __forceinline__ uint2 ldEnt( LR L, const Wave& w, KP P, u32 h, u32 meta, u32 pos)
+{ if (!SP || pos < (meta >> 16)) { const u64 v = L.ent[ (meta & 0xFFFFu) + pos]; return make_uint2( (u32)v, (u32)(v >> 32)); } return *(const uint2*)&w.sp[ P.spill.oEnt + 2*(h*FAST_SPILL_BUCKET + pos - (meta >> 16))]; }
+template <bool SP> static __device__ __forceinline__ u32 ldTs( LR L, const Wave& w, KP P, u32 h, u32 meta, u32 pos) { return ldEnt<SP>( L, w, P, h, meta, pos).y; }
 template <bool SP> static __device__ __forceinline__ void stEnt( LR L, const Wave& w, KP P, u32 h, u32 meta, u32 pos, u32 e, u32 t)
 {
-	if (!SP || pos < (meta >> 16)) { L.ev[ (meta & 0xFFFFu) + pos] = e; L.ts[ (meta & 0xFFFFu) + pos] = t; }
+	if (!SP || pos < (meta >> 16)) L.ent[ (meta & 0xFFFFu) + pos] = (u64)e | ((u64)t << 32);
 	else *(uint2*)&w.sp[ P.spill.oEnt + 2*(h*FAST_SPILL_BUCKET + pos - (meta >> 16))] = make_uint2( e, t);
 }
-// ---- the list of rules to deactivate: first FAST_LISTCAP entries in LDS, the rest in the spill area
+// ---- the dispose list: first FAST_LISTCAP entries in LDS, the rest in the spill area
 template <bool SP> static __device__ __forceinline__ u32 ldList( LR L, const Wave& w, KP P, u32 i) { if (!SP || i < (u32)FAST_LISTCAP) return (u32)L.list[ i]; return w.sp[ P.spill.oList + i]; }
 static __device__ __forceinline__ void pushList( LR L, Wave& w, KP P, u32 i, u32 r)	// uniform index, one lane stores
 {
@@ -363,20 +366,26 @@ static __device__ __forceinline__ void fireSignal( LR L, Wave& w, KP P, u32 tsv,
 }
 
 // ---------------------------------------------------------------- deactivation of a list of rules
-// deactivateRule (cpp:679-702) for list[0..n) in list order; freeIds: disposeRule (cpp:704-708).
+// deactivateRule (cpp:679-702) for n rules in list order; freeIds: disposeRule (cpp:704-708).  The list is the
+// dispose list of the transition (EXPROW = false) or, last defined first, the expiry row of a position.
 // The only order-dependent part is the swap-with-last removal of the rules' triggers from the 16 buckets:
-// removals in different buckets do not interact, inside a bucket they must run in list order (rule by
-// rule, a rule's triggers last installed first).  Every lane takes a rule; in each round a lane removes
-// its next trigger if no lane before it still has a trigger in the same bucket.
-template <bool SP>
-static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 n, bool freeIds, bool mayRepeat)
+// removals in different buckets do not interact, inside a bucket they must run in list order (rule by rule, a
+// rule's triggers last installed first).  Every lane takes a rule.  A prefix count per bucket gives every trigger
+// its rank among the batch's removals from its bucket; a bucket shrinks by one per removal, so a trigger's turn
+// has come exactly when its bucket has reached (size at the start - rank): no lane waits on anything but that.
+template <bool SP, bool EXPROW>
+static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 n, u32 row, bool freeIds, bool mayRepeat)
 {
 	for (u32 base=0; base<n && !w.err; base+=64)
 	{
 		const u32 nb = (n - base) < 64u ? (n - base) : 64u;
 		const bool have = LANE < nb;
 		u32 r = 0, hw = 0;
-		if (have) { r = ldList<SP>( L, w, P, base + LANE); hw = ldHot<SP>( L, w, P, r); }
+		if (have)
+		{
+			r = EXPROW ? ldExp<SP>( L, w, P, row, n - 1u - (base + LANE)) : ldList<SP>( L, w, P, base + LANE);
+			hw = ldHot<SP>( L, w, P, r);
+		}
 		bool act = have && (hw & H_ACTIVE);
 		if (mayRepeat && nb > 1)
 		{
@@ -389,52 +398,71 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 		}
 		u32 mask = act ? ((hw >> H_TMASK_SHIFT) & H_TMASK_MASK) : 0u;
 		if (act) stHot<SP>( L, w, P, r, hw & ~(H_ACTIVE | (H_TMASK_MASK << H_TMASK_SHIFT)));
-		// buckets of my triggers
-		u32 hj[ 3];
-#pragma unroll
-		for (int j=0; j<3; ++j) hj[ j] = ((mask >> j) & 1u) ? (ldLink<SP>( L, w, P, r, (u32)j) >> 12) : 16u;
-		u32 removed = 0;
-#ifdef SPA_PROF
-		const u64 prof_r0 = __builtin_amdgcn_s_memtime(); u32 prof_rounds = 0;
-#endif
-		for (u32 guard=0; guard<=3u*64u; ++guard)
+		if (__ballot( mask != 0))
 		{
-#ifdef SPA_PROF
-			++prof_rounds;
-#endif
-			if (!__ballot( mask != 0)) break;
-			// my next trigger: the highest remaining slot
-			const u32 j = mask ? (31u - (u32)__builtin_clz( mask)) : 0u;
-			const u32 h = mask ? (j == 2 ? hj[ 2] : j == 1 ? hj[ 1] : hj[ 0]) : 0u;
-			u32 pb = 0;
+			// my triggers in removal order (slot 2, 1, 0): bucket, and the bucket size at which each one's turn comes
+			u32 hj[ 3], turn[ 3], metaj[ 3];
+			u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
-			for (int q=0; q<3; ++q) if ((mask >> q) & 1u) pb |= 1u << hj[ q];
-			const u32 before = fromLaneBelow( waveScanOr( pb));
-			const bool go = mask != 0 && !((before >> h) & 1u);
-			if (go)
+			for (int j=2; j>=0; --j)
 			{
-				// cpp:133-152: the bucket's last entry moves into the hole
-				const u32 pos = ldLink<SP>( L, w, P, r, j) & 0xFFFu;
-				const u32 last = L.bsize[ h] - 1u;
-				if (pos != last)
-				{
-					const u32 meta = L.bmeta[ h];
-					const u32 me = ldEv<SP>( L, w, P, h, meta, last), mt = ldTs<SP>( L, w, P, h, meta, last);
-					stEnt<SP>( L, w, P, h, meta, pos, me, mt);
-					stLink<SP>( L, w, P, (mt & 0xFFFFu) >> 2, mt & 3u, (h << 12) | pos);
-				}
-				L.bsize[ h] = last;
-				mask &= ~(1u << j);
-				++removed;
+				hj[ j] = 16u; metaj[ j] = 0;
+				if ((mask >> j) & 1u) { hj[ j] = ldLink<SP>( L, w, P, r, (u32)j) >> 12; byteInc( c0, c1, c2, c3, hj[ j]); metaj[ j] = L.bmeta[ hj[ j]]; }
 			}
-			WAVE_FENCE();
-		}
+			const u32 e0 = waveScanAdd( c0) - c0, e1 = waveScanAdd( c1) - c1, e2 = waveScanAdd( c2) - c2, e3 = waveScanAdd( c3) - c3;	// (fields < 256: 64 x 3)
+#pragma unroll
+			for (int j=2; j>=0; --j)
+			{
+				turn[ j] = 0;
+				if ((mask >> j) & 1u)
+				{
+					u32 mineBefore = 0;
+#pragma unroll
+					for (int jj=2; jj>j; --jj) if (((mask >> jj) & 1u) && hj[ jj] == hj[ j]) ++mineBefore;
+					turn[ j] = L.bsize[ hj[ j]] - (byteField( e0, e1, e2, e3, hj[ j]) + mineBefore);
+				}
+			}
+			u32 removed = 0;
 #ifdef SPA_PROF
-		w.prof[ 7] += __builtin_amdgcn_s_memtime() - prof_r0;
-		w.prof[ 8] += prof_rounds; w.prof[ 9] += 1; w.prof[ 10] += nb;
+			const u64 prof_r0 = __builtin_amdgcn_s_memtime(); u32 prof_rounds = 0;
 #endif
-		{
-			u32 incl = waveScanAdd( removed);
+			for (u32 guard=0; guard<=3u*64u && __ballot( mask != 0); ++guard)
+			{
+#ifdef SPA_PROF
+				++prof_rounds;
+#endif
+				// my next trigger: the highest remaining slot
+				const u32 j = mask ? (31u - (u32)__builtin_clz( mask)) : 0u;
+				const u32 h = j == 2 ? hj[ 2] : j == 1 ? hj[ 1] : hj[ 0];
+				const u32 myTurn = j == 2 ? turn[ 2] : j == 1 ? turn[ 1] : turn[ 0];
+				const u32 meta = j == 2 ? metaj[ 2] : j == 1 ? metaj[ 1] : metaj[ 0];
+				if (mask)
+				{
+					const u32 size = L.bsize[ h];
+					const u32 pos = ldLink<SP>( L, w, P, r, j) & 0xFFFu;	// (read beside the size: an earlier removal of this batch may have moved my trigger)
+					if (size == myTurn)
+					{
+						// cpp:133-152: the bucket's last entry moves into the hole
+						const u32 last = size - 1u;
+						if (pos != last)
+						{
+							const uint2 m = ldEnt<SP>( L, w, P, h, meta, last);
+							stEnt<SP>( L, w, P, h, meta, pos, m.x, m.y);
+							stLink<SP>( L, w, P, (m.y & 0xFFFFu) >> 2, m.y & 3u, (h << 12) | pos);
+						}
+						L.bsize[ h] = last;
+						mask &= ~(1u << j);
+						++removed;
+					}
+				}
+				WAVE_FENCE();
+			}
+#ifdef SPA_PROF
+			w.prof[ 7] += __builtin_amdgcn_s_memtime() - prof_r0;
+			w.prof[ 8] += prof_rounds; w.prof[ 9] += 1; w.prof[ 10] += nb;
+#endif
+			if (__ballot( mask != 0)) { w.err = SPD_ERR_INTERNAL; return; }
+			const u32 incl = waveScanAdd( removed);
 			w.nTrig -= (u32)__builtin_amdgcn_readlane( incl, 63);
 		}
 		if (freeIds)
@@ -454,40 +482,21 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 }
 
 // ---------------------------------------------------------------- expiry (cpp:1084-1135, window part: ranges are <= 63)
-template <bool SP>
-static __device__ __forceinline__ void expireSlot( LR L, Wave& w, KP P, u32 slot, u32 r)
-{
-	// the rules of this position, last defined first (the list is LIFO like the reference's)
-	u32 n = 0;
-#ifdef SPA_PROF
-	const u64 prof_w0 = __builtin_amdgcn_s_memtime();
-#endif
-	for (; r != (u32)NIL16; ++n)
-	{
-		if (n >= P.spill.maxRules) { w.err = SPD_ERR_INTERNAL; return; }
-		if (SP) pushList( L, w, P, n, r);
-		else if (LANE == 0) L.list[ n] = (u16)r;		// (a list beyond FAST_LISTCAP entries only forms in spill mode: R <= FAST_LISTCAP)
-		r = bcast0( ldNext<SP>( L, w, P, r));
-	}
-#ifdef SPA_PROF
-	w.prof[ 6] += __builtin_amdgcn_s_memtime() - prof_w0;
-#endif
-	if (LANE == 0) L.win[ slot] = (u16)NIL16;
-	WAVE_FENCE();
-	deactivateList<SP>( L, w, P, n, true, false);
-}
-
 static __device__ __forceinline__ void setCurrentPos( LR L, Wave& w, KP P, u32 pos)
 {
 	if (w.curpos == pos) return;
+	const u32 W = 1u << P.expShift;			// every live rule expires within the next W positions: one row per position
 	u32 wcnt = 0;
-	for (; wcnt < 64u && w.curpos < pos && !w.err; ++wcnt, ++w.curpos)
+	for (; wcnt < W && w.curpos < pos && !w.err; ++wcnt, ++w.curpos)
 	{
-		const u32 slot = w.curpos & 63u;
-		const u32 r = bcast0( (u32)L.win[ slot]);
-		if (r != (u32)NIL16)
+		const u32 row = w.curpos & (W-1u);
+		const u32 n = bcast0( (u32)L.expCnt[ row]);
+		if (n)
 		{
-			if (w.spill) expireSlot<true>( L, w, P, slot, r); else expireSlot<false>( L, w, P, slot, r);
+			// the rules of this position, last defined first (the reference's list is LIFO)
+			if (w.spill) deactivateList<true,true>( L, w, P, n, row, true, false); else deactivateList<false,true>( L, w, P, n, row, true, false);
+			if (LANE == 0) L.expCnt[ row] = 0;
+			WAVE_FENCE();
 		}
 	}
 	if (w.curpos < pos) w.curpos = pos;
@@ -496,6 +505,7 @@ static __device__ __forceinline__ void setCurrentPos( LR L, Wave& w, KP P, u32 p
 		// back to the LDS-only instance once nothing of the document is in the spill area any more
 		bool over = false;
 		if (LANE < 16u) over = L.bsize[ LANE] > (L.bmeta[ LANE] >> 16);
+		if ((u32)L.expCnt[ LANE] > ((u32)FAST_EXPCAP >> P.expShift)) over = true;
 		if (!__ballot( over) && w.sFreeN == w.usedS) { w.spill = 0; w.sFreeN = 0; w.usedS = 0; }
 	}
 }
@@ -519,27 +529,24 @@ static __device__ __forceinline__ void installBatchT( LR L, Wave& w, KP P, u32 k
 	const bool mat = (matMask >> LANE) & 1ull;
 	const u32 nmat = (u32)__popcll( matMask);
 	const u32 r = rIn;
-	// ---- expiry list of position sord+range (cpp:1066-1082): LIFO, the batch pushes in lane order
+	// ---- expiry row of position sord+range (cpp:1066-1082): appended in lane order (= definition order)
 	if (nmat)
 	{
-		const u32 slot = (sord + range) & 63u;
+		const u32 row = (sord + range) & ((1u << P.expShift) - 1u);
 		u64 same = matMask;
 #pragma unroll
 		for (int k=0; k<6; ++k)
 		{
-			const u64 bk = __ballot( mat && ((slot >> k) & 1u));
-			same &= ((slot >> k) & 1u) ? bk : ~bk;
+			const u64 bk = __ballot( mat && ((row >> k) & 1u));
+			same &= ((row >> k) & 1u) ? bk : ~bk;
 		}
-		const u64 lower = same & lanesBelow();
-		const u32 prevLane = lower ? (63u - (u32)__builtin_clzll( lower)) : 0u;
-		const u32 prevRule = (u32)__builtin_amdgcn_ds_bpermute( (int)(prevLane << 2), (int)r);
 		if (mat)
 		{
-			const u32 nx = lower ? prevRule : (u32)L.win[ slot];
-			stNext<SP>( L, w, P, r, nx);
+			const u32 cnt = (u32)L.expCnt[ row];
+			stExp<SP>( L, w, P, row, cnt + (u32)__popcll( same & lanesBelow()), r);
+			WAVE_FENCE();
+			if (!(same >> LANE >> 1)) L.expCnt[ row] = (u16)(cnt + (u32)__popcll( same));	// the last lane of a position closes its group
 		}
-		WAVE_FENCE();
-		if (mat && !(same >> LANE >> 1)) L.win[ slot] = (u16)r;	// the last lane of a position becomes its head
 	}
 	// ---- triggers: bucket positions in (program, template) order (cpp:1204-1250 -> EventTriggerTable::add :114-131)
 	u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -638,6 +645,8 @@ static __device__ __forceinline__ void installBatchT( LR L, Wave& w, KP P, u32 k
 
 static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb, u32 kc, u32 sord)
 {
+	// (requesting an event's install records one event ahead was measured: no gain -- the kernel is bound by the
+	// instructions it issues, not by this load)
 	for (u32 base=0; base<kc && !w.err; base+=64)
 	{
 		const u32 nb = (kc - base) < 64u ? (kc - base) : 64u;
@@ -731,7 +740,13 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 			}
 			w.freeN -= a; w.usedL += b;
 		}
-		// ---- a bucket that outgrows its LDS region switches the document to the two-place accessors
+		// ---- an expiry row or a bucket that outgrows its LDS region switches the document to the two-place accessors
+		if (nmat && !w.spill)
+		{
+			const u32 row = (sord + range) & ((1u << P.expShift) - 1u);
+			const bool over = mat && (u32)L.expCnt[ row] + nmat > ((u32)FAST_EXPCAP >> P.expShift);	// (upper bound: the whole batch in my row)
+			if (__ballot( over)) w.spill = 1;
+		}
 		{
 			u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
@@ -812,7 +827,7 @@ static __device__ __forceinline__ void runKernel()
 		if (doc >= ndocs) break;
 		// per-document reset
 		if (LANE < 16u) { L.bsize[ LANE] = 0; L.bmeta[ LANE] = P.bucketMeta[ LANE]; }
-		L.win[ LANE] = (u16)NIL16;
+		L.expCnt[ LANE] = 0;
 		for (u32 s=LANE; s<P.nofStopWords; s+=64) L.stop[ 3*s+2] = 0;
 		w.curpos = 0; w.timestamp = 0; w.nInstalled = 0; w.nAlt = 0; w.nSignals = 0; w.nTrig = 0; w.openLo = 0; w.openHi = 0;
 		w.freeN = 0; w.usedL = 0; w.sFreeN = 0; w.usedS = 0;
@@ -899,7 +914,7 @@ static __device__ __forceinline__ void runKernel()
 				if (w.nDispose)
 				{
 					WAVE_FENCE();
-					if (w.spill) deactivateList<true>( L, w, P, w.nDispose, false, true); else deactivateList<false>( L, w, P, w.nDispose, false, true);
+					if (w.spill) deactivateList<true,false>( L, w, P, w.nDispose, 0, false, true); else deactivateList<false,false>( L, w, P, w.nDispose, 0, false, true);
 				}
 				if (stopIdx)
 				{

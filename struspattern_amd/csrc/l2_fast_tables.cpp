@@ -109,8 +109,12 @@ std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out
 // T bucket entries in LDS; maxRules rule ids in all).  A bucket's share of T follows the number of trigger
 // templates the rule set can install into it (the bucket of the structure delimiter holds a Del trigger of
 // every *_struct rule instance); what does not fit spills per bucket.
-void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], const std::vector<FastKeyInst>& keyinst, uint32_t R, uint32_t T, uint32_t maxRules, uint32_t maxStaged)
+void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], uint32_t& expShift, const std::vector<FastKeyInst>& keyinst, uint32_t R, uint32_t T, uint32_t maxRules, uint32_t maxStaged)
 {
+	uint32_t maxRange = 0;
+	for (size_t i=0; i<keyinst.size(); ++i) { const uint32_t rg = (keyinst[ i].meta >> FKI_RANGE_SHIFT) & FKI_RANGE_MASK; if (rg > maxRange) maxRange = rg; }
+	expShift = 0;
+	while ((1u << expShift) < maxRange + 1u) ++expShift;		// one expiry row per position a live rule can expire at
 	if (maxRules < R) maxRules = R;
 	uint64_t weight[ 16], total = 0;
 	for (int b=0; b<16; ++b) weight[ b] = 1;
@@ -137,12 +141,13 @@ void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], const std::vector<
 	const uint32_t spillRules = maxRules - R;
 	S.maxRules = maxRules;
 	S.oCold = takeW( 8*maxRules);
-	S.oHot = takeW( spillRules); S.oLink = takeW( 3*spillRules); S.oNext = takeW( spillRules);
+	S.oHot = takeW( spillRules); S.oLink = takeW( 3*spillRules);
 	S.oFree = takeW( spillRules);
 	S.oEnt = takeW( 2*16*FAST_SPILL_BUCKET);
 	S.maxStaged = maxStaged;
 	S.oStaged = takeW( 8*maxStaged);
 	S.oList = takeW( maxRules > FAST_LISTCAP ? maxRules : FAST_LISTCAP);
+	S.oExp = takeW( (1u << expShift) * maxRules);
 	S.totalWords = (w + 63u) & ~63u;
 }
 
