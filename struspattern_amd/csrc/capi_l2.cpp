@@ -495,13 +495,17 @@ int sp_matcher_ctx_reserve_output( sp_matcher_ctx_t* c, uint64_t results, uint64
 namespace {
 
 // enqueue one batch on `stream`; all inputs are device pointers
+// `rerun` (host entry points): only these documents of the batch already in the output buffers run again, on the
+// general kernel in list mode with the working set the caller has just grown -- the results of the other
+// documents stay where they are
 void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg, const void* d_doc_offsets,
-		  size_t ndocs, size_t nlexems, hipStream_t stream, const void* d_doc_ranges=0)
+		  size_t ndocs, size_t nlexems, hipStream_t stream, const void* d_doc_ranges=0, const std::vector<uint32_t>* rerun=0)
 {
 	HIP_CHECK( hipSetDevice( c->device));
 	// geometry: one wave per workgroup; as many as keep every CU busy, never more waves than documents
 	size_t waveSlots = (size_t)c->numCUs*SPA_L2_WAVES_PER_CU;
-	unsigned wavesWanted = (unsigned)(ndocs < waveSlots ? ndocs : waveSlots);
+	const size_t ndocsToRun = rerun ? rerun->size() : ndocs;
+	unsigned wavesWanted = (unsigned)(ndocsToRun < waveSlots ? ndocsToRun : waveSlots);
 	unsigned nblocks = wavesWanted;		// workgroups are single waves
 	if (nblocks == 0) nblocks = 1;
 	unsigned nwaves = nblocks;
@@ -519,7 +523,7 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		size_t perWave = (size_t)c->arena.totalWords * sizeof(uint32_t);
 		size_t full = (size_t)c->numCUs*SPA_L2_WAVES_PER_CU;
 		if (full * perWave > ((size_t)48 << 30)) full = ((size_t)48 << 30) / perWave;
-		unsigned alloc = nwaves < full ? (unsigned)full : nwaves;	// allocate for the full machine once
+		unsigned alloc = (nwaves < full && !rerun) ? (unsigned)full : nwaves;	// allocate for the full machine once (a rerun of a few large documents: for those)
 		c->arenaWaves = 0;
 		c->dArena.alloc( (size_t)alloc * perWave);
 		c->arenaWaves = alloc;
@@ -554,7 +558,8 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	c->dDocStatus.reserve( (ndocs+1)*sizeof(int32_t));
 
 	HIP_CHECK( hipMemsetAsync( c->dCursor.ptr, 0, 256, stream));
-	HIP_CHECK( hipMemsetAsync( c->dCounters.ptr, 0, SPC_COUNT*sizeof(uint64_t), stream));
+	if (!rerun) HIP_CHECK( hipMemsetAsync( c->dCounters.ptr, 0, SPC_COUNT*sizeof(uint64_t), stream));
+	else HIP_CHECK( hipMemsetAsync( (uint64_t*)c->dCounters.ptr + SPC_FAILED, 0, sizeof(uint64_t), stream));	// (the other counters continue)
 
 	L2Params P;
 	std::memset( &P, 0, sizeof(P));
@@ -596,7 +601,18 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 	P.trace = (uint32_t*)traceDev;
 #endif
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
-	if (c->fast)
+	if (rerun)
+	{
+		const uint32_t n = (uint32_t)rerun->size();
+		c->dFallbackList.reserve( (ndocs+1)*sizeof(uint32_t));
+		HIP_CHECK( hipMemcpyAsync( c->dFallbackList.ptr, rerun->data(), n*sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+		HIP_CHECK( hipMemcpyAsync( (uint32_t*)c->dCursor.ptr + 2, &n, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+		HIP_CHECK( hipStreamSynchronize( stream));		// (the list and its count are host temporaries)
+		P.docList = (const uint32_t*)c->dFallbackList.ptr; P.docListCount = (const uint32_t*)c->dCursor.ptr + 2;
+		P.docCursor = (uint32_t*)c->dCursor.ptr + 1;
+		HIP_CHECK( launchL2Match( P, nblocks, stream));
+	}
+	else if (c->fast)
 	{
 		// flat rule set: the LDS-resident kernel first; the documents it hands over (fallbackList) go through the
 		// general kernel in list mode right behind it on the same stream (an empty list costs one short launch)
@@ -758,24 +774,31 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 			dseg = c->dOrigseg.ptr;
 		}
 		uint64_t counters[ SPC_COUNT];
+		std::vector<uint32_t> again;		// documents whose working set exceeded the per-wave arena: only they run again
 		for (int attempt=0;; ++attempt)
 		{
-			launchBatch( c, c->dLexems.ptr, dseg, c->dDocOffsets.ptr, ndocs, nlex, 0);
+			launchBatch( c, c->dLexems.ptr, dseg, c->dDocOffsets.ptr, ndocs, nlex, 0, 0, again.empty() ? 0 : &again);
 			HIP_CHECK( hipStreamSynchronize( 0));
 			HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
 			// the output counters keep counting past the capacity: if the buffers were too small,
 			// grow them to what this batch needs and run it again (the kernel is deterministic)
 			bool grow = false;
+			again.clear();
 			if (counters[ SPC_RESULTS] > c->resultCapacity) { c->minResultCapacity = counters[ SPC_RESULTS] + counters[ SPC_RESULTS]/8 + 1024; grow = true; }
 			if (counters[ SPC_ITEMS] > c->itemCapacity) { c->minItemCapacity = counters[ SPC_ITEMS] + counters[ SPC_ITEMS]/8 + 1024; grow = true; }
 			if (counters[ SPC_FAILED])
 			{
-				// documents whose working set exceeded the per-wave arena: double the arena and rerun
+				// documents whose working set exceeded the per-wave arena: double the arena and run THEM again
+				// (the whole batch only when the output buffers have to be reallocated as well)
 				std::vector<int32_t> st( ndocs);
 				HIP_CHECK( hipMemcpy( st.data(), c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
-				bool arena = false;
-				for (size_t di=0; di<ndocs && !arena; ++di) arena = (st[ di] == SPD_ERR_ARENA);
-				if (arena && sp_matcher_ctx_grow_arena( c) == SP_OK) grow = true;
+				std::vector<uint32_t> arenaDocs;
+				for (size_t di=0; di<ndocs; ++di) if (st[ di] == SPD_ERR_ARENA) arenaDocs.push_back( (uint32_t)di);
+				if (!arenaDocs.empty() && sp_matcher_ctx_grow_arena( c) == SP_OK)
+				{
+					if (!grow) again.swap( arenaDocs);
+					grow = true;
+				}
 			}
 			if (!grow || attempt >= 12) break;
 		}

@@ -1958,8 +1958,8 @@ void spa_l2_match_kernel( L2Params kernelArgs)
 			st[0] = w.refUsed; st[1] = w.ruleUsed; st[2] = w.nTrig; st[3] = w.itemUsed;	// high-water marks
 #endif
 			P.docStatus[ doc] = (int32_t)w.err;
-			atomicAdd( (unsigned long long*)&P.counters[ SPC_EVENTS], (unsigned long long)nEvents);
 			if (w.err) atomicAdd( (unsigned long long*)&P.counters[ SPC_FAILED], 1ull);
+			else atomicAdd( (unsigned long long*)&P.counters[ SPC_EVENTS], (unsigned long long)nEvents);	// (a failed document runs again: its events count then)
 #if defined(SPA_PROF) || defined(SPA_PROF2)
 			for (int pi=0; pi<4; ++pi) atomicAdd( (unsigned long long*)&P.counters[ 4+pi], (unsigned long long)w.raw->prof[ pi]);
 #endif
