@@ -133,6 +133,15 @@ size_t sp_matcher_dump_table(const sp_matcher_t* m, uint32_t** out);
  * Both kernels produce the reference's results (src/ruleMatcherAutomaton.cpp:772-1334); the choice is not observable. */
 int sp_matcher_fast_tier(const sp_matcher_t* m, char* why, size_t whysize);
 
+/* Compiled-table serialisation (the reference has none -- every process recompiles, and with
+ * Hyperscan that takes seconds for 10k patterns, src/patternLexer.cpp:1068-1118): the rule set with its key
+ * index, stop words, names, format strings and options as one self-checking blob (magic, version, FNV-1a 64),
+ * so that the ranks of a multi-GPU job or the workers of a service load it instead of compiling.  The blob is
+ * malloc'ed (sp_free); a loaded matcher behaves like the one that was saved (same tables word for word).
+ * sp_matcher_deserialize returns NULL and the reason in `err` for a blob that is truncated, corrupt or foreign. */
+int sp_matcher_serialize(const sp_matcher_t* m, void** blob, size_t* size);
+sp_matcher_t* sp_matcher_deserialize(const void* blob, size_t size, char* err, size_t errsize);
+
 /* ---- result format strings (definePattern's formatstring, src/patternMatcher.cpp:561-566, :172-181, :253-262).
  * The device does not build strings: it reports which format applies and what its arguments are.
  *   - a result with a format handle: its item list holds the ARGUMENTS of the format string; the
@@ -248,6 +257,10 @@ int sp_lexer_define_symbol(sp_lexer_t* l, uint32_t symbolid, uint32_t patternid,
 uint32_t sp_lexer_get_symbol(const sp_lexer_t* l, uint32_t patternid, const char* name);            /* :1020 */
 int sp_lexer_define_option(sp_lexer_t* l, const char* name, double value);                          /* :1031 */
 int sp_lexer_compile(sp_lexer_t* l);                                                                /* :1068 */
+/* compiled lexer (automaton tables, whole-word literal table, symbol tables, lexem names) as a blob and back; only a
+ * compiled lexer can be saved, a loaded one is compiled and frozen (see sp_matcher_serialize) */
+int sp_lexer_serialize(const sp_lexer_t* l, void** blob, size_t* size);
+sp_lexer_t* sp_lexer_deserialize(const void* blob, size_t size, char* err, size_t errsize);
 /* compiled automaton tables as a flat u64 array (test hook; layout in csrc/capi_l1.cpp) */
 size_t sp_lexer_dump_tables(const sp_lexer_t* l, uint64_t** out);
 

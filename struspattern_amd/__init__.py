@@ -207,14 +207,38 @@ class PatternMatcherContext:
         return self._L.sp_matcher_ctx_last_kernel_ms(self._h)
 
 
+def _serialize(L, fn, handle, err):
+    blob = ctypes.c_void_p()
+    size = ctypes.c_size_t()
+    if fn(handle, ctypes.byref(blob), ctypes.byref(size)) != 0:
+        raise PatternError("serialisation failed: " + err())
+    try:
+        return ctypes.string_at(blob, size.value)
+    finally:
+        L.sp_free(blob)
+
+
 class PatternMatcherInstance:
     """PatternMatcherInstanceInterface (src/patternMatcher.cpp:345-733)."""
 
-    def __init__(self):
+    def __init__(self, _handle=None):
         self._L = capi.lib()
-        self._h = self._L.sp_matcher_create()
+        self._h = _handle or self._L.sp_matcher_create()
         if not self._h:
             raise PatternError("failed to create pattern matcher instance")
+
+    def serialize(self):
+        """the rule set (tables, names, format strings, options) as bytes: SURVEY.md 8(f).4"""
+        return _serialize(self._L, self._L.sp_matcher_serialize, self._h, lambda: self._L.sp_matcher_last_error(self._h).decode())
+
+    @classmethod
+    def deserialize(cls, blob):
+        L = capi.lib()
+        err = ctypes.create_string_buffer(256)
+        h = L.sp_matcher_deserialize(blob, len(blob), err, 256)
+        if not h:
+            raise PatternError("cannot load the rule set: " + err.value.decode())
+        return cls(_handle=h)
 
     def __del__(self):
         try:
@@ -419,11 +443,24 @@ class PatternLexerContext:
 class PatternLexerInstance:
     """PatternLexerInstanceInterface (src/patternLexer.cpp:961-1151)."""
 
-    def __init__(self):
+    def __init__(self, _handle=None):
         self._L = capi.lib()
-        self._h = self._L.sp_lexer_create()
+        self._h = _handle or self._L.sp_lexer_create()
         if not self._h:
             raise PatternError("failed to create term match instance")
+
+    def serialize(self):
+        """the compiled lexer (automaton, literal and symbol tables, names) as bytes: SURVEY.md 8(f).4"""
+        return _serialize(self._L, self._L.sp_lexer_serialize, self._h, lambda: self._L.sp_lexer_last_error(self._h).decode(errors="replace"))
+
+    @classmethod
+    def deserialize(cls, blob):
+        L = capi.lib()
+        err = ctypes.create_string_buffer(256)
+        h = L.sp_lexer_deserialize(blob, len(blob), err, 256)
+        if not h:
+            raise PatternError("cannot load the lexer: " + err.value.decode())
+        return cls(_handle=h)
 
     def __del__(self):
         try:

@@ -80,6 +80,10 @@ SIGNATURES = {
     "sp_matcher_variable_name": (c_cp, [c_vp, c_u32]),
     "sp_matcher_dump_table": (ctypes.c_size_t, [c_vp, P(P(c_u32))]),
     "sp_matcher_fast_tier": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_size_t]),
+    "sp_matcher_serialize": (ctypes.c_int, [c_vp, P(c_vp), P(ctypes.c_size_t)]),
+    "sp_matcher_deserialize": (c_vp, [c_vp, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]),
+    "sp_lexer_serialize": (ctypes.c_int, [c_vp, P(c_vp), P(ctypes.c_size_t)]),
+    "sp_lexer_deserialize": (c_vp, [c_vp, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]),
     "sp_matcher_format_count": (c_u32, [c_vp]),
     "sp_matcher_format_string": (c_cp, [c_vp, c_u32]),
     "sp_matcher_ctx_fetch_formats": (ctypes.c_int, [c_vp, P(P(c_u32)), P(P(c_u32))]),

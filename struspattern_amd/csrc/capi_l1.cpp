@@ -62,6 +62,37 @@ const char* sp_lexer_last_error( const sp_lexer_t* l) { return l->lasterror.c_st
 
 #define LGUARD( CODE, BODY) return guardedCall1( l->lasterror, CODE, [&]{ BODY; })
 
+// the compiled lexer as a blob (automaton tables, literal and symbol tables, names) and back: SURVEY.md 8(f).4
+int sp_lexer_serialize( const sp_lexer_t* l, void** blob, size_t* size)
+{
+	*blob = 0; *size = 0;
+	return guardedCall1( l->lasterror, SP_ERR_INVALID, [&]{
+		std::vector<uint8_t> buf;
+		l->compiler.save( buf);
+		*blob = std::malloc( buf.size() ? buf.size() : 1);
+		if (!*blob) throw std::bad_alloc();
+		std::memcpy( *blob, buf.data(), buf.size());
+		*size = buf.size();
+	});
+}
+sp_lexer_t* sp_lexer_deserialize( const void* blob, size_t size, char* err, size_t errsize)
+{
+	sp_lexer* l = 0;
+	try
+	{
+		l = new sp_lexer();
+		l->compiler.load( blob, size);
+		return l;
+	}
+	catch (const std::exception& e)
+	{
+		if (err && errsize) { std::strncpy( err, e.what(), errsize-1); err[ errsize-1] = 0; }
+		delete l;
+		return 0;
+	}
+}
+
+
 int sp_lexer_define_lexem_name( sp_lexer_t* l, uint32_t id, const char* name)
 { LGUARD( SP_ERR_INVALID, l->compiler.defineLexemName( id, name ? name : "")); }
 const char* sp_lexer_get_lexem_name( const sp_lexer_t* l, uint32_t id) { return l->compiler.getLexemName( id); }

@@ -200,6 +200,36 @@ int sp_matcher_fast_tier( const sp_matcher_t* m, char* why, size_t whysize)
 	}
 }
 
+// the rule set as a blob (tables, names, format strings, options) and back: SURVEY.md 8(f).4
+int sp_matcher_serialize( const sp_matcher_t* m, void** blob, size_t* size)
+{
+	*blob = 0; *size = 0;
+	return guardedCall( m->lasterror, SP_ERR_INVALID, [&]{
+		std::vector<uint8_t> buf;
+		m->compiler.save( buf, m->compiled);
+		*blob = std::malloc( buf.size() ? buf.size() : 1);
+		if (!*blob) throw std::bad_alloc();
+		std::memcpy( *blob, buf.data(), buf.size());
+		*size = buf.size();
+	});
+}
+sp_matcher_t* sp_matcher_deserialize( const void* blob, size_t size, char* err, size_t errsize)
+{
+	sp_matcher* m = 0;
+	try
+	{
+		m = new sp_matcher();
+		m->compiled = m->compiler.load( blob, size);
+		return m;
+	}
+	catch (const std::exception& e)
+	{
+		if (err && errsize) { std::strncpy( err, e.what(), errsize-1); err[ errsize-1] = 0; }
+		delete m;
+		return 0;
+	}
+}
+
 size_t sp_matcher_dump_table( const sp_matcher_t* m, uint32_t** out)
 {
 	std::vector<uint32_t> buf = m->compiler.dump();

@@ -7,6 +7,7 @@
 // Reported semantics (what the reference obtains from Hyperscan with HS_FLAG_SOM_LEFTMOST|HS_FLAG_UTF8,
 // src/patternLexer.cpp:391-405): every end offset of a non-empty match once, with its leftmost start.
 #include "l1_compile.hpp"
+#include "serial.hpp"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -1133,5 +1134,77 @@ void LexCompiler::compile()
 		}
 		if (T.symbolText.empty()) T.symbolText.push_back( 0);
 	}
+	m_compiled = true;
+}
+
+// ---------------------------------------------------------------- compiled tables as a blob
+static const char L1_MAGIC[ 9] = "SPAL1v01";
+
+void LexCompiler::save( std::vector<uint8_t>& out) const
+{
+	if (!m_compiled) throw std::runtime_error( "only a compiled lexer can be serialised");
+	BlobWriter w( L1_MAGIC);
+	const LexTables& T = m_tables;
+	w.u32( m_options);
+	w.u32( T.nofPasses); w.u32( T.nofClasses); w.u32( T.maxExceptions); w.u32( T.nofLiterals); w.u32( T.nofPositions); w.u32( T.reportsOrdered ? 1u : 0u);
+	w.vec( T.byteClass); w.vec( T.classCtx); w.vec( T.charMask); w.vec( T.startMask); w.vec( T.acceptMask); w.vec( T.shiftDst); w.vec( T.selfLoop);
+	w.vec( T.exCount); w.vec( T.exSrc); w.vec( T.exDst); w.vec( T.wordPatBegin); w.vec( T.wordPats); w.vec( T.patOfBit);
+	w.vec( T.patterns); w.vec( T.symbols); w.vec( T.symbolText); w.vec( T.literals); w.vec( T.literalText); w.vec( T.litPats);
+	w.u32( (uint32_t)m_defs.size());
+	for (size_t i=0; i<m_defs.size(); ++i)
+	{
+		const Def& d = m_defs[ i];
+		w.str( d.expression); w.u32( d.id); w.u32( d.resultIndex); w.u32( d.level); w.u32( d.editdist); w.u32( (uint32_t)d.posbind);
+	}
+	w.u32( (uint32_t)m_symbols.size());
+	for (std::map<uint32_t, std::map<std::string,uint32_t> >::const_iterator ti=m_symbols.begin(); ti!=m_symbols.end(); ++ti)
+	{
+		w.u32( ti->first); w.u32( (uint32_t)ti->second.size());
+		for (std::map<std::string,uint32_t>::const_iterator si=ti->second.begin(); si!=ti->second.end(); ++si) { w.str( si->first); w.u32( si->second); }
+	}
+	w.u32( (uint32_t)m_names.size());
+	for (std::map<uint32_t,std::string>::const_iterator ni=m_names.begin(); ni!=m_names.end(); ++ni) { w.u32( ni->first); w.str( ni->second); }
+	out.swap( w.finish());
+}
+
+void LexCompiler::load( const void* blob, size_t size)
+{
+	BlobReader r( blob, size, L1_MAGIC);
+	LexTables T;
+	m_options = r.u32();
+	T.nofPasses = r.u32(); T.nofClasses = r.u32(); T.maxExceptions = r.u32(); T.nofLiterals = r.u32(); T.nofPositions = r.u32(); T.reportsOrdered = r.u32() != 0;
+	r.vec( T.byteClass); r.vec( T.classCtx); r.vec( T.charMask); r.vec( T.startMask); r.vec( T.acceptMask); r.vec( T.shiftDst); r.vec( T.selfLoop);
+	r.vec( T.exCount); r.vec( T.exSrc); r.vec( T.exDst); r.vec( T.wordPatBegin); r.vec( T.wordPats); r.vec( T.patOfBit);
+	r.vec( T.patterns); r.vec( T.symbols); r.vec( T.symbolText); r.vec( T.literals); r.vec( T.literalText); r.vec( T.litPats);
+	// the shapes the kernel indexes by must fit together (a blob of another build would fault on the device)
+	if (T.byteClass.size() != 256 || T.classCtx.size() != T.nofClasses
+	||  T.charMask.size() != (size_t)T.nofPasses*T.nofClasses*64 || T.startMask.size() != (size_t)T.nofPasses*CTX_COUNT*64 || T.acceptMask.size() != T.startMask.size()
+	||  T.shiftDst.size() != (size_t)T.nofPasses*64 || T.selfLoop.size() != T.shiftDst.size() || T.exCount.size() != T.nofPasses
+	||  T.exSrc.size() != (size_t)T.nofPasses*(T.maxExceptions ? T.maxExceptions : 1)*64 || T.exDst.size() != T.exSrc.size()
+	||  T.patOfBit.size() != (size_t)T.nofPasses*64*64
+	||  T.symbols.empty() || (T.symbols.size() & (T.symbols.size()-1)) || T.literals.empty() || (T.literals.size() & (T.literals.size()-1)))
+	{
+		throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	}
+	for (size_t i=0; i<T.byteClass.size(); ++i) if (T.byteClass[ i] >= T.nofClasses) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	m_defs.clear(); m_symbols.clear(); m_names.clear();
+	const uint32_t nd = r.u32();
+	for (uint32_t i=0; i<nd; ++i)
+	{
+		Def d; d.expression = r.str(); d.id = r.u32(); d.resultIndex = r.u32(); d.level = r.u32(); d.editdist = r.u32(); d.posbind = (int)r.u32();
+		m_defs.push_back( d);
+	}
+	if (T.patterns.size() != m_defs.size()) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	const uint32_t nt = r.u32();
+	for (uint32_t i=0; i<nt; ++i)
+	{
+		const uint32_t id = r.u32(), n = r.u32();
+		std::map<std::string,uint32_t>& tab = m_symbols[ id];
+		for (uint32_t k=0; k<n; ++k) { const std::string name = r.str(); tab[ name] = r.u32(); }
+	}
+	const uint32_t nn = r.u32();
+	for (uint32_t i=0; i<nn; ++i) { const uint32_t id = r.u32(); m_names[ id] = r.str(); }
+	if (!r.atEnd()) throw std::runtime_error( "compiled lexer blob has trailing data");
+	m_tables = T;
 	m_compiled = true;
 }

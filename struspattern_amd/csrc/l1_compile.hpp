@@ -59,6 +59,9 @@ public:
 	bool compiled() const			{return m_compiled;}
 	const LexTables& tables() const		{return m_tables;}
 	size_t nofPatterns() const		{return m_defs.size();}
+	// compiled tables as a blob and back (serial.hpp): a loaded lexer is compiled and frozen
+	void save( std::vector<uint8_t>& out) const;
+	void load( const void* blob, size_t size);
 
 private:
 	struct Def

@@ -6,6 +6,7 @@
 //  * the optimizer's re-keying decisions, which depend on the visiting order of a
 //    std::unordered_map<uint32_t,uint32_t>                       src/ruleMatcherAutomaton.cpp:512-586
 #include "l2_compile.hpp"
+#include "serial.hpp"
 #include <algorithm>
 #include <cstring>
 #include <limits>
@@ -462,4 +463,104 @@ std::vector<uint32_t> RuleCompiler::dump() const
 	}
 	for (std::set<uint32_t>::const_iterator si=m_stopWords.begin(); si!=m_stopWords.end(); ++si) buf.push_back( *si);
 	return buf;
+}
+
+// ---------------------------------------------------------------- the rule set as a blob
+static const char L2_MAGIC[ 9] = "SPAL2v01";
+
+void RuleCompiler::save( std::vector<uint8_t>& out, bool compiled) const
+{
+	BlobWriter w( L2_MAGIC);
+	w.u32( compiled ? 1u : 0u);
+	w.f32( m_stopwordOccurrenceFactor); w.f32( m_weightFactor); w.u32( m_maxRange); w.u32( m_exclusive ? 1u : 0u); w.u32( m_maxResultSize);
+	w.u32( m_exprEvents); w.u32( m_totalKeyedPrograms);
+	w.u32( (uint32_t)m_patterns.names().size());
+	for (size_t i=0; i<m_patterns.names().size(); ++i) w.str( m_patterns.names()[ i]);
+	w.u32( (uint32_t)m_variables.names().size());
+	for (size_t i=0; i<m_variables.names().size(); ++i) w.str( m_variables.names()[ i]);
+	w.u32( (uint32_t)m_formatStrings.size());
+	for (size_t i=0; i<m_formatStrings.size(); ++i) w.str( m_formatStrings[ i]);
+	w.u32( (uint32_t)m_progs.size());
+	for (size_t pi=0; pi<m_progs.size(); ++pi)
+	{
+		const Prog& p = m_progs[ pi];
+		w.u32( p.initsigval); w.u32( p.initcount); w.u32( p.event); w.u32( p.resultHandle); w.u32( p.formatHandle); w.u32( p.range);
+		w.u32( (uint32_t)p.trigs.size());
+		for (size_t ti=0; ti<p.trigs.size(); ++ti)
+		{
+			const Trig& t = p.trigs[ ti];
+			w.u32( t.event); w.u32( t.isKey ? 1u : 0u); w.u32( t.sigtype); w.u32( t.sigval); w.u32( t.variable);
+		}
+	}
+	// key index: lists in push order; the events in ascending order (the map's own order only matters to the optimizer)
+	std::vector<uint32_t> keys;
+	for (std::unordered_map<uint32_t,uint32_t>::const_iterator ki=m_keymap.begin(); ki!=m_keymap.end(); ++ki) keys.push_back( ki->first);
+	std::sort( keys.begin(), keys.end());
+	w.u32( (uint32_t)keys.size());
+	for (size_t k=0; k<keys.size(); ++k)
+	{
+		const std::vector<KeyRef>& lst = m_keylists[ m_keymap.find( keys[ k])->second];
+		w.u32( keys[ k]); w.u32( (uint32_t)lst.size());
+		for (size_t i=0; i<lst.size(); ++i) { w.u32( lst[ i].program); w.u32( lst[ i].pastEvent); }
+	}
+	w.u32( (uint32_t)m_stopWords.size());
+	for (std::set<uint32_t>::const_iterator si=m_stopWords.begin(); si!=m_stopWords.end(); ++si) w.u32( *si);
+	w.u32( (uint32_t)m_keyOccurrence.size());
+	for (std::map<uint32_t,uint32_t>::const_iterator oi=m_keyOccurrence.begin(); oi!=m_keyOccurrence.end(); ++oi) { w.u32( oi->first); w.u32( oi->second); }
+	w.u32( (uint32_t)m_frequency.size());
+	for (std::map<uint32_t,double>::const_iterator fi=m_frequency.begin(); fi!=m_frequency.end(); ++fi) { w.u32( fi->first); w.f64( fi->second); }
+	out.swap( w.finish());
+}
+
+bool RuleCompiler::load( const void* blob, size_t size)
+{
+	BlobReader r( blob, size, L2_MAGIC);
+	RuleCompiler n;
+	const bool compiled = r.u32() != 0;
+	n.m_stopwordOccurrenceFactor = r.f32(); n.m_weightFactor = r.f32(); n.m_maxRange = r.u32(); n.m_exclusive = r.u32() != 0; n.m_maxResultSize = r.u32();
+	n.m_exprEvents = r.u32(); n.m_totalKeyedPrograms = r.u32();
+	const uint32_t np = r.u32();
+	for (uint32_t i=0; i<np; ++i) n.m_patterns.getOrCreate( r.str());
+	const uint32_t nv = r.u32();
+	for (uint32_t i=0; i<nv; ++i) n.m_variables.getOrCreate( r.str());
+	const uint32_t nf = r.u32();
+	for (uint32_t i=0; i<nf; ++i) n.m_formatStrings.push_back( r.str());
+	n.m_formats = nf;
+	const uint32_t ng = r.u32();
+	for (uint32_t pi=0; pi<ng; ++pi)
+	{
+		Prog p;
+		p.initsigval = r.u32(); p.initcount = r.u32(); p.event = r.u32(); p.resultHandle = r.u32(); p.formatHandle = r.u32(); p.range = r.u32();
+		const uint32_t nt = r.u32();
+		for (uint32_t ti=0; ti<nt; ++ti)
+		{
+			Trig t; t.event = r.u32(); t.isKey = r.u32() != 0; t.sigtype = (uint8_t)r.u32(); t.sigval = r.u32(); t.variable = r.u32();
+			if (t.sigtype > SIG_AND || t.variable > nv) throw std::runtime_error( "rule set blob holds an invalid trigger");
+			p.trigs.push_back( t);
+		}
+		if (p.resultHandle > np || p.formatHandle > nf) throw std::runtime_error( "rule set blob holds an invalid program");
+		n.m_progs.push_back( p);
+	}
+	const uint32_t nk = r.u32();
+	for (uint32_t k=0; k<nk; ++k)
+	{
+		const uint32_t ev = r.u32(), cnt = r.u32();
+		n.m_keymap[ ev] = (uint32_t)n.m_keylists.size();
+		n.m_keylists.push_back( std::vector<KeyRef>());
+		for (uint32_t i=0; i<cnt; ++i)
+		{
+			KeyRef kr; kr.program = r.u32(); kr.pastEvent = r.u32();
+			if (kr.program == 0 || kr.program > ng) throw std::runtime_error( "rule set blob holds an invalid key list");
+			n.m_keylists.back().push_back( kr);
+		}
+	}
+	const uint32_t ns = r.u32();
+	for (uint32_t i=0; i<ns; ++i) n.m_stopWords.insert( r.u32());
+	const uint32_t no = r.u32();
+	for (uint32_t i=0; i<no; ++i) { const uint32_t ev = r.u32(); n.m_keyOccurrence[ ev] = r.u32(); }
+	const uint32_t nq = r.u32();
+	for (uint32_t i=0; i<nq; ++i) { const uint32_t ev = r.u32(); n.m_frequency[ ev] = r.f64(); }
+	if (!r.atEnd()) throw std::runtime_error( "rule set blob has trailing data");
+	*this = n;
+	return compiled;
 }

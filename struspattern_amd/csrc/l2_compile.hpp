@@ -32,6 +32,7 @@ public:
 	uint32_t getOrCreate( const std::string& name);
 	uint32_t get( const std::string& name) const;
 	const char* key( uint32_t id) const;
+	const std::vector<std::string>& names() const {return m_names;}
 private:
 	std::map<std::string,uint32_t> m_ids;
 	std::vector<std::string> m_names;
@@ -60,6 +61,9 @@ public:
 	const char* formatString( uint32_t handle) const	{return (handle && handle <= m_formatStrings.size()) ? m_formatStrings[ handle-1].c_str() : 0;}
 
 	void flatten( FlatTables& out) const;
+	// the rule set as a blob and back (serial.hpp): tables, names, format strings, options
+	void save( std::vector<uint8_t>& out, bool compiled) const;
+	bool load( const void* blob, size_t size);		// returns the `compiled` flag of save()
 	// canonical dump (same format as oracle's orc_l2_dump_table, see oracle/oracle_capi.cpp)
 	std::vector<uint32_t> dump() const;
 
