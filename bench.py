@@ -295,7 +295,7 @@ def pmc_traffic(kernel_prefix, wl, args, kernel_ms):
     as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself: the figure is
     reported only for the default configuration and only while the profiled kernel ran as long as the one
     timed here (within 15 %), i.e. it is the same kernel revision on the same work."""
-    if wl != "pipeline" or args.docs or args.regexes or args.docbytes:
+    if wl != "pipeline" or args.docs or args.regexes or args.docbytes not in (0, 65536) or args.rules != 10000:
         return None, None
     try:
         with open(PMC_SUMMARY) as f:
