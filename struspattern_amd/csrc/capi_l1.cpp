@@ -43,14 +43,15 @@ struct sp_lexer_ctx
 	DeviceBuffer dByteClass, dClassCtx, dCharMask, dStartMask, dAcceptMask, dShiftDst, dSelfLoop, dExSrc, dExDst, dExCount,
 		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit;
 	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst; unsigned blockThreads;
-	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus;
+	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus, dQueue, dReportCount;
+	uint32_t queueMul;		// report queue between the two kernels: queueMul/16 reports per text byte (+64 per document)
 	uint32_t queueCap, eventCap;
 	unsigned arenaWaves; uint64_t arenaWords;
 	uint64_t lexemCapacity, minLexemCapacity;
 	unsigned numCUs;
 	hipEvent_t evStart, evStop; bool evValid;
 	hipStream_t lastStream; size_t lastNdocs;
-	sp_lexer_ctx() :inst(0),device(0),ldsWords(0),ldsAccept(0),ldsStart(0),ldsShift(0),ldsSelf(0),ldsExSrc(0),ldsExDst(0),blockThreads(256),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
+	sp_lexer_ctx() :inst(0),device(0),ldsWords(0),ldsAccept(0),ldsStart(0),ldsShift(0),ldsSelf(0),ldsExSrc(0),ldsExDst(0),blockThreads(256),queueMul(8),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
 		,numCUs(256),evStart(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0){}
 };
 
@@ -260,6 +261,7 @@ int sp_lexer_ctx_grow_arena( sp_lexer_ctx_t* c)
 {
 	if (c->eventCap >= (1u<<26)) { c->lasterror = "arena at its maximum size"; return SP_ERR_INVALID; }
 	c->eventCap *= 2; c->queueCap *= 2; c->arenaWaves = 0;
+	if (c->queueMul < 4096) c->queueMul *= 2;
 	return SP_OK;
 }
 
@@ -275,7 +277,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	unsigned nblocks = (wavesWanted + wpb-1) / wpb;
 	if (nblocks == 0) nblocks = 1;
 	unsigned nwaves = nblocks*wpb;
-	uint64_t perWaveWords = 4ull*c->queueCap + 4ull*c->eventCap;
+	uint64_t perWaveWords = 4ull*c->eventCap;		// the handler's event array (the report queue is per document: dQueue)
 	{
 		size_t maxWaves = ((size_t)48 << 30) / (perWaveWords*4);
 		if (maxWaves < 4) maxWaves = 4;
@@ -295,6 +297,8 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	if (c->lexemCapacity < want) { c->lexemCapacity = 0; c->dLexems.alloc( want*sizeof(sp_lexem_t)); c->lexemCapacity = want; }	// (capacity follows the buffer also when the allocation fails)
 	c->dDocRange.reserve( (ndocs+1)*2*sizeof(uint64_t));
 	c->dDocStatus.reserve( (ndocs+1)*sizeof(int32_t));
+	c->dReportCount.reserve( (ndocs+1)*sizeof(uint32_t));
+	c->dQueue.reserve( ((((uint64_t)nbytes * c->queueMul) >> 4) + 64ull*(ndocs+2)) * 16);
 	HIP_CHECK( hipMemsetAsync( c->dCounters.ptr, 0, L1C_ALLOC*sizeof(uint64_t), stream));
 
 	L1Params P;
@@ -316,6 +320,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.arenaBase = (uint32_t*)c->dArena.ptr; P.arenaWords = perWaveWords; P.queueCap = c->queueCap; P.eventCap = c->eventCap;
 	P.counters = (uint64_t*)c->dCounters.ptr; P.lexems = (uint32_t*)c->dLexems.ptr; P.lexemCapacity = c->lexemCapacity;
 	P.docRange = (uint64_t*)c->dDocRange.ptr; P.docStatus = (int32_t*)c->dDocStatus.ptr;
+	P.reportQueue = (uint32_t*)c->dQueue.ptr; P.reportCount = (uint32_t*)c->dReportCount.ptr; P.queueMul = c->queueMul;
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
 	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = c->ldsWords;
 	P.ldsAccept = c->ldsAccept; P.ldsStart = c->ldsStart; P.ldsShift = c->ldsShift; P.ldsSelf = c->ldsSelf;

@@ -1091,8 +1091,9 @@ void LexCompiler::compile()
 		T.nofLiterals = (uint32_t)literalWords.size();
 		for (std::map<std::string,std::vector<uint32_t> >::const_iterator li=literalWords.begin(); li!=literalWords.end(); ++li)
 		{
-			uint32_t h = 2166136261u;
-			for (size_t k=0; k<li->first.size(); ++k) h = symbolHashStep( h, (unsigned char)li->first[k]);
+			uint32_t h = 0;
+			for (size_t k=0; k<li->first.size(); ++k) h = h * (uint32_t)L1_LITHASH_MUL + (uint32_t)(unsigned char)li->first[k] + 1u;
+			h = literalHashFinish( h);
 			if (!h) h = 1;
 			DevLiteral e; std::memset( &e, 0, sizeof(e));
 			e.hash = h; e.textOffset = (uint32_t)T.literalText.size(); e.len = (uint32_t)li->first.size();
@@ -1103,7 +1104,7 @@ void LexCompiler::compile()
 			while (T.literals[ slot].hash) slot = (slot+1) & (size-1);
 			T.literals[ slot] = e;
 		}
-		if (T.literalText.empty()) T.literalText.push_back( 0);
+		for (int pad=0; pad<4; ++pad) T.literalText.push_back( 0);	// (the kernel compares four bytes at a time)
 		if (T.litPats.empty()) T.litPats.push_back( 0);
 	}
 

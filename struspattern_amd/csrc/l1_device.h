@@ -6,7 +6,7 @@
 
 namespace spa {
 
-enum {L1C_LEXEMS=0, L1C_BYTES=1, L1C_RAW=2, L1C_FAILED=3, L1C_COUNT=8, L1C_CURSOR=8 /*document cursor, behind the counters*/, L1C_ALLOC=9};
+enum {L1C_LEXEMS=0, L1C_BYTES=1, L1C_RAW=2, L1C_FAILED=3, L1C_COUNT=8, L1C_CURSOR=8 /*document cursor of the scan kernel, behind the counters*/, L1C_CURSOR2=9 /*of the post-processing kernel*/, L1C_ALLOC=10};
 
 struct L1Params
 {
@@ -47,8 +47,14 @@ struct L1Params
 	// per-wave working memory
 	uint32_t* arenaBase;
 	uint64_t arenaWords;		// words per wave
-	uint32_t queueCap;		// raw-match queue records (4 words each)
+	uint32_t queueCap;		// (unused since the kernels were split)
 	uint32_t eventCap;		// event array records (4 words each)
+	// hand-over between the scan kernel and the post-processing kernel: the raw reports of document d, 16 B each,
+	// at reportQueue[ 4*qbase(d) ..) with qbase(d) = (begin(d)*queueMul >> 4) + 64*d -- room for queueMul/16 reports
+	// per text byte plus 64; reportCount[d] = how many there are
+	uint32_t* reportQueue;
+	uint32_t* reportCount;
+	uint32_t queueMul;
 	// output
 	uint64_t* counters;		// L1C_*
 	uint32_t* lexems;		// sp_lexem_t[lexemCapacity]

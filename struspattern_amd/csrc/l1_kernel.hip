@@ -4,12 +4,20 @@
 // per-match callback PatternLexerContext::match_event_handler (:717-826) and the ordinal-position
 // pass of PatternLexerContext::match (:893-945).
 //
-// Stages per document, fused in one kernel so that raw matches never leave the wave's arena:
+// Two kernels per batch (round 2; one fused kernel before): the SCAN kernel runs stage 1 and leaves the raw
+// reports of a document in its slice of a report queue in HBM (16 B per report, ~3 B per text byte); the
+// POST kernel runs stages 1b-4 on them.  Fused, the two halves shared one register allocation: 106 scalar
+// registers of the byte loop were spilled and every step reloaded kernel arguments.
+// Stages per document:
 //  1. SCAN   bit-parallel position automaton (tables: l1_tables.h).  Lane l owns word l of every
 //            pass; the document byte is wave-uniform, the table row of its byte class is one
 //            coalesced 512-byte read; a report is detected with one __ballot per pass and byte.
 //            Reports are appended to a queue in (end offset, pattern index) order = the order in
 //            which the reference's handler is called.
+//  1b. LITERALS  \bWORD\b patterns are no automaton bits: per 64-byte tile the runs of word characters come out
+//            of one ballot, their hashes out of one segmented scan, and every lane where a run has ended probes
+//            the literal table by itself; the literal reports are merged with the automaton's by (end offset,
+//            pattern index).
 //  2. SOM    start of match: one lane per queued report runs the pattern's automaton BACKWARDS from
 //            the end offset (predecessor sets from the same shift/self/exception tables) and keeps
 //            the smallest offset at which a start position is live = leftmost start.
@@ -63,7 +71,7 @@ struct LexWave
 {
 	u32* queue;		// raw reports: 4 words {to, pattern, accLo, accHi}; after SOM word 2 holds `from`
 	Event* events;
-	u32 nQueue, nEvents, err;
+	u32 nQueue, nEvents, err, queueCap;
 	Event tail; bool tailValid;	// copy of events[nEvents-1] in scalar registers: most reports only touch the tail
 	const unsigned char* doc;
 	u32 docLen;
@@ -80,19 +88,19 @@ __device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* do
 
 // ---------------------------------------------------------------- stage 2: leftmost start per report
 // lane-parallel: lane i resolves report base+i
-struct LaneReport { u32 to, from, id, levelBind, prefixLen, suffixLen; };	// one queued report per lane, pattern attributes attached
+struct LaneReport { u32 to, from, id, levelBind, prefixLen, suffixLen, pi; };	// one queued report per lane, pattern attributes attached
 
 template <bool LDS>
 __device__ void resolveStarts( LexWave& w, const L1Params& P, const LexTab<LDS>& T, u32 base, u32 count, LaneReport& out)
 {
 	u32 i = base + LANE;
-	out.to = 0; out.from = 0; out.id = 0; out.levelBind = 0; out.prefixLen = 0; out.suffixLen = 0;
+	out.to = 0; out.from = 0; out.id = 0; out.levelBind = 0; out.prefixLen = 0; out.suffixLen = 0; out.pi = 0;
 	if (LANE < count)
 	{
 		const uint4 q = *(const uint4*)(w.queue + 4*(u64)i);	// {to, pattern, accLo|from, accHi}
 		u32 to = q.x, pi = q.y & ~L1_LITERAL_FLAG;
 		const uint4 p0 = *(const uint4*)&P.patterns[ pi], p1 = *((const uint4*)&P.patterns[ pi] + 1);	// {id,word,levelBind,prefixLen} {suffixLen,maskLo,maskHi,-}
-		out.to = to; out.id = p0.x; out.levelBind = p0.z; out.prefixLen = p0.w; out.suffixLen = p1.x;
+		out.to = to; out.id = p0.x; out.levelBind = p0.z; out.prefixLen = p0.w; out.suffixLen = p1.x; out.pi = pi;
 		if (q.y & L1_LITERAL_FLAG) { out.from = q.z; return; }		// whole-word literal: start already known
 		u64 R = ((u64)q.w << 32) | q.z;
 		const u32 pass = p0.y >> 6, ln = p0.y & 63u;
@@ -245,70 +253,83 @@ __device__ void handleReport( LexWave& w, const L1Params& P, u32 id, u32 lb, u32
 	w.tailValid = false;		// reloaded on the next report
 }
 
-// drain the report queue: SOM in batches of 64 lanes, handler in report order
-template <bool LDS>
-__device__ void drainQueue( LexWave& w, const L1Params& P, const LexTab<LDS>& T)
+// four text bytes from an arbitrary address (global memory takes unaligned dword loads)
+__device__ __forceinline__ u32 ld32u( const unsigned char* p) { u32 v; __builtin_memcpy( &v, p, 4); return v; }
+
+// The literals of one 64-byte tile, all lanes at once.  Lane l holds byte tile+l: the runs of word characters of
+// the tile come out of one ballot, their hashes out of one segmented scan (polynomial hash, l1_tables.h), and every
+// lane where a run has just ended looks its word up in the literal table by itself.  A run that crosses the tile
+// boundary is carried (hash, length and start so far).
+struct LitCarry { bool in; u32 hash, len, start; };
+__device__ __forceinline__ void tileLiterals(  const LexWave& w, const L1Params& P, u32 tile, u32 mine, bool isW, LitCarry& c,
+						u64& endMask, u32& litFrom, u32& litBegin, u32& litCount, u32& litPi0, u32& litId0, u32& litLb0)
 {
-	for (u32 base=0; base<w.nQueue && !w.err; base+=64)
+	const u64 wm = __ballot( isW);
+	const u64 prevW = (wm << 1) | (c.in ? 1ull : 0ull);
+	const u64 startM = wm & ~prevW;
+	endMask = ~wm & prevW;				// bit e: the run that ended just before byte tile+e
+	const u64 sb = startM & (((1ull << LANE) - 1ull) | (1ull << LANE));
+	const int ss = sb ? 63 - (int)__builtin_clzll( sb) : -1;	// start of my run inside the tile (-1: it began in an earlier tile)
+	u32 H = isW ? mine + 1u : 0u, M = (u32)L1_LITHASH_MUL;
+#pragma unroll
+	for (int d=1; d<64; d<<=1)
 	{
-		u32 count = w.nQueue - base < 64 ? w.nQueue - base : 64;
-		u64 t0 = PROF_T();
-		LaneReport lr;
-		resolveStarts( w, P, T, base, count, lr);
-		for (u32 k=0; k<count && !w.err; ++k)
-		{
-			handleReport( w, P, (u32)__builtin_amdgcn_readlane( lr.id, k), (u32)__builtin_amdgcn_readlane( lr.levelBind, k),
-					(u32)__builtin_amdgcn_readlane( lr.prefixLen, k), (u32)__builtin_amdgcn_readlane( lr.suffixLen, k),
-					(u32)__builtin_amdgcn_readlane( lr.from, k), (u32)__builtin_amdgcn_readlane( lr.to, k));
-		}
-		PROF_ACC( 1, t0);
+		const u32 Hs = (u32)__shfl_up( (int)H, d), Ms = (u32)__shfl_up( (int)M, d);
+		const bool take = isW && (int)LANE >= d && (int)LANE - d >= ss;
+		if (take) { H = Hs * M + H; M = Ms * M; }
 	}
-	w.nQueue = 0;
-}
-
-
-// ---------------------------------------------------------------- whole-word literals (\bWORD\b patterns)
-// A maximal run of word characters [from,to) has ended: if it equals a literal, every pattern defined
-// by that literal reports (from,to).  The reports are merged into the current end-offset group of the
-// queue in ascending pattern index (the order the automaton reports have there already).
-__device__ void literalReports( LexWave& w, const L1Params& P, u32 groupStart, u32 from, u32 to, u32 hash)
-{
-	const u32 len = to - from;
-	u32 h = hash ? hash : 1u;
-	u32 slot = h & P.literalMask;
-	for (u32 probes=0; probes<=P.literalMask; ++probes)
+	const bool carried = isW && ss < 0;
+	const u32 Htot = carried ? c.hash * M + H : H;		// (M = MUL^(lane+1) for a carried run)
+	u32 runLen = isW ? (carried ? c.len + LANE + 1u : LANE - (u32)ss + 1u) : 0u;
+	if (runLen > 65u) runLen = 65u;
+	const u32 from = carried ? c.start : tile + (u32)(ss < 0 ? 0 : ss);
+	// the run that ended before me = the values of the lane before me
+	u32 pH = (u32)__shfl_up( (int)Htot, 1), pLen = (u32)__shfl_up( (int)runLen, 1), pFrom = (u32)__shfl_up( (int)from, 1);
+	if (LANE == 0) { pH = c.hash; pLen = c.len; pFrom = c.start; }
+	litFrom = pFrom; litBegin = 0; litCount = 0; litPi0 = 0; litId0 = 0; litLb0 = 0;
+	if (((endMask >> LANE) & 1ull) && pLen >= 1u && pLen <= 64u)
 	{
-		// one 32-byte entry = one load: lane k < 8 fetches word k
-		const u32 ew = (LANE < 8u) ? ((const u32*)&P.literals[ slot])[ LANE] : 0u;
-		const u32 eh = (u32)__builtin_amdgcn_readlane( ew, 0);
-		if (!eh) return;
-		if (eh == h && (u32)__builtin_amdgcn_readlane( ew, 2) == len)
+		const u32 h = literalHashFinish( pH);
+		u32 slot = h & P.literalMask;
+		for (u32 probes=0; probes<=P.literalMask; ++probes)
 		{
-			const u32 off = (u32)__builtin_amdgcn_readlane( ew, 1);
-			const bool differ = LANE < len && w.doc[ from + LANE] != P.literalText[ off + LANE];	// one byte per lane (len <= 64)
-			if (!__ballot( differ))
+			const uint4 e = *(const uint4*)&P.literals[ slot];		// {hash, textOffset, len, patBegin}
+			if (!e.x) break;
+			if (e.x == h && e.z == pLen)
 			{
-				const u32 pb = (u32)__builtin_amdgcn_readlane( ew, 3), pc = (u32)__builtin_amdgcn_readlane( ew, 4);
-				for (u32 k=0; k<pc; ++k)
+				bool same = true;
+				for (u32 k=0; k<pLen && same; k+=4)
 				{
-					const u32 pi = ldu( &P.litPats[ pb+k]);
-					if (w.nQueue + 1 > P.queueCap) { w.err = L1D_ERR_ARENA; return; }
-					u32 at = groupStart;
-					while (at < w.nQueue && (ldu( &w.queue[ 4*(u64)at+1]) & ~L1_LITERAL_FLAG) < pi) ++at;
-					for (u32 m=w.nQueue; m>at; --m)
+					const u32 rem = pLen - k;
+					u32 a;
+					if (pFrom + k + 4u <= w.docLen) a = ld32u( w.doc + pFrom + k);
+					else
 					{
-						u32* dst = w.queue + 4*(u64)m; const u32* src = w.queue + 4*(u64)(m-1);
-						u32 a0 = ldu( &src[0]), a1 = ldu( &src[1]), a2 = ldu( &src[2]), a3 = ldu( &src[3]);
-						dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+						a = 0;
+						for (u32 q=0; q<rem && q<4u; ++q) a |= (u32)w.doc[ pFrom + k + q] << (8*q);
 					}
-					u32* q = w.queue + 4*(u64)at;
-					q[0] = to; q[1] = pi | L1_LITERAL_FLAG; q[2] = from; q[3] = 0;
-					w.nQueue += 1;
+					const u32 b = ld32u( P.literalText + e.y + k);
+					const u32 mask = rem >= 4u ? 0xFFFFFFFFu : ((1u << (8*rem)) - 1u);
+					same = ((a ^ b) & mask) == 0;
 				}
-				return;
+				if (same)
+				{
+					// (almost every literal defines one pattern: its attributes come along, the handler needs no further load)
+					litBegin = e.w; litCount = P.literals[ slot].patCount;
+					litPi0 = P.litPats[ e.w];
+					const uint4 p0 = *(const uint4*)&P.patterns[ litPi0];	// {id, word, levelBind, prefixLen}
+					litId0 = p0.x; litLb0 = p0.z;
+					break;
+				}
 			}
+			slot = (slot+1) & P.literalMask;
 		}
-		slot = (slot+1) & P.literalMask;
+	}
+	// carry the run that reaches the end of the tile
+	c.in = (wm >> 63) & 1ull;
+	if (c.in)
+	{
+		c.hash = uni( (u32)__shfl( (int)Htot, 63)); c.len = uni( (u32)__shfl( (int)runLen, 63)); c.start = uni( (u32)__shfl( (int)from, 63));
 	}
 }
 
@@ -322,9 +343,8 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 	const u32 len = w.docLen;
 	// instances for 1..8 passes run tables of exactly that many passes; the 16 / 32 instances run anything up to it
 	const u32 nofPasses = (PASSES <= 8) ? (u32)PASSES : uni( P.nofPasses);
-	const u32 drainAt = P.queueCap > P.nofPatterns + 64 ? P.queueCap - P.nofPatterns - 64 : 0;
+	const u32 nofClasses = uni( P.nofClasses), maxEx = uni( P.maxExceptions);
 	int prevctx = CTX_EDGE;
-	bool inWord = false; u32 runStart = 0, runHash = 0;		// token hash of the current run of word characters
 	// byte -> class / context without touching memory: lane l keeps the entries of bytes 4l..4l+3
 	u32 clsReg = 0, ctxReg = 0;
 	for (u32 k=0; k<4; ++k)
@@ -347,16 +367,23 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 		// 64 document bytes per load, one per lane; replayed byte by byte through a scalar register
 		u32 mine = (tile + LANE < len) ? w.doc[ tile + LANE] : 0u;
 		u32 inTile = (len - tile) < 64 ? (len - tile) : 64;	// document bytes in this tile
+		// class and context of my byte (lane-parallel lookup in the register tables), replayed per byte with one readlane
+		u32 ccv;
+		{
+			const u32 shm = (mine & 3u)*8;
+			const u32 clsL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)clsReg) >> shm) & 0xFFu;
+			const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> shm) & 0xFFu;
+			ccv = clsL | (ctxL << 8);
+		}
 		// one byte step; the virtual step behind the last byte (matches that end with the document) is a
 		// separate instance so that the hot one carries no end-of-document conditions
 		auto step = [&]( auto atEndTag, const u32 k)
 		{
 			constexpr bool atEnd = decltype(atEndTag)::value;
 			const u32 i = tile + k;
-			const u32 b = atEnd ? 0u : (u32)__builtin_amdgcn_readlane( mine, k);
-			const u32 sh = (b & 3u)*8;
-			const u32 cls = atEnd ? 0u : (((u32)__builtin_amdgcn_readlane( clsReg, b >> 2) >> sh) & 0xFFu);
-			const int ctx = atEnd ? (int)CTX_EDGE : (int)(((u32)__builtin_amdgcn_readlane( ctxReg, b >> 2) >> sh) & 0xFFu);
+			const u32 cc = atEnd ? ((u32)CTX_EDGE << 8) : (u32)__builtin_amdgcn_readlane( ccv, k);
+			const u32 cls = cc & 0xFFu;
+			const int ctx = (int)(cc >> 8);
 			const u32 groupStart = w.nQueue;	// reports of this end offset start here
 			// every table row this byte needs, for all passes, before anything depends on them
 			u64 accRow[ PASSES], cmRow[ PASSES], stRow[ PASSES];
@@ -368,7 +395,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 				if ((u32)p < nofPasses)
 				{
 					accRow[ p] = T.at( T.oAccept + (p*CTX_COUNT + ctx)*64 + LANE);
-					cmRow[ p] = T.at( (p*P.nofClasses + cls)*64 + LANE);
+					cmRow[ p] = T.at( (p*nofClasses + cls)*64 + LANE);
 					stRow[ p] = T.at( T.oStart + (p*CTX_COUNT + prevctx)*64 + LANE);
 				}
 			}
@@ -388,7 +415,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 					const u32 nEx = nExOf[ p];
 					for (u32 e=0; e<nEx; ++e)
 					{
-						const u32 at = (p*P.maxExceptions + e)*64 + LANE;
+						const u32 at = (p*maxEx + e)*64 + LANE;
 						const u64 es = T.at( T.oExSrc + at), ed = T.at( T.oExDst + at);
 						nxt |= (st & es) ? ed : 0ull;
 					}
@@ -426,7 +453,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 					u32 incl = waveScanAdd( mycount);
 					u32 total = (u32)__builtin_amdgcn_readlane( incl, 63);
 					u32 at = w.nQueue + incl - mycount;
-					if (w.nQueue + total > P.queueCap) { w.err = L1D_ERR_ARENA; break; }
+					if (w.nQueue + total > w.queueCap) { w.err = L1D_ERR_ARENA; break; }
 					if (mycount)
 					{
 						u64 rem = a;
@@ -488,35 +515,92 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 				}
 				PROF_ACC( 2, tHit);
 			}
-			if (P.nofLiterals)
-			{
-				const bool isW = (ctx == CTX_WORD);
-				if (inWord && !isW)
-				{
-					inWord = false;
-					if (i - runStart <= 64u) { u64 t0 = PROF_T(); __builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront"); literalReports( w, P, groupStart, runStart, i, runHash); PROF_ACC( 3, t0); }
-				}
-				if (isW)
-				{
-					if (!inWord) { inWord = true; runStart = i; runHash = 2166136261u; }
-					runHash = symbolHashStep( runHash, b);
-				}
-			}
 			prevctx = ctx;
-			if (w.nQueue >= drainAt && w.nQueue)
-			{
-				__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
-				drainQueue( w, P, T);
-			}
 		};
 		for (u32 k=0; k<inTile && !w.err; ++k) step( std::false_type(), k);
 		if (tile + 64 > len && !w.err) step( std::true_type(), inTile);
 	}
-	if (!w.err && w.nQueue)
+}
+
+// ---------------------------------------------------------------- stages 1b-3: literals, start of match, handler
+// The document's raw reports (scan kernel) and its literal reports (found here, tile by tile) go through the
+// reference's handler in the order the reference's callback sees them: ascending end offset, ascending pattern
+// index inside one end offset.
+template <bool LDS>
+__device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& T)
+{
+	const u32 len = w.docLen;
+	u32 ctxReg = 0;			// byte -> context: lane l keeps the entries of bytes 4l..4l+3
+	for (u32 k=0; k<4; ++k) ctxReg |= (u32)P.classCtx[ P.byteClass[ 4*LANE + k]] << (8*k);
+	LitCarry carry; carry.in = false; carry.hash = 0; carry.len = 0; carry.start = 0;
+	const u32 nq = w.nQueue;
+	u32 qi = 0, qb = 0, qn = 0;		// next report; the batch [qb, qb+qn) is resolved in lr
+	LaneReport lr;
+	lr.to = 0; lr.from = 0; lr.id = 0; lr.levelBind = 0; lr.prefixLen = 0; lr.suffixLen = 0; lr.pi = 0;
+	if (nq) { qn = nq < 64u ? nq : 64u; resolveStarts( w, P, T, 0, qn, lr); }
+	for (u32 tile=0; tile<=len && !w.err; tile+=64)
 	{
-		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
-		drainQueue( w, P, T);
+		const u32 mine = (tile + LANE < len) ? w.doc[ tile + LANE] : 0u;
+		const u32 inTile = (len - tile) < 64 ? (len - tile) : 64;
+		u64 litEnds = 0; u32 litFrom = 0, litBegin = 0, litCount = 0, litPi0 = 0, litId0 = 0, litLb0 = 0;
+		if (P.nofLiterals)
+		{
+			const u32 shm = (mine & 3u)*8;
+			const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> shm) & 0xFFu;
+			tileLiterals( w, P, tile, mine, LANE < inTile && ctxL == (u32)CTX_WORD, carry, litEnds, litFrom, litBegin, litCount, litPi0, litId0, litLb0);
+			litEnds &= __ballot( litCount != 0);
+		}
+		// every report that ends inside this tile: end offsets tile .. tile+63 (a full tile) or .. len (the last one)
+		const u32 lastTo = (tile + 64 > len) ? len : tile + 63u;
+		while (!w.err)
+		{
+			u32 toA = 0xFFFFFFFFu;
+			if (qi < nq) toA = (u32)__builtin_amdgcn_readlane( lr.to, qi - qb);
+			const u32 kL = litEnds ? (u32)__builtin_ctzll( litEnds) : 64u;
+			const u32 toL = litEnds ? tile + kL : 0xFFFFFFFFu;
+			const u32 toNext = toA < toL ? toA : toL;
+			if (toNext > lastTo) break;
+			// the literal's patterns (ascending) merged with the automaton's reports of the same end offset (ascending)
+			const u32 pb = toL == toNext ? (u32)__builtin_amdgcn_readlane( litBegin, kL) : 0u;
+			const u32 pc = toL == toNext ? (u32)__builtin_amdgcn_readlane( litCount, kL) : 0u;
+			const u32 lfrom = toL == toNext ? (u32)__builtin_amdgcn_readlane( litFrom, kL) : 0u;
+			u32 lj = 0;
+			u32 lpi = pc ? (u32)__builtin_amdgcn_readlane( litPi0, kL) : 0xFFFFFFFFu;
+			u32 lid = pc ? (u32)__builtin_amdgcn_readlane( litId0, kL) : 0u, llb = pc ? (u32)__builtin_amdgcn_readlane( litLb0, kL) : 0u;
+			while (!w.err)
+			{
+				u32 api = 0xFFFFFFFFu;
+				if (qi < nq && (u32)__builtin_amdgcn_readlane( lr.to, qi - qb) == toNext) api = (u32)__builtin_amdgcn_readlane( lr.pi, qi - qb);
+				if (api == 0xFFFFFFFFu && lj >= pc) break;
+				if (lj < pc && lpi < api)
+				{
+					handleReport( w, P, lid, llb, 0, 0, lfrom, toNext);
+					++lj;
+					if (lj < pc)
+					{
+						lpi = ldu( &P.litPats[ pb + lj]);
+						const DevLexPattern* pat = &P.patterns[ lpi];
+						lid = ldu( &pat->id); llb = ldu( &pat->levelBind);
+					}
+				}
+				else
+				{
+					const u32 x = qi - qb;
+					handleReport( w, P, (u32)__builtin_amdgcn_readlane( lr.id, x), (u32)__builtin_amdgcn_readlane( lr.levelBind, x),
+							(u32)__builtin_amdgcn_readlane( lr.prefixLen, x), (u32)__builtin_amdgcn_readlane( lr.suffixLen, x),
+							(u32)__builtin_amdgcn_readlane( lr.from, x), toNext);
+					++qi;
+					if (qi == qb + qn && qi < nq)
+					{
+						qb = qi; qn = (nq - qb) < 64u ? (nq - qb) : 64u;
+						resolveStarts( w, P, T, qb, qn, lr);
+					}
+				}
+			}
+			if (toL == toNext) litEnds &= litEnds - 1;
+		}
 	}
+	if (!w.err && qi != nq) w.err = L1D_ERR_INTERNAL;
 }
 
 // ---------------------------------------------------------------- stage 4: ordinal positions + output (:893-945)
@@ -616,10 +700,17 @@ __device__ void emitLexems( LexWave& w, const L1Params& P, u32 doc)
 	}
 }
 
-template <int PASSES, bool LDS>
-__device__ void lexDocuments( const L1Params& P)
+// ---------------------------------------------------------------- the two kernels
+__device__ __forceinline__ void docBounds( const L1Params& P, u32 doc, u64& beg, u64& end)
 {
-	LexTab<LDS> T;
+	beg = ((u64)ldu( (const u32*)&P.docOffsets[ doc]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc]);
+	end = ((u64)ldu( (const u32*)&P.docOffsets[ doc+1]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc+1]);
+}
+__device__ __forceinline__ u64 queueBase( const L1Params& P, u64 beg, u32 doc) { return ((beg * P.queueMul) >> 4) + 64ull*doc; }
+
+template <bool LDS>
+__device__ __forceinline__ void stageTables( const L1Params& P, LexTab<LDS>& T)
+{
 	T.g = P.tableImage; T.oAccept = P.ldsAccept; T.oStart = P.ldsStart; T.oShift = P.ldsShift; T.oSelf = P.ldsSelf;
 	T.oExSrc = P.ldsExSrc; T.oExDst = P.ldsExDst;
 	if (LDS)
@@ -628,12 +719,18 @@ __device__ void lexDocuments( const L1Params& P)
 		for (u32 k=threadIdx.x; k<P.ldsWords; k+=blockDim.x) ldsImage[ k] = P.tableImage[ k];
 		__syncthreads();
 	}
+}
+
+// SCAN: automaton over the document's bytes, raw reports into the document's slice of the report queue
+template <int PASSES, bool LDS>
+__device__ void scanDocuments( const L1Params& P)
+{
+	LexTab<LDS> T;
+	stageTables( P, T);
 	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
-	u32* A = P.arenaBase + (u64)waveSlot * P.arenaWords;
 	LexWave w;
-	w.queue = A;
-	w.events = (Event*)(A + 4*(u64)P.queueCap);
+	w.events = 0; w.nEvents = 0; w.tailValid = false;
 	// every wave starts with document `waveSlot` and takes its next ones from a device-side cursor;
 	// the loop is bounded so that it ends whatever the cursor holds
 	for (u32 round=0; round<=P.ndocs; ++round)
@@ -646,14 +743,57 @@ __device__ void lexDocuments( const L1Params& P)
 			doc = nWaveSlots + uni( nx);
 		}
 		if (doc >= P.ndocs) break;
-		const u64 beg = ((u64)ldu( (const u32*)&P.docOffsets[ doc]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc]);
-		const u64 end = ((u64)ldu( (const u32*)&P.docOffsets[ doc+1]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc+1]);
+		u64 beg, end;
+		docBounds( P, doc, beg, end);
 		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
-		w.nQueue = 0; w.nEvents = 0; w.err = 0; w.tailValid = false;
-#ifdef SPA_PROF
-		w.prof[0] = w.prof[1] = w.prof[2] = w.prof[3] = 0;
-#endif
-		{ u64 t0 = PROF_T(); scanDocument<PASSES,LDS>( w, P, T); PROF_ACC( 0, t0); }
+		const u64 qb = queueBase( P, beg, doc);
+		w.queue = P.reportQueue + 4*qb;
+		w.queueCap = (u32)(queueBase( P, end, doc+1) - qb);
+		w.nQueue = 0; w.err = 0;
+		scanDocument<PASSES,LDS>( w, P, T);
+		if (LANE == 0)
+		{
+			P.reportCount[ doc] = w.err ? 0u : w.nQueue;
+			P.docStatus[ doc] = (int32_t)w.err;
+			atomicAdd( (unsigned long long*)&P.counters[ L1C_RAW], (unsigned long long)w.nQueue);
+			if (w.err)
+			{
+				P.docRange[ 2*(u64)doc] = 0; P.docRange[ 2*(u64)doc+1] = 0;
+				atomicAdd( (unsigned long long*)&P.counters[ L1C_BYTES], (unsigned long long)w.docLen);
+				atomicAdd( (unsigned long long*)&P.counters[ L1C_FAILED], 1ull);
+			}
+		}
+	}
+}
+
+// POST: literals, start of match, handler, ordinal positions, lexems
+template <bool LDS>
+__device__ void postDocuments( const L1Params& P)
+{
+	LexTab<LDS> T;
+	stageTables( P, T);
+	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
+	LexWave w;
+	w.events = (Event*)(P.arenaBase + (u64)waveSlot * P.arenaWords);
+	for (u32 round=0; round<=P.ndocs; ++round)
+	{
+		u32 doc = waveSlot;
+		if (round)
+		{
+			u32 nx = 0;
+			if (LANE == 0) nx = atomicAdd( (u32*)&P.counters[ L1C_CURSOR2], 1u);
+			doc = nWaveSlots + uni( nx);
+		}
+		if (doc >= P.ndocs) break;
+		if (ldu( (const u32*)&P.docStatus[ doc]) != 0) continue;		// failed in the scan kernel
+		u64 beg, end;
+		docBounds( P, doc, beg, end);
+		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
+		w.queue = P.reportQueue + 4*queueBase( P, beg, doc);
+		w.nQueue = ldu( &P.reportCount[ doc]);
+		w.queueCap = w.nQueue; w.nEvents = 0; w.err = 0; w.tailValid = false;
+		postDocument<LDS>( w, P, T);
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		if (!w.err) emitLexems( w, P, doc);
 		else if (LANE == 0) { P.docRange[ 2*(u64)doc] = 0; P.docRange[ 2*(u64)doc+1] = 0; }
@@ -662,26 +802,18 @@ __device__ void lexDocuments( const L1Params& P)
 			P.docStatus[ doc] = (int32_t)w.err;
 			atomicAdd( (unsigned long long*)&P.counters[ L1C_BYTES], (unsigned long long)w.docLen);
 			if (w.err) atomicAdd( (unsigned long long*)&P.counters[ L1C_FAILED], 1ull);
-#ifdef SPA_PROF
-			for (int pi=0; pi<4; ++pi) atomicAdd( (unsigned long long*)&P.counters[ 4+pi], (unsigned long long)w.prof[ pi]);
-#endif
 		}
 	}
 }
 
 } // anonymous namespace
 
-// One instance per pass count (the per-pass rows of a byte step live in registers, so the count is a
-// template parameter: an instance for 8 passes running a 6-pass table would spill three times as many
-// registers).  Up to 5 passes fit the 128 registers of a 1024-thread workgroup without spills; 6..8
-// spill 22..96 of them, which was measured faster than halving the waves (512-thread groups).
+// One scan instance per pass count (the per-pass rows of a byte step live in registers, so the count is a
+// template parameter).
 #define SPA_L1_KERNEL( NAME, N, T) \
-extern "C" __global__ __launch_bounds__(T) void spa_l1_lex_kernel_##NAME( L1Params P) { if (P.ldsWords) lexDocuments<N,true>( P); else lexDocuments<N,false>( P); }
-// up to 2 passes: under 96 registers (5 waves per SIMD, 20 per CU)
-#define SPA_L1_KERNEL5( NAME, N, T) \
-extern "C" __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5,8))) void spa_l1_lex_kernel_##NAME( L1Params P) { if (P.ldsWords) lexDocuments<N,true>( P); else lexDocuments<N,false>( P); }
-SPA_L1_KERNEL5( p1, 1, 1024)
-SPA_L1_KERNEL5( p2, 2, 1024)
+extern "C" __global__ __launch_bounds__(T) void spa_l1_scan_kernel_##NAME( L1Params P) { if (P.ldsWords) scanDocuments<N,true>( P); else scanDocuments<N,false>( P); }
+SPA_L1_KERNEL( p1, 1, 1024)
+SPA_L1_KERNEL( p2, 2, 1024)
 SPA_L1_KERNEL( p3, 3, 1024)
 SPA_L1_KERNEL( p4, 4, 1024)
 SPA_L1_KERNEL( p5, 5, 1024)
@@ -690,14 +822,15 @@ SPA_L1_KERNEL( p7, 7, 1024)
 SPA_L1_KERNEL( p8, 8, 1024)
 SPA_L1_KERNEL( p16, 16, 256)
 SPA_L1_KERNEL( p32, 32, 256)
+extern "C" __global__ __launch_bounds__(1024) void spa_l1_post_kernel( L1Params P) { if (P.ldsWords) postDocuments<true>( P); else postDocuments<false>( P); }
 
 namespace spa {
 hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, hipStream_t stream)
 {
 	const size_t lds = (size_t)P.ldsWords * 8;
 #define SPA_L1_LAUNCH( N) do { \
-	if (lds > 65536) { hipError_t e = hipFuncSetAttribute( (const void*)spa_l1_lex_kernel_##N, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
-	hipLaunchKernelGGL( spa_l1_lex_kernel_##N, dim3( nblocks), dim3( nthreads), lds, stream, P); } while (0)
+	if (lds > 65536) { hipError_t e = hipFuncSetAttribute( (const void*)spa_l1_scan_kernel_##N, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
+	hipLaunchKernelGGL( spa_l1_scan_kernel_##N, dim3( nblocks), dim3( nthreads), lds, stream, P); } while (0)
 	switch (P.nofPasses)
 	{
 		case 1: SPA_L1_LAUNCH( p1); break;
@@ -713,7 +846,10 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 			else if (P.nofPasses <= 32) SPA_L1_LAUNCH( p32);
 			else return hipErrorInvalidValue;
 	}
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	if (lds > 65536) { e = hipFuncSetAttribute( (const void*)spa_l1_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+	hipLaunchKernelGGL( spa_l1_post_kernel, dim3( nblocks), dim3( nthreads), lds, stream, P);
 	return hipGetLastError();
 }
 }
-

@@ -61,5 +61,21 @@ __host__ __device__
 #endif
 uint32_t symbolHashStep( uint32_t h, uint32_t byte) { return (h ^ byte) * 16777619u; }
 
+// Hash of a whole-word literal: polynomial in the bytes, so that the kernel gets the hashes of all words of a
+// 64-byte tile with one segmented scan over the lanes (h = h*MUL + byte+1 per byte, then a finishing mix
+// because the low bits of a polynomial hash only see the low bits of the bytes); 0 is reserved for "empty".
+enum {L1_LITHASH_MUL=0x9E3779B1u};
+static inline
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+uint32_t literalHashFinish( uint32_t h)
+{
+	h ^= h >> 16; h *= 0x7feb352dU;
+	h ^= h >> 15; h *= 0x846ca68bU;
+	h ^= h >> 16;
+	return h ? h : 1u;
+}
+
 } // namespace
 #endif
