@@ -67,12 +67,14 @@ struct LexTab
 	__device__ __forceinline__ u64 at( u32 off) const { if (LDS) return ldsImage[ off]; else return g[ off]; }
 };
 
+struct EventLanes { u32 id, pos, size, lb; };	// one event per lane
+
 struct LexWave
 {
 	u32* queue;		// raw reports: 4 words {to, pattern, accLo, accHi}; after SOM word 2 holds `from`
 	Event* events;
 	u32 nQueue, nEvents, err, queueCap;
-	Event tail; bool tailValid;	// copy of events[nEvents-1] in scalar registers: most reports only touch the tail
+	EventLanes e; u32 cnt;	// the cnt most recent events, lane L holds event nEvents-1-L
 	const unsigned char* doc;
 	u32 docLen;
 #ifdef SPA_PROF
@@ -91,13 +93,13 @@ __device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* do
 struct LaneReport { u32 to, from, id, levelBind, prefixLen, suffixLen, pi; };	// one queued report per lane, pattern attributes attached
 
 template <bool LDS>
-__device__ void resolveStarts( LexWave& w, const L1Params& P, const LexTab<LDS>& T, u32 base, u32 count, LaneReport& out)
+__device__ __forceinline__ void resolveStarts( const u32* queue, const unsigned char* doc, u32 docLen, const L1Params& P, const LexTab<LDS>& T, u32 base, u32 count, LaneReport& out)
 {
 	u32 i = base + LANE;
 	out.to = 0; out.from = 0; out.id = 0; out.levelBind = 0; out.prefixLen = 0; out.suffixLen = 0; out.pi = 0;
 	if (LANE < count)
 	{
-		const uint4 q = *(const uint4*)(w.queue + 4*(u64)i);	// {to, pattern, accLo|from, accHi}
+		const uint4 q = *(const uint4*)(queue + 4*(u64)i);	// {to, pattern, accLo|from, accHi}
 		u32 to = q.x, pi = q.y & ~L1_LITERAL_FLAG;
 		const uint4 p0 = *(const uint4*)&P.patterns[ pi], p1 = *((const uint4*)&P.patterns[ pi] + 1);	// {id,word,levelBind,prefixLen} {suffixLen,maskLo,maskHi,-}
 		out.to = to; out.id = p0.x; out.levelBind = p0.z; out.prefixLen = p0.w; out.suffixLen = p1.x; out.pi = pi;
@@ -111,7 +113,7 @@ __device__ void resolveStarts( LexWave& w, const L1Params& P, const LexTab<LDS>&
 		long j = (long)to;			// R = positions that consumed byte j-1
 		while (R && j > 0)
 		{
-			int prevctx = ctxAt( P, w.doc, w.docLen, j-2);
+			int prevctx = ctxAt( P, doc, docLen, j-2);
 			if (R & T.at( T.oStart + (pass*CTX_COUNT + prevctx)*64 + ln)) from = (u32)(j-1);
 			if (j-1 == 0) break;
 			u64 Rp = ((R & shiftDst) >> 1) | (R & selfLoop);
@@ -121,7 +123,7 @@ __device__ void resolveStarts( LexWave& w, const L1Params& P, const LexTab<LDS>&
 				const u64 es = T.at( T.oExSrc + at), ed = T.at( T.oExDst + at);
 				Rp |= (R & ed) ? es : 0ull;
 			}
-			u32 cls = P.byteClass[ w.doc[ j-2]];
+			u32 cls = P.byteClass[ doc[ j-2]];
 			R = Rp & mask & T.at( (pass*P.nofClasses + cls)*64 + ln);
 			--j;
 		}
@@ -140,11 +142,11 @@ __device__ __forceinline__ void stEvent( Event* p, const Event& e)
 }
 
 // symbol lookup (PatternTable::symbolId, patternLexer.cpp:312-317): exact text of the match
-__device__ u32 lookupSymbol( const LexWave& w, const L1Params& P, u32 lexemId, u32 from, u32 len)
+__device__ u32 lookupSymbol( const unsigned char* doc, const L1Params& P, u32 lexemId, u32 from, u32 len)
 {
 	u32 h = 2166136261u;
 	for (u32 b=0; b<4; ++b) h = symbolHashStep( h, (lexemId >> (8*b)) & 0xFFu);
-	for (u32 k=0; k<len; ++k) h = symbolHashStep( h, uni( w.doc[ from+k]));
+	for (u32 k=0; k<len; ++k) h = symbolHashStep( h, uni( doc[ from+k]));
 	if (!h) h = 1;
 	u32 slot = h & P.symbolMask;
 	for (u32 probes=0; probes<=P.symbolMask; ++probes)
@@ -156,7 +158,7 @@ __device__ u32 lookupSymbol( const LexWave& w, const L1Params& P, u32 lexemId, u
 		{
 			u32 off = ldu( &s->textOffset);
 			bool same = true;
-			for (u32 k=0; k<len && same; ++k) same = (uni( P.symbolText[ off+k]) == uni( w.doc[ from+k]));
+			for (u32 k=0; k<len && same; ++k) same = (uni( P.symbolText[ off+k]) == uni( doc[ from+k]));
 			if (same) return ldu( &s->symbolId);
 		}
 		slot = (slot+1) & P.symbolMask;
@@ -164,79 +166,73 @@ __device__ u32 lookupSymbol( const LexWave& w, const L1Params& P, u32 lexemId, u
 	return 0;
 }
 
-__device__ void handleReport( LexWave& w, const L1Params& P, u32 id, u32 lb, u32 pre, u32 suf, u32 from, u32 to)
+// The reference's handler (patternLexer.cpp:727-822) edits its event array near the tail almost always.  The wave
+// keeps the most recent events in registers, one per lane: lane L holds event nEvents-1-L (L < cnt), the older
+// ones (indices < nEvents-cnt) are in the wave's arena in global memory.  The three scans of the handler (delete
+// pass, ignore pass, insertion point) become ballots over the lanes, element moves become wave shifts.  A scan
+// that would run past the registers into the arena is rare; it goes through handleReportArena on the whole array
+// in global memory, a literal restatement of the reference's loops.
+__device__ __forceinline__ u32 laneFromAbove( u32 v) { return (u32)__builtin_amdgcn_update_dpp( 0, (int)v, 0x130, 0xF, 0xF, false); }	// wave_shl:1, lane i <- lane i+1
+__device__ __forceinline__ u32 laneFromBelow( u32 v) { return (u32)__builtin_amdgcn_update_dpp( 0, (int)v, 0x138, 0xF, 0xF, false); }	// wave_shr:1, lane i <- lane i-1
+__device__ __forceinline__ u64 lowMask( u32 n) { return n ? (~0ull >> (64u - n)) : 0ull; }		// n <= 64
+
+// stage 0: the whole handler; stage 1: insertion only (the delete pass has already removed something)
+// returns the new number of events
+__device__ __noinline__ u32 handleReportArena( Event* events, u32 n, u32 stage, u32 id, u32 patternid, u32 levelBind, u32 from, u32 to)
 {
-	if (to - from >= 65535u) { w.err = L1D_ERR_LEXEMSIZE; return; }			// :727-730
-	if (lb & (1u<<17))										// sub expression selection
-	{
-		if (pre + suf > to - from) return;
-		from += pre; to -= suf;
-	}
-	u32 patternid = id;
-	if (lb & (1u<<16))
-	{
-		u32 sym = lookupSymbol( w, P, id, from, to-from);
-		if (sym) patternid = sym;
-	}
-	Event ev; ev.id = id; ev.origpos = from; ev.origsize = to-from; ev.levelBind = lb & 0xFFFFu;
-	const u32 level = lb & 0xFFu;
+	struct { Event* events; Event tail; bool tailValid; } w;
+	w.events = events; w.tailValid = false;
+	const u32 level = levelBind & 0xFFu;
 	const bool twin = (patternid != id);
-	u32 n = w.nEvents;
-	if (n + 2 > P.eventCap) { w.err = L1D_ERR_ARENA; return; }
+	Event ev; ev.id = id; ev.origpos = from; ev.origsize = to-from; ev.levelBind = levelBind;
 	if (n && !w.tailValid) { ldEvent( w.tail, &w.events[ n-1]); w.tailValid = true; }
 	if (n == 0)
 	{
-		stEvent( &w.events[0], ev); n = 1; w.tail = ev;
-		if (twin) { Event t = ev; t.id = patternid; stEvent( &w.events[1], t); n = 2; w.tail = t; }
-		w.nEvents = n; w.tailValid = true;
-		return;
+		stEvent( &w.events[0], ev); n = 1;
+		if (twin) { Event t = ev; t.id = patternid; stEvent( &w.events[1], t); n = 2; }
+		return n;
 	}
 	const u32 n0 = n;
-	// delete pass (:757-777): from the back while origpos >= the new origpos
 	const u32 lastPos = from + (to-from);
 	u32 nofDeletes = 0;
-	for (u32 k=n; k>0; --k)
+	if (stage == 0)
 	{
-		Event m;
-		if (k == n0 && w.tailValid) m = w.tail; else ldEvent( m, &w.events[ k-1]);
-		if (!(m.origpos >= ev.origpos)) break;
-		u32 mlevel = m.levelBind & 0xFFu;
-		if ((ev.id == m.id && m.origpos == ev.origpos && mlevel == level)
-		||  (mlevel < level && m.origpos + m.origsize <= lastPos))
-		{
-			// close the gap: lanes move the tail down by one (ascending order, distinct elements)
-			for (u32 t=k-1+LANE; t+1<n; t+=64)
-			{
-				Event x = w.events[ t+1];
-				__builtin_amdgcn_wave_barrier();
-				w.events[ t] = x;
-			}
-			--n; ++nofDeletes;
-			w.tailValid = false;
-		}
-	}
-	if (!nofDeletes)
-	{
-		// ignore pass (:778-792)
+		// delete pass (:757-777): from the back while origpos >= the new origpos
 		for (u32 k=n; k>0; --k)
 		{
 			Event m;
 			if (k == n0 && w.tailValid) m = w.tail; else ldEvent( m, &w.events[ k-1]);
-			if (!(m.origpos + m.origsize >= lastPos)) break;
-			if ((m.levelBind & 0xFFu) > level && m.origpos <= ev.origpos) { w.nEvents = n; return; }
+			if (!(m.origpos >= ev.origpos)) break;
+			u32 mlevel = m.levelBind & 0xFFu;
+			if ((ev.id == m.id && m.origpos == ev.origpos && mlevel == level)
+			||  (mlevel < level && m.origpos + m.origsize <= lastPos))
+			{
+				// close the gap: lanes move the tail down by one (ascending order, distinct elements)
+				for (u32 t=k-1+LANE; t+1<n; t+=64)
+				{
+					Event x = w.events[ t+1];
+					__builtin_amdgcn_wave_barrier();
+					w.events[ t] = x;
+				}
+				--n; ++nofDeletes;
+				w.tailValid = false;
+			}
+		}
+		if (!nofDeletes)
+		{
+			// ignore pass (:778-792)
+			for (u32 k=n; k>0; --k)
+			{
+				Event m;
+				if (k == n0 && w.tailValid) m = w.tail; else ldEvent( m, &w.events[ k-1]);
+				if (!(m.origpos + m.origsize >= lastPos)) break;
+				if ((m.levelBind & 0xFFu) > level && m.origpos <= ev.origpos) return n;
+			}
 		}
 	}
 	// insert (:793-822), literal element moves of the reference (see oracle/l1_oracle.cpp for the
 	// two-slot quirk of the symbol twin variant)
 	const u32 newSlots = twin ? 2u : 1u;
-	if (!nofDeletes && w.tailValid && !(w.tail.origpos > ev.origpos))
-	{
-		// common case: the new event goes behind the current tail, nothing moves
-		stEvent( &w.events[ n], ev); w.tail = ev;
-		if (twin) { Event t = ev; t.id = patternid; stEvent( &w.events[ n+1], t); w.tail = t; }
-		w.nEvents = n + newSlots;
-		return;
-	}
 	Event zero; zero.id = 0; zero.origpos = 0; zero.origsize = 0; zero.levelBind = 0;
 	for (u32 s=0; s<newSlots; ++s) stEvent( &w.events[ n+s], zero);
 	long prev = (long)n + (long)newSlots - 1, mi = (long)n - 1;
@@ -249,11 +245,114 @@ __device__ void handleReport( LexWave& w, const L1Params& P, u32 id, u32 lb, u32
 	++mi;
 	stEvent( &w.events[ mi], ev);
 	if (twin) { Event t = ev; t.id = patternid; stEvent( &w.events[ mi+1], t); }
-	w.nEvents = n + newSlots;
-	w.tailValid = false;		// reloaded on the next report
+	return n + newSlots;
 }
 
-// four text bytes from an arbitrary address (global memory takes unaligned dword loads)
+// the lanes [keep, cnt) go to the arena
+__device__ __forceinline__ void spillLanes( LexWave& w, u32 keep)
+{
+	if (LANE >= keep && LANE < w.cnt) *(uint4*)&w.events[ w.nEvents - 1u - LANE] = make_uint4( w.e.id, w.e.pos, w.e.size, w.e.lb);
+	w.cnt = keep < w.cnt ? keep : w.cnt;
+}
+__device__ __forceinline__ void reloadLanes( LexWave& w)
+{
+	enum {RELOAD=32};
+	w.cnt = w.nEvents < (u32)RELOAD ? w.nEvents : (u32)RELOAD;
+	uint4 x = make_uint4( 0, 0, 0, 0);
+	if (LANE < w.cnt) x = *(const uint4*)&w.events[ w.nEvents - 1u - LANE];
+	w.e.id = x.x; w.e.pos = x.y; w.e.size = x.z; w.e.lb = x.w;
+}
+__device__ __forceinline__ void pushEvent( LexWave& w, u32 at, u32 id, u32 pos, u32 size, u32 lb)
+{
+	// lanes above `at` take their lower neighbour's event, lane `at` the new one
+	const u32 a = laneFromBelow( w.e.id), b = laneFromBelow( w.e.pos), c = laneFromBelow( w.e.size), d = laneFromBelow( w.e.lb);
+	const bool up = LANE > at, here = LANE == at;
+	w.e.id = up ? a : (here ? id : w.e.id);
+	w.e.pos = up ? b : (here ? pos : w.e.pos);
+	w.e.size = up ? c : (here ? size : w.e.size);
+	w.e.lb = up ? d : (here ? lb : w.e.lb);
+	++w.cnt; ++w.nEvents;
+}
+
+__device__ __forceinline__ void handleReport( LexWave& w, const L1Params& P, u32 id, u32 lb, u32 pre, u32 suf, u32 from, u32 to)
+{
+	if (to - from >= 65535u) { w.err = L1D_ERR_LEXEMSIZE; return; }			// :727-730
+	if (lb & (1u<<17))										// sub expression selection
+	{
+		if (pre + suf > to - from) return;
+		from += pre; to -= suf;
+	}
+	u32 patternid = id;
+	if (lb & (1u<<16))
+	{
+		const u32 sym = uni( lookupSymbol( w.doc, P, id, from, to-from));	// (a call's result counts as lane-varying unless told otherwise)
+		if (sym) patternid = sym;
+	}
+	const u32 levelBind = lb & 0xFFFFu, level = lb & 0xFFu;
+	const bool twin = (patternid != id);
+	if (w.nEvents + 2 > P.eventCap) { w.err = L1D_ERR_ARENA; return; }
+	if (w.cnt >= 62u) spillLanes( w, 32);
+	const bool more = w.nEvents > w.cnt;		// older events in the arena
+	const u32 lastPos = to;
+	u32 stage = 0;
+	bool arena = false;
+	{
+		const u32 cnt = w.cnt;
+		const u64 valid = lowMask( cnt);
+		const u32 lvlL = w.e.lb & 0xFFu, endL = w.e.pos + w.e.size;
+		// delete pass (:757-777): the run of events from the back with origpos >= the new origpos
+		const u64 ge = __ballot( w.e.pos >= from) & valid;
+		const u32 run = (u32)__builtin_ctzll( ~ge);
+		if (run == cnt && more) arena = true;
+		else
+		{
+			u64 del = __ballot( (w.e.id == id && w.e.pos == from && lvlL == level) || (lvlL < level && endL <= lastPos)) & lowMask( run);
+			if (del)
+			{
+				stage = 1;
+				while (del)
+				{
+					// remove the highest lane of the set: the lanes from there on take their upper neighbour's event
+					const u32 d = 63u - (u32)__builtin_clzll( del);
+					del &= ~(1ull << d);
+					const u32 a = laneFromAbove( w.e.id), b = laneFromAbove( w.e.pos), c = laneFromAbove( w.e.size), e = laneFromAbove( w.e.lb);
+					const bool dn = LANE >= d;
+					w.e.id = dn ? a : w.e.id; w.e.pos = dn ? b : w.e.pos; w.e.size = dn ? c : w.e.size; w.e.lb = dn ? e : w.e.lb;
+					--w.cnt; --w.nEvents;
+				}
+			}
+			else
+			{
+				// ignore pass (:778-792): the run of events from the back that end at or behind the new end
+				const u64 ge2 = __ballot( endL >= lastPos) & valid;
+				const u32 run2 = (u32)__builtin_ctzll( ~ge2);
+				if (run2 == cnt && more) arena = true;
+				else if (__ballot( lvlL > level && w.e.pos <= from) & lowMask( run2)) return;
+			}
+		}
+	}
+	u32 at = 0;
+	if (!arena)
+	{
+		// insertion point (:793-822): behind the events from the back that start to the right of the new one
+		const u64 gt = __ballot( w.e.pos > from) & lowMask( w.cnt);
+		at = (u32)__builtin_ctzll( ~gt);
+		if ((at == w.cnt && more) || (twin && at)) arena = true;
+	}
+	if (arena)
+	{
+		spillLanes( w, 0);
+		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+		const u32 n = uni( handleReportArena( w.events, w.nEvents, stage, id, patternid, levelBind, from, to));
+		__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront");
+		w.nEvents = n;
+		reloadLanes( w);
+		return;
+	}
+	pushEvent( w, at, id, from, to-from, levelBind);
+	if (twin) pushEvent( w, 0, patternid, from, to-from, levelBind);
+}
+
 __device__ __forceinline__ u32 ld32u( const unsigned char* p) { u32 v; __builtin_memcpy( &v, p, 4); return v; }
 
 // The literals of one 64-byte tile, all lanes at once.  Lane l holds byte tile+l: the runs of word characters of
@@ -424,7 +523,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 			}
 			if (__ballot( anyAcc != 0))
 			{
-				u64 tHit = PROF_T();
+				
 #pragma unroll
 				for (int p=0; p<PASSES; ++p)
 				{
@@ -513,7 +612,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 					}
 				}
-				PROF_ACC( 2, tHit);
+				
 			}
 			prevctx = ctx;
 		};
@@ -537,17 +636,21 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 	u32 qi = 0, qb = 0, qn = 0;		// next report; the batch [qb, qb+qn) is resolved in lr
 	LaneReport lr;
 	lr.to = 0; lr.from = 0; lr.id = 0; lr.levelBind = 0; lr.prefixLen = 0; lr.suffixLen = 0; lr.pi = 0;
-	if (nq) { qn = nq < 64u ? nq : 64u; resolveStarts( w, P, T, 0, qn, lr); }
+	if (nq) { qn = nq < 64u ? nq : 64u; resolveStarts( w.queue, w.doc, w.docLen, P, T, 0, qn, lr); }
+	u32 ahead = (LANE < len) ? w.doc[ LANE] : 0u;		// the next tile's bytes are loaded one tile ahead
 	for (u32 tile=0; tile<=len && !w.err; tile+=64)
 	{
-		const u32 mine = (tile + LANE < len) ? w.doc[ tile + LANE] : 0u;
+		const u32 mine = ahead;
+		ahead = (tile + 64 + LANE < len) ? w.doc[ tile + 64 + LANE] : 0u;
 		const u32 inTile = (len - tile) < 64 ? (len - tile) : 64;
 		u64 litEnds = 0; u32 litFrom = 0, litBegin = 0, litCount = 0, litPi0 = 0, litId0 = 0, litLb0 = 0;
 		if (P.nofLiterals)
 		{
 			const u32 shm = (mine & 3u)*8;
 			const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> shm) & 0xFFu;
+			const u64 tLit = PROF_T();
 			tileLiterals( w, P, tile, mine, LANE < inTile && ctxL == (u32)CTX_WORD, carry, litEnds, litFrom, litBegin, litCount, litPi0, litId0, litLb0);
+			PROF_ACC( 1, tLit);
 			litEnds &= __ballot( litCount != 0);
 		}
 		// every report that ends inside this tile: end offsets tile .. tile+63 (a full tile) or .. len (the last one)
@@ -569,12 +672,21 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 			u32 lid = pc ? (u32)__builtin_amdgcn_readlane( litId0, kL) : 0u, llb = pc ? (u32)__builtin_amdgcn_readlane( litLb0, kL) : 0u;
 			while (!w.err)
 			{
+				const u32 x = qi - qb;
 				u32 api = 0xFFFFFFFFu;
-				if (qi < nq && (u32)__builtin_amdgcn_readlane( lr.to, qi - qb) == toNext) api = (u32)__builtin_amdgcn_readlane( lr.pi, qi - qb);
+				if (qi < nq && (u32)__builtin_amdgcn_readlane( lr.to, x) == toNext) api = (u32)__builtin_amdgcn_readlane( lr.pi, x);
 				if (api == 0xFFFFFFFFu && lj >= pc) break;
-				if (lj < pc && lpi < api)
+				const bool lit = (lj < pc && lpi < api);
+				const u32 hid = lit ? lid : (u32)__builtin_amdgcn_readlane( lr.id, x);
+				const u32 hlb = lit ? llb : (u32)__builtin_amdgcn_readlane( lr.levelBind, x);
+				const u32 hpre = lit ? 0u : (u32)__builtin_amdgcn_readlane( lr.prefixLen, x);
+				const u32 hsuf = lit ? 0u : (u32)__builtin_amdgcn_readlane( lr.suffixLen, x);
+				const u32 hfrom = lit ? lfrom : (u32)__builtin_amdgcn_readlane( lr.from, x);
+				const u64 tH = PROF_T();
+				handleReport( w, P, hid, hlb, hpre, hsuf, hfrom, toNext);
+				PROF_ACC( 3, tH);
+				if (lit)
 				{
-					handleReport( w, P, lid, llb, 0, 0, lfrom, toNext);
 					++lj;
 					if (lj < pc)
 					{
@@ -585,15 +697,13 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 				}
 				else
 				{
-					const u32 x = qi - qb;
-					handleReport( w, P, (u32)__builtin_amdgcn_readlane( lr.id, x), (u32)__builtin_amdgcn_readlane( lr.levelBind, x),
-							(u32)__builtin_amdgcn_readlane( lr.prefixLen, x), (u32)__builtin_amdgcn_readlane( lr.suffixLen, x),
-							(u32)__builtin_amdgcn_readlane( lr.from, x), toNext);
 					++qi;
 					if (qi == qb + qn && qi < nq)
 					{
 						qb = qi; qn = (nq - qb) < 64u ? (nq - qb) : 64u;
-						resolveStarts( w, P, T, qb, qn, lr);
+						const u64 tR = PROF_T();
+						resolveStarts( w.queue, w.doc, w.docLen, P, T, qb, qn, lr);
+						PROF_ACC( 2, tR);
 					}
 				}
 			}
@@ -730,7 +840,7 @@ __device__ void scanDocuments( const L1Params& P)
 	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
 	LexWave w;
-	w.events = 0; w.nEvents = 0; w.tailValid = false;
+	w.events = 0; w.nEvents = 0; w.cnt = 0;
 	// every wave starts with document `waveSlot` and takes its next ones from a device-side cursor;
 	// the loop is bounded so that it ends whatever the cursor holds
 	for (u32 round=0; round<=P.ndocs; ++round)
@@ -776,6 +886,9 @@ __device__ void postDocuments( const L1Params& P)
 	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
 	LexWave w;
 	w.events = (Event*)(P.arenaBase + (u64)waveSlot * P.arenaWords);
+#ifdef SPA_PROF
+	for (int k=0; k<4; ++k) w.prof[ k] = 0;
+#endif
 	for (u32 round=0; round<=P.ndocs; ++round)
 	{
 		u32 doc = waveSlot;
@@ -792,11 +905,15 @@ __device__ void postDocuments( const L1Params& P)
 		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
 		w.queue = P.reportQueue + 4*queueBase( P, beg, doc);
 		w.nQueue = ldu( &P.reportCount[ doc]);
-		w.queueCap = w.nQueue; w.nEvents = 0; w.err = 0; w.tailValid = false;
+		w.queueCap = w.nQueue; w.nEvents = 0; w.err = 0; w.cnt = 0;
+		w.e.id = 0; w.e.pos = 0; w.e.size = 0; w.e.lb = 0;
+		const u64 tDoc = PROF_T();
 		postDocument<LDS>( w, P, T);
+		spillLanes( w, 0);
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		if (!w.err) emitLexems( w, P, doc);
 		else if (LANE == 0) { P.docRange[ 2*(u64)doc] = 0; P.docRange[ 2*(u64)doc+1] = 0; }
+		PROF_ACC( 0, tDoc);
 		if (LANE == 0)
 		{
 			P.docStatus[ doc] = (int32_t)w.err;
@@ -804,6 +921,9 @@ __device__ void postDocuments( const L1Params& P)
 			if (w.err) atomicAdd( (unsigned long long*)&P.counters[ L1C_FAILED], 1ull);
 		}
 	}
+#ifdef SPA_PROF
+	if (LANE == 0) for (int k=0; k<4; ++k) atomicAdd( (unsigned long long*)&P.counters[ 4+k], (unsigned long long)w.prof[ k]);
+#endif
 }
 
 } // anonymous namespace
@@ -822,7 +942,9 @@ SPA_L1_KERNEL( p7, 7, 1024)
 SPA_L1_KERNEL( p8, 8, 1024)
 SPA_L1_KERNEL( p16, 16, 256)
 SPA_L1_KERNEL( p32, 32, 256)
-extern "C" __global__ __launch_bounds__(1024) void spa_l1_post_kernel( L1Params P) { if (P.ldsWords) postDocuments<true>( P); else postDocuments<false>( P); }
+// the post-processing kernel reads the automaton's tables from global memory (start of match only)
+enum {POST_WAVES=4};
+extern "C" __global__ __launch_bounds__(64*POST_WAVES) void spa_l1_post_kernel( L1Params P) { postDocuments<false>( P); }
 
 namespace spa {
 hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, hipStream_t stream)
@@ -848,8 +970,8 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 	}
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	if (lds > 65536) { e = hipFuncSetAttribute( (const void*)spa_l1_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
-	hipLaunchKernelGGL( spa_l1_post_kernel, dim3( nblocks), dim3( nthreads), lds, stream, P);
+	// the same number of waves (one arena slot each), in workgroups of POST_WAVES
+	hipLaunchKernelGGL( spa_l1_post_kernel, dim3( (nblocks * (nthreads/64) + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
 	return hipGetLastError();
 }
 }

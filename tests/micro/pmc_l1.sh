@@ -1,5 +1,5 @@
 #!/bin/bash
-# instruction mix of the L1 kernel on the 10k-regex set (separate counter passes; run on the GPU box from the repo root)
+# instruction mix of the two L1 kernels (scan, post) on the 10k-regex set (separate counter passes; run on the GPU box from the repo root)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/pmc_l1
@@ -14,7 +14,9 @@ for run in "abc":
     for f in glob.glob("gpurun_out/pmc_l1/%s/**/*counter_collection.csv" % run, recursive=True):
         acc = collections.defaultdict(float); n = collections.Counter()
         for r in csv.DictReader(open(f)):
-            if "l1_lex" in r["Kernel_Name"]:
-                acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
-        for k in acc: print(run, k, "per launch %.4g (%d launches)" % (acc[k] / n[k], n[k]))
+            kn = r["Kernel_Name"]
+            if "spa_l1_" in kn:
+                key = ("scan" if "scan" in kn else "post", r["Counter_Name"])
+                acc[key] += float(r["Counter_Value"]); n[key] += 1
+        for k in sorted(acc): print(run, k[0], k[1], "per launch %.4g (%d launches)" % (acc[k] / n[k], n[k]))
 PY
