@@ -1100,6 +1100,8 @@ void LexCompiler::compile()
 			e.patBegin = (uint32_t)T.litPats.size(); e.patCount = (uint32_t)li->second.size();
 			T.literalText.insert( T.literalText.end(), li->first.begin(), li->first.end());
 			T.litPats.insert( T.litPats.end(), li->second.begin(), li->second.end());	// definition order = ascending
+			e.pat0 = li->second.front(); e.id0 = T.patterns[ e.pat0].id; e.levelBind0 = T.patterns[ e.pat0].levelBind;
+			for (size_t k=0; k<li->first.size() && k<sizeof(e.text); ++k) e.text[ k] = (uint8_t)li->first[ k];
 			size_t slot = h & (size-1);
 			while (T.literals[ slot].hash) slot = (slot+1) & (size-1);
 			T.literals[ slot] = e;
@@ -1139,7 +1141,7 @@ void LexCompiler::compile()
 }
 
 // ---------------------------------------------------------------- compiled tables as a blob
-static const char L1_MAGIC[ 9] = "SPAL1v01";
+static const char L1_MAGIC[ 9] = "SPAL1v02";
 
 void LexCompiler::save( std::vector<uint8_t>& out) const
 {

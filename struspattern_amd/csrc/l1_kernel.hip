@@ -75,6 +75,7 @@ struct LexWave
 	Event* events;
 	u32 nQueue, nEvents, err, queueCap;
 	EventLanes e; u32 cnt;	// the cnt most recent events, lane L holds event nEvents-1-L
+	u32 tailPos, tailEnd;	// start and end of the last event (lane 0), valid while cnt > 0
 	const unsigned char* doc;
 	u32 docLen;
 #ifdef SPA_PROF
@@ -272,6 +273,11 @@ __device__ __forceinline__ void pushEvent( LexWave& w, u32 at, u32 id, u32 pos, 
 	w.e.size = up ? c : (here ? size : w.e.size);
 	w.e.lb = up ? d : (here ? lb : w.e.lb);
 	++w.cnt; ++w.nEvents;
+	if (at == 0) { w.tailPos = pos; w.tailEnd = pos + size; }
+}
+__device__ __forceinline__ void readTail( LexWave& w)
+{
+	w.tailPos = (u32)__builtin_amdgcn_readlane( w.e.pos, 0); w.tailEnd = w.tailPos + (u32)__builtin_amdgcn_readlane( w.e.size, 0);
 }
 
 __device__ __forceinline__ void handleReport( LexWave& w, const L1Params& P, u32 id, u32 lb, u32 pre, u32 suf, u32 from, u32 to)
@@ -292,6 +298,13 @@ __device__ __forceinline__ void handleReport( LexWave& w, const L1Params& P, u32
 	const bool twin = (patternid != id);
 	if (w.nEvents + 2 > P.eventCap) { w.err = L1D_ERR_ARENA; return; }
 	if (w.cnt >= 62u) spillLanes( w, 32);
+	if (w.nEvents == 0 || (w.cnt && w.tailPos < from && w.tailEnd < to))
+	{
+		// most reports of a new token: the last event starts and ends before it, all three scans stop at once
+		pushEvent( w, 0, id, from, to-from, levelBind);
+		if (twin) pushEvent( w, 0, patternid, from, to-from, levelBind);
+		return;
+	}
 	const bool more = w.nEvents > w.cnt;		// older events in the arena
 	const u32 lastPos = to;
 	u32 stage = 0;
@@ -320,6 +333,7 @@ __device__ __forceinline__ void handleReport( LexWave& w, const L1Params& P, u32
 					w.e.id = dn ? a : w.e.id; w.e.pos = dn ? b : w.e.pos; w.e.size = dn ? c : w.e.size; w.e.lb = dn ? e : w.e.lb;
 					--w.cnt; --w.nEvents;
 				}
+				readTail( w);
 			}
 			else
 			{
@@ -347,6 +361,7 @@ __device__ __forceinline__ void handleReport( LexWave& w, const L1Params& P, u32
 		__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront");
 		w.nEvents = n;
 		reloadLanes( w);
+		readTail( w);
 		return;
 	}
 	pushEvent( w, at, id, from, to-from, levelBind);
@@ -354,6 +369,7 @@ __device__ __forceinline__ void handleReport( LexWave& w, const L1Params& P, u32
 }
 
 __device__ __forceinline__ u32 ld32u( const unsigned char* p) { u32 v; __builtin_memcpy( &v, p, 4); return v; }
+__device__ __forceinline__ uint4 ld128u( const unsigned char* p) { uint4 v; __builtin_memcpy( &v, p, 16); return v; }
 
 // The literals of one 64-byte tile, all lanes at once.  Lane l holds byte tile+l: the runs of word characters of
 // the tile come out of one ballot, their hashes out of one segmented scan (polynomial hash, l1_tables.h), and every
@@ -390,14 +406,28 @@ __device__ __forceinline__ void tileLiterals(  const LexWave& w, const L1Params&
 	{
 		const u32 h = literalHashFinish( pH);
 		u32 slot = h & P.literalMask;
+		// the word's first 16 bytes, read once beside the first probe (the table entry carries its own first 16)
+		uint4 dw = make_uint4( 0, 0, 0, 0);
+		if (pFrom + 16u <= w.docLen) dw = ld128u( w.doc + pFrom);
+		else
+		{
+			u32 d[ 4] = {0,0,0,0};
+			for (u32 q=0; q<16u && pFrom+q<w.docLen; ++q) d[ q>>2] |= (u32)w.doc[ pFrom + q] << (8*(q&3u));
+			dw = make_uint4( d[0], d[1], d[2], d[3]);
+		}
+		const u32 m0 = pLen >= 4u ? 0xFFFFFFFFu : ((1u << (8*pLen)) - 1u);
+		const u32 m1 = pLen >= 8u ? 0xFFFFFFFFu : (pLen > 4u ? ((1u << (8*(pLen-4u))) - 1u) : 0u);
+		const u32 m2 = pLen >= 12u ? 0xFFFFFFFFu : (pLen > 8u ? ((1u << (8*(pLen-8u))) - 1u) : 0u);
+		const u32 m3 = pLen >= 16u ? 0xFFFFFFFFu : (pLen > 12u ? ((1u << (8*(pLen-12u))) - 1u) : 0u);
 		for (u32 probes=0; probes<=P.literalMask; ++probes)
 		{
-			const uint4 e = *(const uint4*)&P.literals[ slot];		// {hash, textOffset, len, patBegin}
-			if (!e.x) break;
-			if (e.x == h && e.z == pLen)
+			const uint4* ep = (const uint4*)&P.literals[ slot];
+			const uint4 e0 = ep[ 0], e1 = ep[ 1], tx = ep[ 2];	// {hash, len, patBegin, patCount} {pat0, id0, levelBind0, textOffset} {text}
+			if (!e0.x) break;
+			if (e0.x == h && e0.y == pLen)
 			{
-				bool same = true;
-				for (u32 k=0; k<pLen && same; k+=4)
+				bool same = (((dw.x ^ tx.x) & m0) | ((dw.y ^ tx.y) & m1) | ((dw.z ^ tx.z) & m2) | ((dw.w ^ tx.w) & m3)) == 0;
+				for (u32 k=16; k<pLen && same; k+=4)		// (a word beyond 16 bytes: the rest from the text pool)
 				{
 					const u32 rem = pLen - k;
 					u32 a;
@@ -407,17 +437,13 @@ __device__ __forceinline__ void tileLiterals(  const LexWave& w, const L1Params&
 						a = 0;
 						for (u32 q=0; q<rem && q<4u; ++q) a |= (u32)w.doc[ pFrom + k + q] << (8*q);
 					}
-					const u32 b = ld32u( P.literalText + e.y + k);
+					const u32 b = ld32u( P.literalText + e1.w + k);
 					const u32 mask = rem >= 4u ? 0xFFFFFFFFu : ((1u << (8*rem)) - 1u);
 					same = ((a ^ b) & mask) == 0;
 				}
 				if (same)
 				{
-					// (almost every literal defines one pattern: its attributes come along, the handler needs no further load)
-					litBegin = e.w; litCount = P.literals[ slot].patCount;
-					litPi0 = P.litPats[ e.w];
-					const uint4 p0 = *(const uint4*)&P.patterns[ litPi0];	// {id, word, levelBind, prefixLen}
-					litId0 = p0.x; litLb0 = p0.z;
+					litBegin = e0.z; litCount = e0.w; litPi0 = e1.x; litId0 = e1.y; litLb0 = e1.z;
 					break;
 				}
 			}
@@ -840,7 +866,7 @@ __device__ void scanDocuments( const L1Params& P)
 	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
 	LexWave w;
-	w.events = 0; w.nEvents = 0; w.cnt = 0;
+	w.events = 0; w.nEvents = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
 	// every wave starts with document `waveSlot` and takes its next ones from a device-side cursor;
 	// the loop is bounded so that it ends whatever the cursor holds
 	for (u32 round=0; round<=P.ndocs; ++round)
@@ -905,7 +931,7 @@ __device__ void postDocuments( const L1Params& P)
 		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
 		w.queue = P.reportQueue + 4*queueBase( P, beg, doc);
 		w.nQueue = ldu( &P.reportCount[ doc]);
-		w.queueCap = w.nQueue; w.nEvents = 0; w.err = 0; w.cnt = 0;
+		w.queueCap = w.nQueue; w.nEvents = 0; w.err = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
 		w.e.id = 0; w.e.pos = 0; w.e.size = 0; w.e.lb = 0;
 		const u64 tDoc = PROF_T();
 		postDocument<LDS>( w, P, T);

@@ -43,14 +43,17 @@ struct DevSymbol		// 32 B, open addressing (linear probing), hash==0 = empty
 	uint32_t _pad[3];
 };
 
-struct DevLiteral		// 32 B, open addressing, hash==0 = empty: a whole-word literal and the patterns defined by it
+struct DevLiteral		// 48 B, open addressing, hash==0 = empty: a whole-word literal and the patterns defined by it
 {
 	uint32_t hash;
-	uint32_t textOffset;	// into the literal text pool
 	uint32_t len;
 	uint32_t patBegin;	// litPats[patBegin .. patBegin+patCount): pattern indices, ascending
 	uint32_t patCount;
-	uint32_t _pad[3];
+	uint32_t pat0;		// the first pattern and what the handler needs of it: one probe answers the common case
+	uint32_t id0;
+	uint32_t levelBind0;
+	uint32_t textOffset;	// into the literal text pool
+	uint8_t text[ 16];	// the first 16 bytes of the word, zero padded
 };
 
 // FNV-1a step used for the symbol hash (lexem id first, then the text bytes); 0 is reserved for
