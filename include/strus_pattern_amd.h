@@ -302,6 +302,9 @@ int sp_lexer_ctx_batch_fetch_docs(sp_lexer_ctx_t* c, size_t first_doc, size_t nd
 int sp_lexer_ctx_batch_counters(sp_lexer_ctx_t* c, uint64_t counters[8]);
 int sp_lexer_ctx_batch_status(sp_lexer_ctx_t* c, int32_t* status, size_t ndocs);
 double sp_lexer_ctx_last_kernel_ms(sp_lexer_ctx_t* c);
+/* the same interval split at the boundary of the lexer's two kernels (automaton scan; literals + start of match +
+ * handler + ordinal positions) */
+int sp_lexer_ctx_last_kernel_ms_split(sp_lexer_ctx_t* c, double* scan_ms, double* post_ms);
 int sp_lexer_ctx_reserve_output(sp_lexer_ctx_t* c, uint64_t lexems);
 int sp_lexer_ctx_grow_arena(sp_lexer_ctx_t* c);
 

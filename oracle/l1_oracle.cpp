@@ -723,15 +723,235 @@ void LexerInstance::defineOption( const std::string& name, double)
 	else throw std::runtime_error( "unknown option '" + name + "'");
 }
 
-// patternLexer.cpp:1068-1118 + :333-412.  Edit distance / BYTECHAR / UCP / ALLOWEMPTY belong to the
-// "next" rows of SURVEY.md 8(f) and are rejected here.
+// ------------------------------------------------------------------ approximate literal tables
+// A table with at least one `~N` expression takes the reference's other route through its two libraries
+// (patternLexer.cpp:333-412): EVERY expression is pre-matched by Hyperscan on the one-byte-per-character
+// hash of the text (OneByteCharMap, unicodeUtils.cpp:19-44: a character <= 127 is itself, any other is
+// 128 + code point % 128) and every candidate is re-matched by libtre on wide characters
+// (SubExpressionDef, :450-601).  Restated for expressions that are plain literals:
+//   stage 1 (Hyperscan, approximate matching with leftmost start of match): for every pattern and every
+//     character end position e, a candidate (s,e) exists when some s < e has
+//     levenshtein( hash(text[s:e]), hash(literal)) <= N; s is the smallest such start (N = 0: the
+//     hashed literal itself ends at e).  Candidates are delivered by end position, then pattern index.
+//   stage 2 (libtre): an edit distance pattern is searched approximately (unit costs, maximum cost
+//     N+3, :527-535) in the window of the candidate's bytes plus N*4 further bytes (:561); an exact
+//     pattern is searched exactly from the candidate's start to the end of the document and must end
+//     inside the candidate (:505).  The match found replaces the candidate's (from,to).
+// MODEL (what libtre returns among several approximate matches is not derivable from the reference's
+// sources): the window is read left to right with the usual states (pattern characters consumed, cost,
+// start); pattern characters may be skipped (cost 1) before a character is read; a match is recorded
+// when the last pattern character is consumed by reading a character (exactly or as a substitution), or
+// at the end of the window; a later match replaces the recorded one only if it is strictly cheaper.
+// This reproduces both vectors of testCharRegexMatch.cpp:161-196, which is all that pins it.
+static bool decodeChar( const unsigned char* s, size_t len, size_t at, uint32_t& cp, unsigned& n)
+{
+	// lenient UTF-8: a lead byte with all its continuation bytes is one character, any other byte is a
+	// character of its own value
+	unsigned char c = s[ at];
+	n = 1; cp = c;
+	unsigned want = (c >= 0xC2 && c <= 0xDF) ? 2 : (c >= 0xE0 && c <= 0xEF) ? 3 : (c >= 0xF0 && c <= 0xF4) ? 4 : 1;
+	if (want == 1 || at + want > len) return true;
+	uint32_t v = c & (0xFFu >> (want+1));
+	for (unsigned i=1; i<want; ++i)
+	{
+		if ((s[ at+i] & 0xC0) != 0x80) return true;
+		v = (v << 6) | (s[ at+i] & 0x3F);
+	}
+	cp = v; n = want;
+	return true;
+}
+static inline uint32_t oneByteHash( uint32_t cp) { return cp <= 127 ? cp : 128 + (cp % 128); }
+
+static unsigned levenshtein( const uint32_t* a, size_t na, const uint32_t* b, size_t nb)
+{
+	std::vector<unsigned> prev( nb+1), cur( nb+1);
+	for (size_t j=0; j<=nb; ++j) prev[ j] = (unsigned)j;
+	for (size_t i=1; i<=na; ++i)
+	{
+		cur[ 0] = (unsigned)i;
+		for (size_t j=1; j<=nb; ++j)
+		{
+			unsigned v = prev[ j-1] + (a[ i-1] != b[ j-1] ? 1u : 0u);
+			if (prev[ j] + 1 < v) v = prev[ j] + 1;
+			if (cur[ j-1] + 1 < v) v = cur[ j-1] + 1;
+			cur[ j] = v;
+		}
+		prev.swap( cur);
+	}
+	return prev[ nb];
+}
+
+// the second stage's approximate search: (start, end) in characters of `w`, false if nothing within maxCost
+static bool approxSearch( const std::vector<uint32_t>& w, const std::vector<uint32_t>& lit, unsigned maxCost, size_t& ms, size_t& me)
+{
+	const size_t m = lit.size();
+	const unsigned NONE = 0xFFFFFFFFu;
+	std::vector<unsigned> cost( m+1, NONE), ncost( m+1, NONE);
+	std::vector<size_t> start( m+1, 0), nstart( m+1, 0);
+	bool have = false; unsigned best = NONE;
+	size_t pos = 0;
+	for (;;)
+	{
+		if (!have || best > 0)
+		{
+			if (cost[ 0] == NONE || cost[ 0] > 0) { cost[ 0] = 0; start[ 0] = pos; }
+		}
+		// pattern characters skipped
+		for (size_t k=0; k<m; ++k)
+		{
+			if (cost[ k] == NONE) continue;
+			unsigned c = cost[ k] + 1;
+			if (c > maxCost || (have && c >= best)) continue;
+			if (cost[ k+1] == NONE || c < cost[ k+1]) { cost[ k+1] = c; start[ k+1] = start[ k]; }
+		}
+		if (pos == w.size())
+		{
+			if (cost[ m] != NONE && (!have || cost[ m] < best)) { have = true; best = cost[ m]; ms = start[ m]; me = pos; }
+			break;
+		}
+		const uint32_t ch = w[ pos]; ++pos;
+		std::fill( ncost.begin(), ncost.end(), NONE);
+		for (size_t k=0; k<m; ++k)			// (the final state has no transitions)
+		{
+			if (cost[ k] == NONE) continue;
+			// the character is the next pattern character, or stands for it
+			{
+				unsigned c = cost[ k] + (ch != lit[ k] ? 1u : 0u);
+				if (c <= maxCost && !(have && c >= best))
+				{
+					if (ncost[ k+1] == NONE || c < ncost[ k+1]) { ncost[ k+1] = c; nstart[ k+1] = start[ k]; }
+					if (k+1 == m && (!have || c < best)) { have = true; best = c; ms = start[ k]; me = pos; }
+				}
+			}
+			// the character is an extra one
+			{
+				unsigned c = cost[ k] + 1;
+				if (c <= maxCost && !(have && c >= best))
+				{
+					if (ncost[ k] == NONE || c < ncost[ k]) { ncost[ k] = c; nstart[ k] = start[ k]; }
+				}
+			}
+		}
+		cost.swap( ncost); start.swap( nstart);
+	}
+	return have;
+}
+
+bool LexerInstance::approxSecondStage( const char* src, size_t len, const ApproxCandidate& c, uint32_t& from, uint32_t& to) const
+{
+	const Def& def = m_defs[ c.idx-1];
+	const std::vector<uint32_t>& lit = m_literal[ c.idx-1];
+	const unsigned char* s = (const unsigned char*)src;
+	if (def.editdist)
+	{
+		// WCharString( src+from, to-from + editdist*sizeof(wchar_t)) (:561): whole characters of that many bytes
+		size_t wend = (size_t)c.to + 4u * def.editdist;
+		if (wend > len) wend = len;
+		std::vector<uint32_t> w; std::vector<size_t> off;
+		for (size_t at=c.from; at<wend;)
+		{
+			uint32_t cp; unsigned n; decodeChar( s, wend, at, cp, n);
+			off.push_back( at); w.push_back( cp); at += n;
+		}
+		off.push_back( wend);
+		size_t ms, me;
+		if (!approxSearch( w, lit, def.editdist + 3, ms, me)) return false;
+		from = (uint32_t)off[ ms]; to = (uint32_t)off[ me];
+		return true;
+	}
+	// exact re-match: leftmost occurrence from the candidate's start on, must end inside the candidate (:505)
+	std::string bytes;
+	for (size_t k=0; k<lit.size(); ++k)
+	{
+		unsigned char b[ 4]; int n = utf8Encode( lit[ k], b);
+		bytes.append( (const char*)b, n);
+	}
+	for (size_t at=c.from; at + bytes.size() <= len; ++at)
+	{
+		if (std::memcmp( s + at, bytes.data(), bytes.size()) == 0)
+		{
+			if (at + bytes.size() > c.to) return false;
+			from = (uint32_t)at; to = (uint32_t)(at + bytes.size());
+			return true;
+		}
+	}
+	return false;
+}
+
+std::vector<LexemOut> LexerInstance::matchApprox( const char* src, size_t len) const
+{
+	const unsigned char* s = (const unsigned char*)src;
+	// OneByteCharMap::init: hashed text and the byte offset of every character
+	std::vector<uint32_t> hashed; std::vector<uint32_t> posar;
+	for (size_t at=0; at<len;)
+	{
+		uint32_t cp; unsigned n; decodeChar( s, len, at, cp, n);
+		posar.push_back( (uint32_t)at); hashed.push_back( oneByteHash( cp)); at += n;
+	}
+	posar.push_back( (uint32_t)len);
+	std::vector<ApproxCandidate> cand;
+	for (size_t e=1; e<=hashed.size(); ++e)
+	{
+		for (size_t pi=0; pi<m_defs.size(); ++pi)
+		{
+			std::vector<uint32_t> hl;
+			for (size_t k=0; k<m_literal[ pi].size(); ++k) hl.push_back( oneByteHash( m_literal[ pi][ k]));
+			const size_t m = hl.size(), N = m_defs[ pi].editdist;
+			for (size_t L = m+N < e ? m+N : e; L >= 1 && L + N >= m; --L)
+			{
+				if (levenshtein( &hashed[ e-L], L, hl.data(), m) <= N)
+				{
+					ApproxCandidate c; c.idx = (uint32_t)pi+1; c.from = posar[ e-L]; c.to = posar[ e];
+					cand.push_back( c);
+					break;
+				}
+			}
+		}
+	}
+	std::vector<MatchEvent> ar;
+	for (size_t i=0; i<cand.size(); ++i)
+	{
+		if (cand[i].to - cand[i].from >= 65535) throw std::runtime_error( "size of matched term out of range");
+		uint32_t from = 0, to = 0;
+		if (!approxSecondStage( src, len, cand[i], from, to)) continue;
+		handleEvent( ar, src, cand[i].idx, from, to);
+	}
+	return ordinalPositions( ar);
+}
+
+static bool plainLiteral( const std::string& expr)
+{
+	if (expr.empty()) return false;
+	for (size_t i=0; i<expr.size(); ++i) if (std::strchr( "\\.[](){}|*+?^$", expr[i])) return false;
+	return true;
+}
+
+// patternLexer.cpp:1068-1118 + :333-412.  BYTECHAR / UCP / ALLOWEMPTY belong to the "next" rows of
+// SURVEY.md 8(f) and are rejected here.
 void LexerInstance::compile()
 {
 	if (m_options & (OptUcp|OptByteChar|OptAllowEmpty)) throw std::runtime_error( "option not supported by this oracle (UCP, BYTECHAR, ALLOWEMPTY)");
-	m_regex.clear();
+	m_regex.clear(); m_literal.clear(); m_approx = false;
+	for (size_t i=0; i<m_defs.size(); ++i) if (m_defs[i].editdist) m_approx = true;
+	if (m_approx)
+	{
+		if (m_options & OptCaseless) throw std::runtime_error( "edit distance matching (~N) with CASELESS is not supported by this oracle");
+		if (!m_symbols.empty()) throw std::runtime_error( "edit distance matching (~N) with symbols is not supported by this oracle");
+		for (size_t i=0; i<m_defs.size(); ++i)
+		{
+			const Def& d = m_defs[i];
+			if (!plainLiteral( d.expression) || d.resultIndex) throw std::runtime_error( "a table with edit distance matching (~N) holds plain literal expressions only: " + d.expression);
+			std::vector<uint32_t> cps;
+			const unsigned char* s = (const unsigned char*)d.expression.data();
+			for (size_t at=0; at<d.expression.size();) { uint32_t cp; unsigned n; decodeChar( s, d.expression.size(), at, cp, n); cps.push_back( cp); at += n; }
+			if (cps.size() > 24 || d.editdist > 3 || d.editdist >= cps.size()) throw std::runtime_error( "edit distance literal: at most 24 characters, distance at most 3 and below the length: " + d.expression);
+			m_literal.push_back( cps);
+		}
+		m_compiled = true;
+		return;
+	}
 	for (size_t i=0; i<m_defs.size(); ++i)
 	{
-		if (m_defs[i].editdist) throw std::runtime_error( "edit distance matching (~N) is not supported by this oracle");
 		m_regex.push_back( Regex( m_defs[i].expression, m_options));
 		if (m_defs[i].resultIndex)
 		{
@@ -770,6 +990,13 @@ void LexerInstance::handleMatch( std::vector<MatchEvent>& ar, const char* src, u
 		if (def.prefixLen + def.suffixLen > to - from) return;
 		from += def.prefixLen; to -= def.suffixLen;
 	}
+	handleEvent( ar, src, idx, from, to);
+}
+
+// the handler behind the sub-expression step (:739-826)
+void LexerInstance::handleEvent( std::vector<MatchEvent>& ar, const char* src, uint32_t idx, uint32_t from, uint32_t to) const
+{
+	const Def& def = m_defs[ idx-1];
 	uint32_t patternid = def.id;
 	std::map<uint32_t, std::map<std::string,uint32_t> >::const_iterator ti = m_symbols.find( def.id);
 	if (ti != m_symbols.end())
@@ -844,11 +1071,16 @@ std::vector<LexemOut> LexerInstance::match( const char* src, size_t len) const
 {
 	if (!m_compiled) throw std::runtime_error( "called create context without calling 'compile'");
 	if (len >= 0xFFFFFFFFull) throw std::runtime_error( "size of string to scan out of range");
+	if (m_approx) return matchApprox( src, len);
 	std::vector<RawMatch> raw = rawMatches( src, len);
 	std::vector<MatchEvent> ar;
 	for (size_t i=0; i<raw.size(); ++i) handleMatch( ar, src, raw[i].idx, raw[i].from, raw[i].to);
+	return ordinalPositions( ar);
+}
 
-	// ordinal positions (:893-945)
+// ordinal positions (:893-945)
+std::vector<LexemOut> LexerInstance::ordinalPositions( const std::vector<MatchEvent>& ar) const
+{
 	std::vector<LexemOut> rt;
 	size_t mi = 0;
 	uint32_t ordpos = 0, origpos = 0;

@@ -13,6 +13,13 @@
 // Beyond those lexems parity with Hyperscan is UNPINNED; the regex semantics are additionally
 // cross-checked against Python's `re` on small random cases (same test file).
 //
+// EDIT DISTANCE (`expr ~N`, patternLexer.cpp:333-412, :414-426, :450-601): the reference pre-matches on a
+// one-byte-per-character hash of text and expression (unicodeUtils.cpp:19-44) with Hyperscan's
+// approximate matching and re-matches every candidate with libtre's approximate matcher.  Neither library
+// is here; the restatement (l1_oracle.cpp, "approximate literal tables") covers tables whose expressions
+// are all plain literals and is pinned by the two vectors of testCharRegexMatch.cpp:161-196 ONLY -- the
+// tie-breaking of the second stage is a model fitted to those vectors, stated where it is implemented.
+//
 // Deliberately a different algorithm from the product (which builds a Glushkov position automaton
 // with bit-parallel tables): here the regex AST is compiled to a Thompson-style epsilon NFA and
 // simulated with a per-state minimal start offset.
@@ -58,7 +65,7 @@ private:
 class LexerInstance
 {
 public:
-	LexerInstance() :m_options(0),m_compiled(false){}
+	LexerInstance() :m_approx(false),m_options(0),m_compiled(false){}
 	// PatternLexerInstanceInterface (patternLexer.cpp:971-1141)
 	void defineLexem( uint32_t id, const std::string& expression, uint32_t resultIndex, uint32_t level, PosBind posbind);
 	void defineSymbol( uint32_t symbolid, uint32_t patternid, const std::string& name);
@@ -78,6 +85,15 @@ private:
 	};
 	struct MatchEvent { uint32_t id; uint8_t level; uint8_t posbind; uint16_t origsize; uint32_t origpos; };
 	void handleMatch( std::vector<MatchEvent>& ar, const char* src, uint32_t idx, uint32_t from, uint32_t to) const;
+	void handleEvent( std::vector<MatchEvent>& ar, const char* src, uint32_t idx, uint32_t from, uint32_t to) const;
+	std::vector<LexemOut> ordinalPositions( const std::vector<MatchEvent>& ar) const;
+
+	// tables with an edit distance pattern (see "approximate literal tables" in l1_oracle.cpp)
+	struct ApproxCandidate { uint32_t idx, from, to; };
+	bool approxSecondStage( const char* src, size_t len, const ApproxCandidate& c, uint32_t& from, uint32_t& to) const;
+	std::vector<LexemOut> matchApprox( const char* src, size_t len) const;
+	std::vector<std::vector<uint32_t> > m_literal;	// per definition: its code points (approximate tables only)
+	bool m_approx;
 
 	std::vector<Def> m_defs;
 	std::vector<Regex> m_regex;

@@ -433,6 +433,13 @@ class PatternLexerContext:
     def lastKernelMs(self):
         return self._L.sp_lexer_ctx_last_kernel_ms(self._h)
 
+    def lastKernelMsSplit(self):
+        """(scan kernel ms, post-processing kernel ms) of the last launch"""
+        a, b = ctypes.c_double(-1.0), ctypes.c_double(-1.0)
+        if self._L.sp_lexer_ctx_last_kernel_ms_split(self._h, ctypes.byref(a), ctypes.byref(b)) != 0:
+            raise PatternError("no timed launch")
+        return a.value, b.value
+
     def reserveOutput(self, lexems):
         self._L.sp_lexer_ctx_reserve_output(self._h, lexems)
 

@@ -14,7 +14,7 @@
 #include <vector>
 
 namespace spa {
-hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, hipStream_t stream);
+hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, hipStream_t stream, hipEvent_t betweenKernels);
 }
 using namespace spa;
 
@@ -41,7 +41,7 @@ struct sp_lexer_ctx
 	int device;
 	std::string lasterror;
 	DeviceBuffer dByteClass, dClassCtx, dCharMask, dStartMask, dAcceptMask, dShiftDst, dSelfLoop, dExSrc, dExDst, dExCount,
-		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit;
+		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit, dApprox, dCharCp, dCharPos;
 	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst; unsigned blockThreads;
 	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus, dQueue, dReportCount;
 	uint32_t queueMul;		// report queue between the two kernels: queueMul/16 reports per text byte (+64 per document)
@@ -49,10 +49,10 @@ struct sp_lexer_ctx
 	unsigned arenaWaves; uint64_t arenaWords;
 	uint64_t lexemCapacity, minLexemCapacity;
 	unsigned numCUs;
-	hipEvent_t evStart, evStop; bool evValid;
+	hipEvent_t evStart, evMid, evStop; bool evValid;
 	hipStream_t lastStream; size_t lastNdocs;
 	sp_lexer_ctx() :inst(0),device(0),ldsWords(0),ldsAccept(0),ldsStart(0),ldsShift(0),ldsSelf(0),ldsExSrc(0),ldsExDst(0),blockThreads(256),queueMul(8),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
-		,numCUs(256),evStart(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0){}
+		,numCUs(256),evStart(0),evMid(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0){}
 };
 
 extern "C" {
@@ -191,6 +191,7 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 		c->dLiterals.upload( T.literals.data(), T.literals.size()*sizeof(DevLiteral));
 		c->dLiteralText.upload( T.literalText.data(), T.literalText.size());
 		c->dLitPats.upload( T.litPats.data(), T.litPats.size()*4);
+		if (!T.approx.empty()) c->dApprox.upload( T.approx.data(), T.approx.size()*sizeof(DevApproxPattern));
 		{
 			// LDS image of the hot tables when it fits (one copy per workgroup; bigger workgroups when the copy is big)
 			std::vector<uint64_t> img;
@@ -231,6 +232,7 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 		uint32_t npat = (uint32_t)T.patterns.size();
 		c->queueCap = 4096 > 2*npat+256 ? 4096 : 2*npat+256;
 		HIP_CHECK( hipEventCreate( &c->evStart));
+		HIP_CHECK( hipEventCreate( &c->evMid));
 		HIP_CHECK( hipEventCreate( &c->evStop));
 		return c;
 	}
@@ -246,6 +248,7 @@ void sp_lexer_ctx_free( sp_lexer_ctx_t* c)
 {
 	if (!c) return;
 	if (c->evStart) (void)hipEventDestroy( c->evStart);
+	if (c->evMid) (void)hipEventDestroy( c->evMid);
 	if (c->evStop) (void)hipEventDestroy( c->evStop);
 	delete c;
 }
@@ -299,6 +302,12 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	c->dDocStatus.reserve( (ndocs+1)*sizeof(int32_t));
 	c->dReportCount.reserve( (ndocs+1)*sizeof(uint32_t));
 	c->dQueue.reserve( ((((uint64_t)nbytes * c->queueMul) >> 4) + 64ull*(ndocs+2)) * 16);
+	if (!T.approx.empty())
+	{
+		// approximate literal table: the decoded characters of every document (code point, byte offset)
+		c->dCharCp.reserve( ((uint64_t)nbytes + ndocs + 64) * 4);
+		c->dCharPos.reserve( ((uint64_t)nbytes + ndocs + 64) * 4);
+	}
 	HIP_CHECK( hipMemsetAsync( c->dCounters.ptr, 0, L1C_ALLOC*sizeof(uint64_t), stream));
 
 	L1Params P;
@@ -321,11 +330,13 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.counters = (uint64_t*)c->dCounters.ptr; P.lexems = (uint32_t*)c->dLexems.ptr; P.lexemCapacity = c->lexemCapacity;
 	P.docRange = (uint64_t*)c->dDocRange.ptr; P.docStatus = (int32_t*)c->dDocStatus.ptr;
 	P.reportQueue = (uint32_t*)c->dQueue.ptr; P.reportCount = (uint32_t*)c->dReportCount.ptr; P.queueMul = c->queueMul;
+	P.approx = T.approx.empty() ? 0 : (const DevApproxPattern*)c->dApprox.ptr; P.nofApprox = (uint32_t)T.approx.size();
+	P.charCp = (uint32_t*)c->dCharCp.ptr; P.charPos = (uint32_t*)c->dCharPos.ptr;
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
 	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = c->ldsWords;
 	P.ldsAccept = c->ldsAccept; P.ldsStart = c->ldsStart; P.ldsShift = c->ldsShift; P.ldsSelf = c->ldsSelf;
 	P.ldsExSrc = c->ldsExSrc; P.ldsExDst = c->ldsExDst;
-	HIP_CHECK( launchL1Lex( P, nblocks, c->blockThreads, stream));
+	HIP_CHECK( launchL1Lex( P, nblocks, c->blockThreads, stream, c->evMid));
 	HIP_CHECK( hipEventRecord( c->evStop, stream));
 	c->evValid = true; c->lastStream = stream; c->lastNdocs = ndocs;
 }
@@ -373,6 +384,18 @@ double sp_lexer_ctx_last_kernel_ms( sp_lexer_ctx_t* c)
 	if (hipEventSynchronize( c->evStop) != hipSuccess) return -1.0;
 	if (hipEventElapsedTime( &ms, c->evStart, c->evStop) != hipSuccess) return -1.0;
 	return (double)ms;
+}
+
+int sp_lexer_ctx_last_kernel_ms_split( sp_lexer_ctx_t* c, double* scan_ms, double* post_ms)
+{
+	*scan_ms = -1.0; *post_ms = -1.0;
+	if (!c->evValid) return SP_ERR_INVALID;
+	float a = 0.0f, b = 0.0f;
+	if (hipEventSynchronize( c->evStop) != hipSuccess) return SP_ERR_INVALID;
+	if (hipEventElapsedTime( &a, c->evStart, c->evMid) != hipSuccess) return SP_ERR_INVALID;
+	if (hipEventElapsedTime( &b, c->evMid, c->evStop) != hipSuccess) return SP_ERR_INVALID;
+	*scan_ms = (double)a; *post_ms = (double)b;
+	return SP_OK;
 }
 
 int sp_lexer_ctx_match_docs( sp_lexer_ctx_t* c, const char* text, const uint64_t* doc_offsets, size_t ndocs, sp_lex_batch_t* out)

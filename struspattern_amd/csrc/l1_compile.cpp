@@ -766,6 +766,17 @@ void LexCompiler::compile()
 	LexTables& T = m_tables;
 	T = LexTables();
 
+	// 0. a table with an edit distance expression: every expression takes the approximate route
+	//    (src/patternLexer.cpp:333-352); supported for tables of plain literals
+	bool approxTable = false;
+	for (size_t di=0; di<m_defs.size(); ++di) if (m_defs[ di].editdist) approxTable = true;
+	if (approxTable)
+	{
+		if (m_options & LEX_CASELESS) throw std::runtime_error( "approximate matching (~N) together with CASELESS is not supported by this lexer");
+		if (!m_symbols.empty()) throw std::runtime_error( "approximate matching (~N) together with symbols is not supported by this lexer");
+		if (m_defs.size() > L1_APPROX_MAXPATTERNS) throw std::runtime_error( "too many expressions in a table with approximate matching (~N)");
+	}
+
 	// 1. per pattern automata
 	std::vector<Automaton> autos;
 	std::map<std::string,std::vector<uint32_t> > literalWords;
@@ -773,7 +784,39 @@ void LexCompiler::compile()
 	for (size_t di=0; di<m_defs.size(); ++di)
 	{
 		const Def& d = m_defs[ di];
-		if (d.editdist) throw std::runtime_error( "failed to compile pattern \"" + d.expression + "\": approximate matching (~N) is not supported by this lexer yet");
+		if (approxTable)
+		{
+			if (d.expression.empty() || d.expression.find_first_of( "\\.[](){}|*+?^$") != std::string::npos || d.resultIndex)
+			{
+				throw std::runtime_error( "failed to compile pattern \"" + d.expression + "\": a table with approximate matching (~N) holds plain literal expressions only in this lexer");
+			}
+			DevApproxPattern ap; std::memset( &ap, 0, sizeof(ap));
+			ap.id = d.id; ap.levelBind = (d.level & 0xFF) | ((uint32_t)d.posbind << 8); ap.editdist = d.editdist; ap.byteLen = (uint32_t)d.expression.size();
+			const unsigned char* s = (const unsigned char*)d.expression.data();
+			for (size_t at=0; at<d.expression.size();)
+			{
+				// lenient UTF-8 (the kernel's rule): a lead byte with all its continuation bytes, else the byte itself
+				unsigned char c = s[ at];
+				unsigned want = (c >= 0xC2 && c <= 0xDF) ? 2 : (c >= 0xE0 && c <= 0xEF) ? 3 : (c >= 0xF0 && c <= 0xF4) ? 4 : 1;
+				uint32_t cp = c; unsigned n = 1;
+				if (want > 1 && at + want <= d.expression.size())
+				{
+					uint32_t v = c & (0xFFu >> (want+1)); bool ok = true;
+					for (unsigned i=1; i<want; ++i) { if ((s[ at+i] & 0xC0) != 0x80) { ok = false; break; } v = (v << 6) | (s[ at+i] & 0x3F); }
+					if (ok) { cp = v; n = want; }
+				}
+				if (ap.len >= L1_APPROX_MAXCHARS) throw std::runtime_error( "failed to compile pattern \"" + d.expression + "\": a literal with approximate matching has at most 24 characters");
+				ap.cp[ ap.len++] = cp; at += n;
+			}
+			if (d.editdist > L1_APPROX_MAXDIST || d.editdist >= ap.len) throw std::runtime_error( "failed to compile pattern \"" + d.expression + "\": the edit distance is at most 3 and below the number of characters");
+			T.approx.push_back( ap);
+			DevLexPattern dp; std::memset( &dp, 0, sizeof(dp));
+			dp.id = d.id; dp.levelBind = ap.levelBind; dp.word = L1_WORD_LITERAL;
+			T.patterns.push_back( dp);
+			autos.push_back( Automaton());
+			for (int c=0; c<CTX_COUNT; ++c) { autos.back().start[c] = 0; autos.back().accept[c] = 0; }
+			continue;
+		}
 		Syntax syn( d.expression, m_options);
 		Tree tree = syn.run();
 		DevLexPattern dp; std::memset( &dp, 0, sizeof(dp));
@@ -1141,7 +1184,7 @@ void LexCompiler::compile()
 }
 
 // ---------------------------------------------------------------- compiled tables as a blob
-static const char L1_MAGIC[ 9] = "SPAL1v02";
+static const char L1_MAGIC[ 9] = "SPAL1v03";
 
 void LexCompiler::save( std::vector<uint8_t>& out) const
 {
@@ -1152,7 +1195,7 @@ void LexCompiler::save( std::vector<uint8_t>& out) const
 	w.u32( T.nofPasses); w.u32( T.nofClasses); w.u32( T.maxExceptions); w.u32( T.nofLiterals); w.u32( T.nofPositions); w.u32( T.reportsOrdered ? 1u : 0u);
 	w.vec( T.byteClass); w.vec( T.classCtx); w.vec( T.charMask); w.vec( T.startMask); w.vec( T.acceptMask); w.vec( T.shiftDst); w.vec( T.selfLoop);
 	w.vec( T.exCount); w.vec( T.exSrc); w.vec( T.exDst); w.vec( T.wordPatBegin); w.vec( T.wordPats); w.vec( T.patOfBit);
-	w.vec( T.patterns); w.vec( T.symbols); w.vec( T.symbolText); w.vec( T.literals); w.vec( T.literalText); w.vec( T.litPats);
+	w.vec( T.patterns); w.vec( T.symbols); w.vec( T.symbolText); w.vec( T.literals); w.vec( T.literalText); w.vec( T.litPats); w.vec( T.approx);
 	w.u32( (uint32_t)m_defs.size());
 	for (size_t i=0; i<m_defs.size(); ++i)
 	{
@@ -1178,7 +1221,7 @@ void LexCompiler::load( const void* blob, size_t size)
 	T.nofPasses = r.u32(); T.nofClasses = r.u32(); T.maxExceptions = r.u32(); T.nofLiterals = r.u32(); T.nofPositions = r.u32(); T.reportsOrdered = r.u32() != 0;
 	r.vec( T.byteClass); r.vec( T.classCtx); r.vec( T.charMask); r.vec( T.startMask); r.vec( T.acceptMask); r.vec( T.shiftDst); r.vec( T.selfLoop);
 	r.vec( T.exCount); r.vec( T.exSrc); r.vec( T.exDst); r.vec( T.wordPatBegin); r.vec( T.wordPats); r.vec( T.patOfBit);
-	r.vec( T.patterns); r.vec( T.symbols); r.vec( T.symbolText); r.vec( T.literals); r.vec( T.literalText); r.vec( T.litPats);
+	r.vec( T.patterns); r.vec( T.symbols); r.vec( T.symbolText); r.vec( T.literals); r.vec( T.literalText); r.vec( T.litPats); r.vec( T.approx);
 	// the shapes the kernel indexes by must fit together (a blob of another build would fault on the device)
 	if (T.byteClass.size() != 256 || T.classCtx.size() != T.nofClasses
 	||  T.charMask.size() != (size_t)T.nofPasses*T.nofClasses*64 || T.startMask.size() != (size_t)T.nofPasses*CTX_COUNT*64 || T.acceptMask.size() != T.startMask.size()
@@ -1197,7 +1240,12 @@ void LexCompiler::load( const void* blob, size_t size)
 		Def d; d.expression = r.str(); d.id = r.u32(); d.resultIndex = r.u32(); d.level = r.u32(); d.editdist = r.u32(); d.posbind = (int)r.u32();
 		m_defs.push_back( d);
 	}
-	if (T.patterns.size() != m_defs.size()) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	if (T.patterns.size() != m_defs.size() || (!T.approx.empty() && T.approx.size() != m_defs.size())) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	for (size_t i=0; i<T.approx.size(); ++i)
+	{
+		if (T.approx[ i].len == 0 || T.approx[ i].len > L1_APPROX_MAXCHARS || T.approx[ i].editdist > L1_APPROX_MAXDIST || T.approx[ i].editdist >= T.approx[ i].len || T.approx.size() > L1_APPROX_MAXPATTERNS)
+			throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	}
 	const uint32_t nt = r.u32();
 	for (uint32_t i=0; i<nt; ++i)
 	{

@@ -38,6 +38,7 @@ struct LexTables
 	std::vector<DevLiteral> literals;	// power-of-two size (>=1)
 	std::vector<uint8_t> literalText;
 	std::vector<uint32_t> litPats;
+	std::vector<DevApproxPattern> approx;	// non-empty: approximate literal table, the automaton tables are empty
 	uint32_t nofLiterals;
 	uint32_t nofPositions;
 	bool reportsOrdered;			// patterns sit in the words in definition order (else the kernel sorts the reports of one end offset)

@@ -61,6 +61,11 @@ struct L1Params
 	uint64_t lexemCapacity;
 	uint64_t* docRange;		// ndocs x (first lexem, count)
 	int32_t* docStatus;		// ndocs
+	// approximate literal tables (new fields go behind everything else: see the note on the layout slots above)
+	const DevApproxPattern* approx;	// nofApprox patterns, or null
+	uint32_t nofApprox;
+	uint32_t* charCp;		// characters of document d: charCp / charPos [ begin(d)+d .. ), code point and byte offset
+	uint32_t* charPos;
 };
 
 } // namespace

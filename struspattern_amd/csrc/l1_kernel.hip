@@ -844,6 +844,248 @@ __device__ __forceinline__ void docBounds( const L1Params& P, u32 doc, u64& beg,
 }
 __device__ __forceinline__ u64 queueBase( const L1Params& P, u64 beg, u32 doc) { return ((beg * P.queueMul) >> 4) + 64ull*doc; }
 
+// ---------------------------------------------------------------- approximate literal tables
+// A table with an edit distance expression (`literal ~N`) takes the reference's other route (src/patternLexer.cpp
+// :333-412): every expression is pre-matched on the one-byte-per-character hash of the text
+// (src/unicodeUtils.cpp:19-44) -- approximately for `~N` -- and every candidate is re-matched on the characters
+// themselves (:450-601).  One wave per document: the characters are decoded once into charCp/charPos; then 64
+// candidate end positions at a time, each lane runs both stages for its end position and every pattern; the
+// events of the tile go through the handler in the order of the candidates (end position, pattern index).
+// The second stage's choice among several approximate matches is a model pinned by the reference's two vectors,
+// stated with the oracle's restatement (oracle/l1_oracle.cpp, "approximate literal tables"); the code here
+// follows that statement step by step.
+__shared__ uint2 approxCand[ L1_APPROX_MAXPATTERNS][ 64];
+
+__device__ __forceinline__ u32 oneByteHash( u32 cp) { return cp <= 127u ? cp : 128u + (cp & 127u); }
+// lenient UTF-8: a lead byte with all its continuation bytes below `bound` is one character, any other byte is one of its own value
+__device__ __forceinline__ void decodeAt( const unsigned char* doc, u32 bound, u32 at, u32& cp, u32& n)
+{
+	const u32 c = doc[ at];
+	cp = c; n = 1;
+	const u32 want = (c >= 0xC2u && c <= 0xDFu) ? 2u : (c >= 0xE0u && c <= 0xEFu) ? 3u : (c >= 0xF0u && c <= 0xF4u) ? 4u : 1u;
+	if (want == 1u || at + want > bound) return;
+	u32 v = c & (0xFFu >> (want+1u));
+	for (u32 i=1; i<want; ++i)
+	{
+		const u32 x = doc[ at+i];
+		if ((x & 0xC0u) != 0x80u) return;
+		v = (v << 6) | (x & 0x3Fu);
+	}
+	cp = v; n = want;
+}
+__device__ __forceinline__ u32 encodeCp( u32 cp, u32* b)
+{
+	if (cp < 0x80u) { b[0] = cp; return 1; }
+	if (cp < 0x800u) { b[0] = 0xC0u | (cp >> 6); b[1] = 0x80u | (cp & 0x3Fu); return 2; }
+	if (cp < 0x10000u) { b[0] = 0xE0u | (cp >> 12); b[1] = 0x80u | ((cp >> 6) & 0x3Fu); b[2] = 0x80u | (cp & 0x3Fu); return 3; }
+	b[0] = 0xF0u | (cp >> 18); b[1] = 0x80u | ((cp >> 12) & 0x3Fu); b[2] = 0x80u | ((cp >> 6) & 0x3Fu); b[3] = 0x80u | (cp & 0x3Fu); return 4;
+}
+
+// stage 1 for one end position: the smallest start s < e with levenshtein( hash(text[s:e]), hash(literal)) <= N
+__device__ bool approxFirstStage( const u32* cps, const DevApproxPattern* ap, u32 e, u32& sOut)
+{
+	const u32 m = ap->len, N = ap->editdist;
+	u32 L = m + N < e ? m + N : e;
+	for (; L >= 1u && L + N >= m; --L)
+	{
+		u32 prev[ L1_APPROX_MAXCHARS+1], cur[ L1_APPROX_MAXCHARS+1];
+		for (u32 j=0; j<=m; ++j) prev[ j] = j;
+		for (u32 i=1; i<=L; ++i)
+		{
+			const u32 a = oneByteHash( cps[ e-L+i-1]);
+			cur[ 0] = i;
+			for (u32 j=1; j<=m; ++j)
+			{
+				u32 v = prev[ j-1] + (a != oneByteHash( ap->cp[ j-1]) ? 1u : 0u);
+				if (prev[ j] + 1u < v) v = prev[ j] + 1u;
+				if (cur[ j-1] + 1u < v) v = cur[ j-1] + 1u;
+				cur[ j] = v;
+			}
+			for (u32 j=0; j<=m; ++j) prev[ j] = cur[ j];
+		}
+		if (prev[ m] <= N) { sOut = e - L; return true; }
+	}
+	return false;
+}
+
+// stage 2, `~N` expression: approximate search in the window [from, wend) of the document
+__device__ bool approxSearch( const unsigned char* doc, u32 from, u32 wend, const DevApproxPattern* ap, u32& mFrom, u32& mTo)
+{
+	const u32 m = ap->len, maxCost = ap->editdist + 3u, NONE = 0xFFFFu;
+	u32 cost[ L1_APPROX_MAXCHARS+1], start[ L1_APPROX_MAXCHARS+1], ncost[ L1_APPROX_MAXCHARS+1], nstart[ L1_APPROX_MAXCHARS+1];
+	for (u32 k=0; k<=m; ++k) { cost[ k] = NONE; start[ k] = 0; }
+	bool have = false; u32 best = NONE;
+	u32 at = from;
+	for (;;)
+	{
+		if (!have || best > 0u)
+		{
+			if (cost[ 0] == NONE || cost[ 0] > 0u) { cost[ 0] = 0; start[ 0] = at; }
+		}
+		for (u32 k=0; k<m; ++k)				// pattern characters skipped
+		{
+			if (cost[ k] == NONE) continue;
+			const u32 c = cost[ k] + 1u;
+			if (c > maxCost || (have && c >= best)) continue;
+			if (cost[ k+1] == NONE || c < cost[ k+1]) { cost[ k+1] = c; start[ k+1] = start[ k]; }
+		}
+		if (at >= wend)
+		{
+			if (cost[ m] != NONE && (!have || cost[ m] < best)) { have = true; best = cost[ m]; mFrom = start[ m]; mTo = at; }
+			break;
+		}
+		u32 ch, n;
+		decodeAt( doc, wend, at, ch, n);
+		at += n;
+		for (u32 k=0; k<=m; ++k) ncost[ k] = NONE;
+		for (u32 k=0; k<m; ++k)
+		{
+			if (cost[ k] == NONE) continue;
+			{
+				const u32 c = cost[ k] + (ch != ap->cp[ k] ? 1u : 0u);	// the character is the next pattern character, or stands for it
+				if (c <= maxCost && !(have && c >= best))
+				{
+					if (ncost[ k+1] == NONE || c < ncost[ k+1]) { ncost[ k+1] = c; nstart[ k+1] = start[ k]; }
+					if (k+1u == m && (!have || c < best)) { have = true; best = c; mFrom = start[ k]; mTo = at; }
+				}
+			}
+			{
+				const u32 c = cost[ k] + 1u;				// the character is an extra one
+				if (c <= maxCost && !(have && c >= best))
+				{
+					if (ncost[ k] == NONE || c < ncost[ k]) { ncost[ k] = c; nstart[ k] = start[ k]; }
+				}
+			}
+		}
+		for (u32 k=0; k<=m; ++k) { cost[ k] = ncost[ k]; start[ k] = nstart[ k]; }
+	}
+	return have;
+}
+
+// stage 2, exact expression: the leftmost occurrence of the literal from the candidate's start on must end inside the candidate
+__device__ bool exactSearch( const unsigned char* doc, u32 from, u32 to, const DevApproxPattern* ap, u32& mFrom, u32& mTo)
+{
+	u32 bytes[ 4*L1_APPROX_MAXCHARS];
+	u32 nb = 0;
+	for (u32 k=0; k<ap->len; ++k) nb += encodeCp( ap->cp[ k], bytes + nb);
+	for (u32 at=from; at + nb <= to; ++at)
+	{
+		bool same = true;
+		for (u32 q=0; q<nb && same; ++q) same = doc[ at+q] == bytes[ q];
+		if (same) { mFrom = at; mTo = at + nb; return true; }
+	}
+	return false;
+}
+
+__device__ void approxDocument( LexWave& w, const L1Params& P, u32* cps, u32* cpos)
+{
+	const u32 len = w.docLen;
+	// the characters of the document
+	u32 nChars = 0;
+	u64 carry = 0;				// continuation bytes at the start of the next tile that belong to a character of this one
+	for (u32 tile=0; tile<len; tile+=64)
+	{
+		const u32 i = tile + LANE;
+		u32 cp = 0, n = 0;
+		if (i < len) decodeAt( w.doc, len, i, cp, n);
+		const u64 m2 = __ballot( n >= 2u), m3 = __ballot( n >= 3u), m4 = __ballot( n >= 4u);
+		const u64 covered = (m2 << 1) | (m3 << 2) | (m4 << 3) | carry;
+		carry = (m2 >> 63) | (m3 >> 62) | (m4 >> 61);
+		const u64 startM = __ballot( i < len) & ~covered;
+		if ((startM >> LANE) & 1ull)
+		{
+			const u32 idx = nChars + (u32)__builtin_popcountll( startM & ((1ull << LANE) - 1ull));
+			cps[ idx] = cp; cpos[ idx] = i;
+		}
+		nChars += (u32)__builtin_popcountll( startM);
+	}
+	if (LANE == 0) cpos[ nChars] = len;
+	__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront");
+	// candidates and their second stage, 64 end positions at a time
+	for (u32 ct=0; ct<nChars && !w.err; ct+=64)
+	{
+		const u32 e = ct + 1u + LANE;
+		for (u32 p=0; p<P.nofApprox; ++p)
+		{
+			const DevApproxPattern* ap = &P.approx[ p];
+			uint2 ev = make_uint2( 0, 0);
+			if (e <= nChars)
+			{
+				u32 s = 0;
+				if (approxFirstStage( cps, ap, e, s))
+				{
+					const u32 from = cpos[ s], to = cpos[ e];
+					u32 mf = 0, mt = 0;
+					bool ok;
+					if (ap->editdist)
+					{
+						u32 wend = to + 4u * ap->editdist;		// (:561: the candidate's bytes and editdist * sizeof(wchar_t) more)
+						if (wend > len) wend = len;
+						ok = approxSearch( w.doc, from, wend, ap, mf, mt);
+					}
+					else ok = exactSearch( w.doc, from, to, ap, mf, mt);
+					if (ok && mt > mf) ev = make_uint2( mf, mt);
+				}
+			}
+			approxCand[ p][ LANE] = ev;
+		}
+		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront");
+		const u32 inTile = (nChars - ct) < 64u ? (nChars - ct) : 64u;
+		for (u32 l=0; l<inTile && !w.err; ++l)
+		{
+			for (u32 p=0; p<P.nofApprox && !w.err; ++p)
+			{
+				const uint2 ev = approxCand[ p][ l];
+				const u32 mf = uni( ev.x), mt = uni( ev.y);
+				if (!mt) continue;
+				const DevApproxPattern* ap = &P.approx[ p];
+				handleReport( w, P, ldu( &ap->id), ldu( &ap->levelBind), 0, 0, mf, mt);
+			}
+		}
+		__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+	}
+}
+
+__device__ void approxDocuments( const L1Params& P)
+{
+	const u32 waveSlot = blockIdx.x, nWaveSlots = gridDim.x;		// one wave per workgroup
+	LexWave w;
+	w.events = (Event*)(P.arenaBase + (u64)waveSlot * P.arenaWords);
+	w.queue = 0; w.nQueue = 0; w.queueCap = 0;
+#ifdef SPA_PROF
+	for (int k=0; k<4; ++k) w.prof[ k] = 0;
+#endif
+	for (u32 round=0; round<=P.ndocs; ++round)
+	{
+		u32 doc = waveSlot;
+		if (round)
+		{
+			u32 nx = 0;
+			if (LANE == 0) nx = atomicAdd( (u32*)&P.counters[ L1C_CURSOR], 1u);
+			doc = nWaveSlots + uni( nx);
+		}
+		if (doc >= P.ndocs) break;
+		u64 beg, end;
+		docBounds( P, doc, beg, end);
+		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
+		w.nEvents = 0; w.err = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
+		w.e.id = 0; w.e.pos = 0; w.e.size = 0; w.e.lb = 0;
+		approxDocument( w, P, P.charCp + beg + doc, P.charPos + beg + doc);
+		spillLanes( w, 0);
+		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+		if (!w.err) emitLexems( w, P, doc);
+		else if (LANE == 0) { P.docRange[ 2*(u64)doc] = 0; P.docRange[ 2*(u64)doc+1] = 0; }
+		if (LANE == 0)
+		{
+			P.docStatus[ doc] = (int32_t)w.err;
+			atomicAdd( (unsigned long long*)&P.counters[ L1C_BYTES], (unsigned long long)w.docLen);
+			if (w.err) atomicAdd( (unsigned long long*)&P.counters[ L1C_FAILED], 1ull);
+		}
+	}
+}
+
 template <bool LDS>
 __device__ __forceinline__ void stageTables( const L1Params& P, LexTab<LDS>& T)
 {
@@ -968,13 +1210,22 @@ SPA_L1_KERNEL( p7, 7, 1024)
 SPA_L1_KERNEL( p8, 8, 1024)
 SPA_L1_KERNEL( p16, 16, 256)
 SPA_L1_KERNEL( p32, 32, 256)
+extern "C" __global__ __launch_bounds__(64) void spa_l1_approx_kernel( L1Params P) { approxDocuments( P); }
 // the post-processing kernel reads the automaton's tables from global memory (start of match only)
 enum {POST_WAVES=4};
 extern "C" __global__ __launch_bounds__(64*POST_WAVES) void spa_l1_post_kernel( L1Params P) { postDocuments<false>( P); }
 
 namespace spa {
-hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, hipStream_t stream)
+hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, hipStream_t stream, hipEvent_t betweenKernels)
 {
+	if (P.nofApprox)
+	{
+		// approximate literal table: one kernel, one wave per workgroup
+		hipLaunchKernelGGL( spa_l1_approx_kernel, dim3( nblocks * (nthreads/64)), dim3( 64), 0, stream, P);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		return betweenKernels ? hipEventRecord( betweenKernels, stream) : hipSuccess;
+	}
 	const size_t lds = (size_t)P.ldsWords * 8;
 #define SPA_L1_LAUNCH( N) do { \
 	if (lds > 65536) { hipError_t e = hipFuncSetAttribute( (const void*)spa_l1_scan_kernel_##N, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
@@ -996,6 +1247,7 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 	}
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
+	if (betweenKernels) { e = hipEventRecord( betweenKernels, stream); if (e != hipSuccess) return e; }
 	// the same number of waves (one arena slot each), in workgroups of POST_WAVES
 	hipLaunchKernelGGL( spa_l1_post_kernel, dim3( (nblocks * (nthreads/64) + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
 	return hipGetLastError();

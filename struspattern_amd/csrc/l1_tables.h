@@ -33,6 +33,20 @@ struct DevLexPattern		// 32 B, one per defineLexem call, index = definition inde
 	uint32_t _pad;
 };
 
+// Approximate literal tables (a table with a `~N` expression, src/patternLexer.cpp:333-412): every expression is
+// a plain literal, matched by the approximate-matching kernel on characters
+enum {L1_APPROX_MAXCHARS=24, L1_APPROX_MAXDIST=3, L1_APPROX_MAXPATTERNS=32};
+struct DevApproxPattern		// 128 B, index = definition index
+{
+	uint32_t id;
+	uint32_t levelBind;	// level | posbind<<8
+	uint32_t editdist;
+	uint32_t len;		// characters
+	uint32_t byteLen;	// UTF-8 bytes
+	uint32_t _pad[3];
+	uint32_t cp[ L1_APPROX_MAXCHARS];	// code points
+};
+
 struct DevSymbol		// 32 B, open addressing (linear probing), hash==0 = empty
 {
 	uint32_t hash;

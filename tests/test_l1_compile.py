@@ -87,9 +87,17 @@ def test_compile_errors_are_reported():
         with pytest.raises(spa.PatternError):
             lx.compile()
     lx = spa.PatternLexerInstance()
-    lx.defineLexem(1, "abc ~1", 0, 1, "content")     # edit distance: a "next" row, rejected loudly
+    lx.defineLexem(1, "a[bc]d ~1", 0, 1, "content")  # edit distance on anything but a plain literal: rejected loudly
     with pytest.raises(spa.PatternError):
         lx.compile()
+    lx = spa.PatternLexerInstance()
+    lx.defineLexem(1, "abc ~1", 0, 1, "content")     # ... and a regex beside an edit distance literal as well
+    lx.defineLexem(2, "x+", 0, 1, "content")
+    with pytest.raises(spa.PatternError):
+        lx.compile()
+    lx = spa.PatternLexerInstance()
+    lx.defineLexem(1, "abc ~1", 0, 1, "content")     # approximate literal table (testCharRegexMatch.cpp:161-196)
+    lx.compile()
     lx = spa.PatternLexerInstance()
     lx.defineLexem(1, "abc", 0, 1, "content")
     lx.compile()

@@ -31,6 +31,74 @@ def test_char_regex_match_golden_case1():
     assert got == case["result"]
 
 
+@pytest.mark.parametrize("index", [1, 2])
+def test_char_regex_match_golden_edit_distance_cases(index):
+    """testCharRegexMatch.cpp:161-196: `abc ~1` and its UTF-8 twin, 5 lexems each"""
+    case = l1_cases.load_char_regex_cases()[index]
+    lx = spa.PatternLexerInstance()
+    l1_cases.build_case(lx, case)
+    got = lx.createContext().match(case["src"].encode()).tolist()
+    assert got == case["result"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_approximate_literal_tables(seed):
+    """Tables of plain literals with edit distances 0..3 (a table with one `~N` expression takes the approximate
+    route for all of them) on random text over a small alphabet with two- and three-byte characters, batches of
+    ragged documents; product vs the oracle's restatement."""
+    rng = random.Random(7000 + seed)
+    alphabet = ["a", "b", "c", "\u00f6", "\u00fc", "\u20ac", " "]
+    chars = [c for c in alphabet if c != " "]
+    npat = rng.randint(1, 5)
+    defs = []
+    for i in range(npat):
+        n = rng.randint(2, 7)
+        word = "".join(rng.choice(chars) for _ in range(n))
+        dist = rng.randint(0, min(3, n - 1)) if i else rng.randint(1, min(3, n - 1))   # at least one ~N
+        defs.append((i + 1, word + (" ~%d" % dist if dist else ""), rng.randint(1, 3), rng.choice(["content", "content", "predecessor", "unique"])))
+
+    def build(x):
+        for pid, expr, level, bind in defs:
+            x.defineLexem(pid, expr, 0, level, bind)
+        x.compile()
+    lx, o = _both(build)
+    docs = []
+    for _ in range(40):
+        n = rng.choice([0, 1, 2, 5, 30, 70, 200, 700])
+        t = "".join(rng.choice(alphabet) for _ in range(n))
+        for _ in range(rng.randint(0, 4)):      # plant near-matches
+            w = list(rng.choice(defs)[1].split(" ~")[0])
+            if w and rng.random() < 0.7:
+                k = rng.randrange(len(w))
+                r = rng.random()
+                if r < 0.33:
+                    w[k] = rng.choice(chars)
+                elif r < 0.66:
+                    del w[k]
+                else:
+                    w.insert(k, rng.choice(chars))
+            at = rng.randint(0, len(t))
+            t = t[:at] + "".join(w) + t[at:]
+        docs.append(t.encode("utf8"))
+    ctx = lx.createContext()
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in docs])
+    got = ctx.matchDocs(b"".join(docs), offs)
+    for di, d in enumerate(docs):
+        want = o.match(d).tolist()
+        assert got.doc(di).tolist() == want, (defs, d)
+
+
+def test_approximate_table_survives_invalid_utf8():
+    def build(x):
+        x.defineLexem(1, "ab\u00f6 ~1", 0, 1, "content")
+        x.defineLexem(2, "\u00f6\u00f6", 0, 2, "content")
+        x.compile()
+    lx, o = _both(build)
+    for text in (b"ab\xc3", b"\xb6ab\xc3\xb6 a\xc3\xb6\xc3", b"\xf0\x9f ab\xc3\xb6\xff\xc3\xb6\xc3\xb6", b"\x80\x80ab"):
+        assert lx.createContext().match(text).tolist() == o.match(text).tolist(), text
+
+
 def test_supersede_levels_symbols():
     def build(x):
         x.defineLexem(1, "\\b\\w+\\b", 0, 1, "content")

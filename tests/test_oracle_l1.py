@@ -19,11 +19,23 @@ def test_char_regex_match_golden_case1():
     assert got == case["result"]
 
 
-def test_edit_distance_is_rejected_not_silently_ignored():
-    case = l1_cases.load_char_regex_cases()[1]
+@pytest.mark.parametrize("index", [1, 2])
+def test_char_regex_match_golden_edit_distance_cases(index):
+    """testCharRegexMatch.cpp:161-196: `abc ~1` on ASCII and `a\u00f6\u00fc ~1` on UTF-8 text, 5 lexems each -- the two
+    vectors that pin the restatement of the approximate route (oracle/l1_oracle.cpp)."""
+    case = l1_cases.load_char_regex_cases()[index]
     lx = oracle.L1Lexer()
-    with pytest.raises(oracle.OracleError):
-        l1_cases.build_case(lx, case)
+    l1_cases.build_case(lx, case)
+    got = lx.match(case["src"].encode()).tolist()
+    assert got == case["result"]
+
+
+def test_edit_distance_outside_the_restated_part_is_rejected_not_silently_ignored():
+    for expr in ("a[bc]d ~1", "\\bword\\b ~1", "ab ~2"):
+        lx = oracle.L1Lexer()
+        lx.defineLexem(1, expr, 0, 1, "content")
+        with pytest.raises(oracle.OracleError):
+            lx.compile()
 
 
 @pytest.mark.parametrize("seed", range(6))
