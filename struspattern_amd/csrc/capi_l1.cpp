@@ -130,7 +130,7 @@ size_t sp_lexer_dump_tables( const sp_lexer_t* l, uint64_t** out)
 	{
 		const DevLexPattern& p = T.patterns[i];
 		b.push_back( p.id); b.push_back( p.word); b.push_back( p.levelBind); b.push_back( p.prefixLen); b.push_back( p.suffixLen);
-		b.push_back( ((uint64_t)p.maskHi << 32) | p.maskLo);
+		b.push_back( ((uint64_t)p.maskHi << 32) | p.maskLo); b.push_back( p.defIndex);
 	}
 	// whole-word literals: count, then per literal {len, patCount, bytes..., pattern indices...}
 	b[5] = T.nofLiterals;
@@ -332,6 +332,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.reportQueue = (uint32_t*)c->dQueue.ptr; P.reportCount = (uint32_t*)c->dReportCount.ptr; P.queueMul = c->queueMul;
 	P.approx = T.approx.empty() ? 0 : (const DevApproxPattern*)c->dApprox.ptr; P.nofApprox = (uint32_t)T.approx.size();
 	P.charCp = (uint32_t*)c->dCharCp.ptr; P.charPos = (uint32_t*)c->dCharPos.ptr;
+	P.splitPatterns = (T.patterns.size() != c->inst->compiler.nofDefinitions()) ? 1u : 0u;
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
 	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = c->ldsWords;
 	P.ldsAccept = c->ldsAccept; P.ldsStart = c->ldsStart; P.ldsShift = c->ldsShift; P.ldsSelf = c->ldsSelf;

@@ -609,7 +609,9 @@ struct Automaton
 	uint64_t accept[ CTX_COUNT];		// positions a match may end with, by context of the byte after
 };
 
-Automaton makeAutomaton( const Tree& tree, const std::string& exprForError)
+struct TooWide {};		// more than 64 byte positions: the caller may cut the expression at an alternation
+
+Automaton makeAutomaton( const Tree& tree, const std::string&)
 {
 	Glushkov g;
 	Sets root = g.build( tree);
@@ -637,10 +639,7 @@ Automaton makeAutomaton( const Tree& tree, const std::string& exprForError)
 			parts[ p].push_back( (uint32_t)a.pos.size()); a.pos.push_back( byCtx[k]); ctxOf.push_back( k);
 		}
 	}
-	if (a.pos.size() > 64)
-	{
-		throw std::runtime_error( "failed to compile pattern \"" + exprForError + "\": expression too complex (more than 64 byte positions)");
-	}
+	if (a.pos.size() > 64) throw TooWide();
 	a.follow.assign( a.pos.size(), 0);
 	for (int c=0; c<CTX_COUNT; ++c) { a.start[c] = 0; a.accept[c] = 0; }
 	for (size_t i=0; i<g.edges.size(); ++i)
@@ -669,6 +668,52 @@ Automaton makeAutomaton( const Tree& tree, const std::string& exprForError)
 		}
 	}
 	return a;
+}
+
+size_t leafCount( const Tree& t)
+{
+	if (t.op == T_SET) return 1;
+	size_t n = 0;
+	for (size_t i=0; i<t.kids.size(); ++i) n += leafCount( t.kids[ i]);
+	return n;
+}
+// the widest alternation that is reached through concatenations and groups only: prefix (a|b|..) suffix is the
+// union of prefix (a|..) suffix and prefix (..|z) suffix
+Tree* widestAlternation( Tree& t)
+{
+	if (t.op == T_ALT) return &t;
+	if (t.op == T_GROUP) return widestAlternation( t.kids[ 0]);
+	if (t.op != T_CAT) return 0;
+	Tree* best = 0; size_t bestN = 0;
+	for (size_t i=0; i<t.kids.size(); ++i)
+	{
+		Tree* c = widestAlternation( t.kids[ i]);
+		if (c && leafCount( *c) > bestN) { best = c; bestN = leafCount( *c); }
+	}
+	return best;
+}
+// automata of an expression: one, or several that accept its language between them
+void makeAutomata( const Tree& tree, const std::string& expr, std::vector<Automaton>& out, unsigned depth=0)
+{
+	try { out.push_back( makeAutomaton( tree, expr)); return; }
+	catch (const TooWide&) {}
+	Tree lo = tree, hi = tree;
+	Tree* a = widestAlternation( lo);
+	Tree* b = widestAlternation( hi);
+	if (!a || a->kids.size() < 2 || depth > 8)
+	{
+		throw std::runtime_error( "failed to compile pattern \"" + expr + "\": expression too complex (more than 64 byte positions outside of an alternation)");
+	}
+	// halves of about equal width
+	const size_t total = leafCount( *a);
+	size_t cut = 0, acc = 0;
+	while (cut + 1 < a->kids.size() && acc + leafCount( a->kids[ cut]) <= total/2) { acc += leafCount( a->kids[ cut]); ++cut; }
+	if (cut == 0) cut = 1;
+	std::vector<Tree> first( a->kids.begin(), a->kids.begin() + cut), second( a->kids.begin() + cut, a->kids.end());
+	*a = Tree::alt( first); *b = Tree::alt( second);
+	makeAutomata( lo, expr, out, depth+1);
+	makeAutomata( hi, expr, out, depth+1);
+	if (out.size() > 32) throw std::runtime_error( "failed to compile pattern \"" + expr + "\": expression too complex (more than 32 words of 64 byte positions)");
 }
 
 bool sameNoCase( const std::string& a, const char* b)
@@ -811,7 +856,7 @@ void LexCompiler::compile()
 			if (d.editdist > L1_APPROX_MAXDIST || d.editdist >= ap.len) throw std::runtime_error( "failed to compile pattern \"" + d.expression + "\": the edit distance is at most 3 and below the number of characters");
 			T.approx.push_back( ap);
 			DevLexPattern dp; std::memset( &dp, 0, sizeof(dp));
-			dp.id = d.id; dp.levelBind = ap.levelBind; dp.word = L1_WORD_LITERAL;
+			dp.id = d.id; dp.levelBind = ap.levelBind; dp.word = L1_WORD_LITERAL; dp.defIndex = (uint32_t)di;
 			T.patterns.push_back( dp);
 			autos.push_back( Automaton());
 			for (int c=0; c<CTX_COUNT; ++c) { autos.back().start[c] = 0; autos.back().accept[c] = 0; }
@@ -820,7 +865,7 @@ void LexCompiler::compile()
 		Syntax syn( d.expression, m_options);
 		Tree tree = syn.run();
 		DevLexPattern dp; std::memset( &dp, 0, sizeof(dp));
-		dp.id = d.id;
+		dp.id = d.id; dp.defIndex = (uint32_t)di;
 		dp.levelBind = (d.level & 0xFF) | ((uint32_t)d.posbind << 8);
 		if (d.resultIndex)
 		{
@@ -837,15 +882,17 @@ void LexCompiler::compile()
 		if (!d.resultIndex && wholeWordLiterals( tree, words))
 		{
 			dp.word = L1_WORD_LITERAL;
-			for (size_t wi=0; wi<words.size(); ++wi) literalWords[ words[ wi]].push_back( (uint32_t)di);
+			for (size_t wi=0; wi<words.size(); ++wi) literalWords[ words[ wi]].push_back( (uint32_t)T.patterns.size());
 			T.patterns.push_back( dp);
 			autos.push_back( Automaton());
 			for (int c=0; c<CTX_COUNT; ++c) { autos.back().start[c] = 0; autos.back().accept[c] = 0; }
 			continue;
 		}
-		T.patterns.push_back( dp);
-		autos.push_back( makeAutomaton( tree, d.expression));
+		std::vector<Automaton> parts;
+		makeAutomata( tree, d.expression, parts);
+		for (size_t k=0; k<parts.size(); ++k) { T.patterns.push_back( dp); autos.push_back( parts[ k]); }
 	}
+	if (T.patterns.size() >= (1u << 24)) throw std::runtime_error( "too many patterns");
 
 	// 2. layout: a pattern never straddles a 64-bit word.  Patterns in definition order make the report
 	//    order for equal end offsets (ascending pattern index) fall out of the (pass, lane, bit) order;
@@ -1184,7 +1231,7 @@ void LexCompiler::compile()
 }
 
 // ---------------------------------------------------------------- compiled tables as a blob
-static const char L1_MAGIC[ 9] = "SPAL1v03";
+static const char L1_MAGIC[ 9] = "SPAL1v04";
 
 void LexCompiler::save( std::vector<uint8_t>& out) const
 {
@@ -1240,7 +1287,11 @@ void LexCompiler::load( const void* blob, size_t size)
 		Def d; d.expression = r.str(); d.id = r.u32(); d.resultIndex = r.u32(); d.level = r.u32(); d.editdist = r.u32(); d.posbind = (int)r.u32();
 		m_defs.push_back( d);
 	}
-	if (T.patterns.size() != m_defs.size() || (!T.approx.empty() && T.approx.size() != m_defs.size())) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	if (T.patterns.size() < m_defs.size() || (!T.approx.empty() && T.approx.size() != m_defs.size())) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	for (size_t i=0; i<T.patterns.size(); ++i)
+	{
+		if (T.patterns[ i].defIndex >= m_defs.size() || (i && T.patterns[ i].defIndex < T.patterns[ i-1].defIndex)) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	}
 	for (size_t i=0; i<T.approx.size(); ++i)
 	{
 		if (T.approx[ i].len == 0 || T.approx[ i].len > L1_APPROX_MAXCHARS || T.approx[ i].editdist > L1_APPROX_MAXDIST || T.approx[ i].editdist >= T.approx[ i].len || T.approx.size() > L1_APPROX_MAXPATTERNS)

@@ -56,6 +56,7 @@ public:
 	void defineSymbol( uint32_t symbolid, uint32_t patternid, const std::string& name);
 	uint32_t getSymbol( uint32_t patternid, const std::string& name) const;
 	void defineOption( const std::string& name, double value);
+	size_t nofDefinitions() const { return m_defs.size(); }
 	void compile();
 	bool compiled() const			{return m_compiled;}
 	const LexTables& tables() const		{return m_tables;}

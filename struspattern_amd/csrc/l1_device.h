@@ -66,6 +66,7 @@ struct L1Params
 	uint32_t nofApprox;
 	uint32_t* charCp;		// characters of document d: charCp / charPos [ begin(d)+d .. ), code point and byte offset
 	uint32_t* charPos;
+	uint32_t splitPatterns;		// some expression is cut into several patterns entries (same defIndex): their reports are merged
 };
 
 } // namespace

@@ -91,19 +91,19 @@ __device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* do
 
 // ---------------------------------------------------------------- stage 2: leftmost start per report
 // lane-parallel: lane i resolves report base+i
-struct LaneReport { u32 to, from, id, levelBind, prefixLen, suffixLen, pi; };	// one queued report per lane, pattern attributes attached
+struct LaneReport { u32 to, from, id, levelBind, prefixLen, suffixLen, pi, def, skip; };	// one queued report per lane, pattern attributes attached
 
 template <bool LDS>
 __device__ __forceinline__ void resolveStarts( const u32* queue, const unsigned char* doc, u32 docLen, const L1Params& P, const LexTab<LDS>& T, u32 base, u32 count, LaneReport& out)
 {
 	u32 i = base + LANE;
-	out.to = 0; out.from = 0; out.id = 0; out.levelBind = 0; out.prefixLen = 0; out.suffixLen = 0; out.pi = 0;
+	out.to = 0; out.from = 0; out.id = 0; out.levelBind = 0; out.prefixLen = 0; out.suffixLen = 0; out.pi = 0; out.def = 0; out.skip = 0;
 	if (LANE < count)
 	{
 		const uint4 q = *(const uint4*)(queue + 4*(u64)i);	// {to, pattern, accLo|from, accHi}
 		u32 to = q.x, pi = q.y & ~L1_LITERAL_FLAG;
 		const uint4 p0 = *(const uint4*)&P.patterns[ pi], p1 = *((const uint4*)&P.patterns[ pi] + 1);	// {id,word,levelBind,prefixLen} {suffixLen,maskLo,maskHi,-}
-		out.to = to; out.id = p0.x; out.levelBind = p0.z; out.prefixLen = p0.w; out.suffixLen = p1.x; out.pi = pi;
+		out.to = to; out.id = p0.x; out.levelBind = p0.z; out.prefixLen = p0.w; out.suffixLen = p1.x; out.pi = pi; out.def = p1.w;
 		if (q.y & L1_LITERAL_FLAG) { out.from = q.z; return; }		// whole-word literal: start already known
 		u64 R = ((u64)q.w << 32) | q.z;
 		const u32 pass = p0.y >> 6, ln = p0.y & 63u;
@@ -130,6 +130,35 @@ __device__ __forceinline__ void resolveStarts( const u32* queue, const unsigned 
 		}
 		out.from = from;
 	}
+}
+
+// The next batch of up to 64 reports with their starts.  An expression cut into several patterns entries reports
+// once per entry: the reports of one expression and one end offset are adjacent; the last of them takes the
+// leftmost start of the group, the others are marked to be skipped, and a group is never cut by a batch boundary.
+template <bool LDS>
+__device__ __forceinline__ void nextBatch( const u32* queue, const unsigned char* doc, u32 docLen, const L1Params& P, const LexTab<LDS>& T, u32 nq, u32 qb, u32& qn, LaneReport& lr)
+{
+	qn = (nq - qb) < 64u ? (nq - qb) : 64u;
+	resolveStarts( queue, doc, docLen, P, T, qb, qn, lr);
+	if (!P.splitPatterns) return;
+	if (qb + qn < nq)
+	{
+		const u32 nto = ldu( queue + 4*(u64)(qb+qn)), npi = ldu( queue + 4*(u64)(qb+qn) + 1) & ~(u32)L1_LITERAL_FLAG;
+		const u32 ndef = ldu( &P.patterns[ npi].defIndex);
+		const u32 lastTo = (u32)__builtin_amdgcn_readlane( lr.to, qn-1), lastDef = (u32)__builtin_amdgcn_readlane( lr.def, qn-1);
+		if (nto == lastTo && ndef == lastDef)
+		{
+			const u32 g = (u32)__builtin_popcountll( __ballot( LANE < qn && lr.to == lastTo && lr.def == lastDef));
+			if (g < qn) qn -= g;
+		}
+	}
+	for (u32 d=1; d<64; d<<=1)
+	{
+		const u32 pf = (u32)__shfl_up( (int)lr.from, d), pt = (u32)__shfl_up( (int)lr.to, d), pd = (u32)__shfl_up( (int)lr.def, d);
+		if (LANE >= d && LANE < qn && pt == lr.to && pd == lr.def && pf < lr.from) lr.from = pf;
+	}
+	const u32 nt = (u32)__shfl_down( (int)lr.to, 1), nd = (u32)__shfl_down( (int)lr.def, 1);
+	lr.skip = (LANE + 1u < qn && nt == lr.to && nd == lr.def) ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------- stage 3: the reference's handler
@@ -661,8 +690,8 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 	const u32 nq = w.nQueue;
 	u32 qi = 0, qb = 0, qn = 0;		// next report; the batch [qb, qb+qn) is resolved in lr
 	LaneReport lr;
-	lr.to = 0; lr.from = 0; lr.id = 0; lr.levelBind = 0; lr.prefixLen = 0; lr.suffixLen = 0; lr.pi = 0;
-	if (nq) { qn = nq < 64u ? nq : 64u; resolveStarts( w.queue, w.doc, w.docLen, P, T, 0, qn, lr); }
+	lr.to = 0; lr.from = 0; lr.id = 0; lr.levelBind = 0; lr.prefixLen = 0; lr.suffixLen = 0; lr.pi = 0; lr.def = 0; lr.skip = 0;
+	if (nq) nextBatch( w.queue, w.doc, w.docLen, P, T, nq, 0, qn, lr);
 	u32 ahead = (LANE < len) ? w.doc[ LANE] : 0u;		// the next tile's bytes are loaded one tile ahead
 	for (u32 tile=0; tile<=len && !w.err; tile+=64)
 	{
@@ -709,7 +738,7 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 				const u32 hsuf = lit ? 0u : (u32)__builtin_amdgcn_readlane( lr.suffixLen, x);
 				const u32 hfrom = lit ? lfrom : (u32)__builtin_amdgcn_readlane( lr.from, x);
 				const u64 tH = PROF_T();
-				handleReport( w, P, hid, hlb, hpre, hsuf, hfrom, toNext);
+				if (lit || !__builtin_amdgcn_readlane( lr.skip, x)) handleReport( w, P, hid, hlb, hpre, hsuf, hfrom, toNext);
 				PROF_ACC( 3, tH);
 				if (lit)
 				{
@@ -726,9 +755,9 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 					++qi;
 					if (qi == qb + qn && qi < nq)
 					{
-						qb = qi; qn = (nq - qb) < 64u ? (nq - qb) : 64u;
+						qb = qi;
 						const u64 tR = PROF_T();
-						resolveStarts( w.queue, w.doc, w.docLen, P, T, qb, qn, lr);
+						nextBatch( w.queue, w.doc, w.docLen, P, T, nq, qb, qn, lr);
 						PROF_ACC( 2, tR);
 					}
 				}

@@ -22,15 +22,15 @@ enum {L1_WORDS_PER_PASS=64};
 enum {L1_WORD_LITERAL=0xFFFFFFFFu};	// pattern \bWORD\b handled by the token hash instead of automaton bits
 enum {L1_LITERAL_FLAG=0x80000000u};	// queue records: start offset already known
 
-struct DevLexPattern		// 32 B, one per defineLexem call, index = definition index (0-based)
-{
+struct DevLexPattern		// 32 B, one per defineLexem call in definition order; an expression too wide for one 64-bit word
+{				// is cut at an alternation into several entries (adjacent, same defIndex) whose reports are merged
 	uint32_t id;		// lexem id reported
 	uint32_t word;		// global word index (pass*64 + lane) holding the pattern's positions; L1_WORD_LITERAL = none
 	uint32_t levelBind;	// level | posbind<<8 | hasSymbols<<16 | hasSubexpr<<17
 	uint32_t prefixLen;	// sub-expression selection: bytes cut at the front ...
 	uint32_t suffixLen;	// ... and at the back of the raw match (fixed-length context)
 	uint32_t maskLo, maskHi;// bits of the word that belong to this pattern
-	uint32_t _pad;
+	uint32_t defIndex;	// definition index (0-based)
 };
 
 // Approximate literal tables (a table with a `~N` expression, src/patternLexer.cpp:333-412): every expression is

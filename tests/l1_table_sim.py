@@ -35,8 +35,8 @@ class Tables:
         self.E = E
         self.patterns = []
         for i in range(self.nofPatterns):
-            pid, word, lb, pre, suf, mask = take(6)
-            self.patterns.append(dict(id=pid, word=word, levelBind=lb, prefixLen=pre, suffixLen=suf, mask=mask))
+            pid, word, lb, pre, suf, mask, defidx = take(7)
+            self.patterns.append(dict(id=pid, word=word, levelBind=lb, prefixLen=pre, suffixLen=suf, mask=mask, defIndex=defidx))
         self.literals = {}
         for i in range(self.nofLiterals):
             ln, pc = take(2)
@@ -91,7 +91,16 @@ class Tables:
             else:
                 i += 1
         out.sort(key=lambda r: (r[2], r[0]))
-        return out
+        # an expression cut into several entries reports once per entry: one report per (definition, end) with the
+        # leftmost start, numbered by definition
+        merged = []
+        for pi, frm, to in out:
+            d = self.patterns[pi - 1]["defIndex"] + 1
+            if merged and merged[-1][0] == d and merged[-1][2] == to:
+                merged[-1] = (d, min(merged[-1][1], frm), to)
+            else:
+                merged.append((d, frm, to))
+        return merged
 
     def som(self, text, pi, to, R):
         pat = self.patterns[pi]

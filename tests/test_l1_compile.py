@@ -80,6 +80,26 @@ def test_options_and_utf8():
         assert _product_reports(pats, t, opts) == _oracle_reports(pats, t, opts), (pats, text, opts)
 
 
+def test_wide_alternations_are_cut_into_several_words():
+    """An expression of more than 64 byte positions is cut at an alternation into entries of one 64-bit word each
+    (same definition index); their reports are merged into one per end offset with the leftmost start."""
+    tlds = "aero|asia|biz|cat|com|coop|edu|gov|info|int|jobs|mil|mobi|museum|name|net|org|pro|tel|travel|ac|ad|ae|af|ag|ai|al|am|an|ao|aq|ar|as|at|au|aw|ax|az|ba|bb|bd|be|ch|de|uk|us"
+    pats = ["([^\\s/?\\.#-][^\\s/?\\.#-]+\\.)(%s)" % tlds, "\\b\\w+\\b", "x(%s)y|z(%s)" % (tlds, tlds)]
+    lx = spa.PatternLexerInstance()
+    for i, p in enumerate(pats):
+        lx.defineLexem(i + 1, p, 0, 1, "content")
+    lx.compile()
+    T = Tables(lx.dumpTables())
+    assert len(T.patterns) > len(pats) and sorted(set(p["defIndex"] for p in T.patterns)) == [0, 1, 2]
+    for text in (b"see www.etc.ch or mail.museum.travel, not a.b; xaeroy zcom xxbey www.example.com/x?y",
+                 b"a.ch", b"ab.ch.de.uk", b"", b"xmuseumy.aero zaero.info.infox"):
+        assert _product_reports(pats, text) == _oracle_reports(pats, text), text
+    lx = spa.PatternLexerInstance()
+    lx.defineLexem(1, "a" * 70, 0, 1, "content")       # nothing to cut at
+    with pytest.raises(spa.PatternError):
+        lx.compile()
+
+
 def test_compile_errors_are_reported():
     for bad in ["(abc", "abc)", "[abc", "a{3,1}", "*a", "\\p{Lu}", "(?=a)b", "a\\"]:
         lx = spa.PatternLexerInstance()

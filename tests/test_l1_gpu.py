@@ -99,6 +99,29 @@ def test_approximate_table_survives_invalid_utf8():
         assert lx.createContext().match(text).tolist() == o.match(text).tolist(), text
 
 
+def test_wide_alternations_cut_into_several_words():
+    """Expressions beyond 64 byte positions (cut at an alternation into several automaton words): several words of
+    one expression report at the same end offset with different starts (suffix-related alternatives sit in
+    different words), on enough text that groups of such reports meet the 64-report batch boundaries."""
+    words = ["w%02d%s" % (i, "xyz"[i % 3] * (1 + i % 4)) for i in range(30)]
+    alts = ["abcdefgh"] + words[:15] + ["cdefgh"] + words[15:] + ["fgh", "h"]
+
+    def build(x):
+        x.defineLexem(1, "(%s)" % "|".join(alts), 0, 2, "content")
+        x.defineLexem(2, "[a-z0-9]+", 0, 1, "content")
+        x.defineLexem(3, "q(%s)\\b" % "|".join(alts), 0, 3, "content")
+        x.compile()
+    lx, o = _both(build)
+    rng = random.Random(5)
+    pieces = ["abcdefgh", "xcdefgh", "fgh", "h", "qabcdefghfgh", " ", " ", "zz"] + words
+    docs = [" ".join(rng.choice(pieces) for _ in range(n)).encode() for n in (0, 1, 3, 40, 300, 1500)]
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in docs])
+    got = lx.createContext().matchDocs(b"".join(docs), offs)
+    for di, d in enumerate(docs):
+        assert got.doc(di).tolist() == o.match(d).tolist(), d[:80]
+
+
 def test_supersede_levels_symbols():
     def build(x):
         x.defineLexem(1, "\\b\\w+\\b", 0, 1, "content")
