@@ -8,6 +8,8 @@ using namespace oracle;
 
 namespace oracle {
 
+#include "unicode_categories.inc"
+
 // ------------------------------------------------------------------ regex AST
 struct Ast
 {
@@ -111,6 +113,31 @@ private:
 			case 'W': negated = true; /*fall*/ case 'w': addRange( r, '0','9'); addRange( r,'A','Z'); addRange( r,'a','z'); addRange( r,'_','_'); break;
 			case 'S': negated = true; /*fall*/ case 's': addRange( r, 9, 13); addRange( r, ' ', ' '); break;
 		}
+	}
+	// \\p{Name} / \\pL / \\P{..} / \\p{^..}: a Unicode general category (m_pos is behind the 'p' or 'P')
+	Ranges propertyClass( bool negated)
+	{
+		if (!m_utf8) fail( "unicode properties need UTF-8 mode");
+		std::string name;
+		if (more() && peek() == '{')
+		{
+			size_t e = m_src.find( '}', m_pos);
+			if (e == std::string::npos) fail( "unterminated \\p{..}");
+			name = m_src.substr( m_pos+1, e-m_pos-1); m_pos = e+1;
+		}
+		else if (more()) { name = std::string( 1, (char)peek()); ++m_pos; }
+		if (!name.empty() && name[0] == '^') { negated = !negated; name.erase( 0, 1); }
+		Ranges r;
+		for (const UcCategory* c=UC_CATEGORIES; c->name; ++c)
+		{
+			if (name == c->name)
+			{
+				for (uint32_t i=0; i<c->count; ++i) addRange( r, c->ranges[i].lo, c->ranges[i].hi);
+				return negated ? negate( r) : r;
+			}
+		}
+		fail( "unknown unicode property");
+		return r;
 	}
 	uint32_t maxCp() const { return m_utf8 ? 0x10FFFFu : 0xFFu; }
 	static Ranges normalize( Ranges r)
@@ -243,7 +270,7 @@ private:
 						addClassEscape( r, e, neg);
 						return makeSetNoFold( neg ? negate( r) : r);
 					}
-					case 'p': case 'P': fail( "unicode properties (UCP) are not supported");
+					case 'p': case 'P': return makeSetNoFold( propertyClass( e == 'P'));
 					default:
 					{
 						Ranges r; uint32_t v = parseEscapeChar( e); addRange( r, v, v);
@@ -314,6 +341,7 @@ private:
 					r.insert( r.end(), t.begin(), t.end());
 					continue;
 				}
+				if (e == 'p' || e == 'P') { Ranges t = propertyClass( e == 'P'); r.insert( r.end(), t.begin(), t.end()); continue; }
 				if (e == 'b') lo = 8;
 				else lo = parseEscapeChar( e);
 			}

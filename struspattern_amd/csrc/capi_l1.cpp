@@ -41,7 +41,7 @@ struct sp_lexer_ctx
 	int device;
 	std::string lasterror;
 	DeviceBuffer dByteClass, dClassCtx, dCharMask, dStartMask, dAcceptMask, dShiftDst, dSelfLoop, dExSrc, dExDst, dExCount,
-		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit, dApprox, dCharCp, dCharPos;
+		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit, dApprox, dCharCp, dCharPos, dCpBlocks, dCpPages;
 	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst; unsigned blockThreads;
 	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus, dQueue, dReportCount;
 	uint32_t queueMul;		// report queue between the two kernels: queueMul/16 reports per text byte (+64 per document)
@@ -143,6 +143,11 @@ size_t sp_lexer_dump_tables( const sp_lexer_t* l, uint64_t** out)
 		for (uint32_t k=0; k<e.len; ++k) b.push_back( T.literalText[ e.textOffset+k]);
 		for (uint32_t k=0; k<e.patCount; ++k) b.push_back( T.litPats[ e.patBegin+k]);
 	}
+	// classes by code point: block table and pages (both may be empty)
+	b.push_back( T.cpBlocks.size());
+	for (size_t i=0; i<T.cpBlocks.size(); ++i) b.push_back( T.cpBlocks[ i]);
+	b.push_back( T.cpPages.size());
+	for (size_t i=0; i<T.cpPages.size(); ++i) b.push_back( T.cpPages[ i]);
 	*out = (uint64_t*)std::malloc( (b.size()+1)*sizeof(uint64_t));
 	if (!*out) return 0;
 	std::memcpy( *out, b.data(), b.size()*sizeof(uint64_t));
@@ -191,6 +196,7 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 		c->dLiterals.upload( T.literals.data(), T.literals.size()*sizeof(DevLiteral));
 		c->dLiteralText.upload( T.literalText.data(), T.literalText.size());
 		c->dLitPats.upload( T.litPats.data(), T.litPats.size()*4);
+		if (!T.cpBlocks.empty()) { c->dCpBlocks.upload( T.cpBlocks.data(), T.cpBlocks.size()*2); c->dCpPages.upload( T.cpPages.data(), T.cpPages.size()); }
 		if (!T.approx.empty()) c->dApprox.upload( T.approx.data(), T.approx.size()*sizeof(DevApproxPattern));
 		{
 			// LDS image of the hot tables when it fits (one copy per workgroup; bigger workgroups when the copy is big)
@@ -332,6 +338,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.reportQueue = (uint32_t*)c->dQueue.ptr; P.reportCount = (uint32_t*)c->dReportCount.ptr; P.queueMul = c->queueMul;
 	P.approx = T.approx.empty() ? 0 : (const DevApproxPattern*)c->dApprox.ptr; P.nofApprox = (uint32_t)T.approx.size();
 	P.charCp = (uint32_t*)c->dCharCp.ptr; P.charPos = (uint32_t*)c->dCharPos.ptr;
+	P.cpBlocks = T.cpBlocks.empty() ? 0 : (const uint16_t*)c->dCpBlocks.ptr; P.cpPages = (const uint8_t*)c->dCpPages.ptr;
 	P.splitPatterns = (T.patterns.size() != c->inst->compiler.nofDefinitions()) ? 1u : 0u;
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
 	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = c->ldsWords;

@@ -20,10 +20,18 @@ namespace {
 
 typedef std::vector<std::pair<uint32_t,uint32_t> > CpRanges;
 
+#include "unicode_categories.inc"
+
+
+// A leaf of the expression tree: a set of byte values.  A leaf with cpRef >= 0 stands for the lead byte of a
+// character whose code point is in the registered set cpRef (all of one UTF-8 length); its byte set then holds
+// the lead bytes such characters begin with, and positions of that kind get their class from the code point
+// (LexTables::cpBlocks / cpPages) instead of from the byte.
 struct ByteSet
 {
 	uint64_t w[4];
-	ByteSet() { w[0]=w[1]=w[2]=w[3]=0; }
+	int cpRef;
+	ByteSet() :cpRef(-1) { w[0]=w[1]=w[2]=w[3]=0; }
 	void add( unsigned c) { w[ c>>6] |= (1ull << (c&63)); }
 	void addRange( unsigned lo, unsigned hi) { for (unsigned c=lo; c<=hi; ++c) add( c); }
 	bool has( unsigned c) const { return (w[ c>>6] >> (c&63)) & 1ull; }
@@ -91,9 +99,9 @@ void splitUtf8( uint32_t lo, uint32_t hi, std::vector<Tree>& alts)
 class Syntax
 {
 public:
-	Syntax( const std::string& text, unsigned options)
+	Syntax( const std::string& text, unsigned options, std::vector<CpRanges>* cpSets)
 		:m_text(text),m_at(0),m_caseless((options & LEX_CASELESS)!=0),m_dotall((options & LEX_DOTALL)!=0)
-		,m_multiline((options & LEX_MULTILINE)!=0),m_utf8(true),m_groups(0){}
+		,m_multiline((options & LEX_MULTILINE)!=0),m_utf8(true),m_groups(0),m_cpSets(cpSets){}
 
 	Tree run()
 	{
@@ -108,6 +116,7 @@ private:
 	size_t m_at;
 	bool m_caseless, m_dotall, m_multiline, m_utf8;
 	unsigned m_groups;
+	std::vector<CpRanges>* m_cpSets;
 
 	void error( const std::string& what) const { throw std::runtime_error( "failed to compile pattern \"" + m_text + "\": " + what); }
 	bool done() const { return m_at >= m_text.size(); }
@@ -233,6 +242,7 @@ private:
 			return Tree::leaf( s);
 		}
 		std::vector<Tree> alts;
+		CpRanges rest;			// what is neither ASCII nor "everything beyond ASCII"
 		// merge all one-byte alternatives into a single leaf
 		ByteSet ascii; bool haveAscii = false;
 		for (size_t i=0; i<r.size(); ++i)
@@ -256,10 +266,70 @@ private:
 				alts.push_back( Tree::cat( s2));
 				continue;
 			}
-			splitUtf8( lo, hi, alts);
+			rest.push_back( std::make_pair( lo, hi));
+		}
+		if (rest.size() <= 4)
+		{
+			for (size_t i=0; i<rest.size(); ++i) splitUtf8( rest[i].first, rest[i].second, alts);
+		}
+		else
+		{
+			// a large set (a Unicode category): ((P4 C | P3) C | P2) C where Pn is the lead byte of an n-byte
+			// character of the set -- told by its code point, see ByteSet::cpRef -- and C any continuation byte
+			static const uint32_t lenLo[5] = {0,0,0x80,0x800,0x10000}, lenHi[5] = {0,0,0x7FF,0xFFFF,0x10FFFF};
+			ByteSet c; c.addRange( 0x80, 0xBF);
+			Tree level; bool have = false;
+			for (int n=4; n>=2; --n)
+			{
+				CpRanges part;
+				ByteSet leads;
+				for (size_t i=0; i<rest.size(); ++i)
+				{
+					uint32_t lo = std::max( rest[i].first, lenLo[n]), hi = std::min( rest[i].second, lenHi[n]);
+					if (lo > hi) continue;
+					part.push_back( std::make_pair( lo, hi));		// (a negated set holds the surrogate range like any other; ED A0..BF xx decodes to it)
+				}
+				for (size_t i=0; i<part.size(); ++i)
+				{
+					unsigned char a[4], b[4]; encodeUtf8( part[i].first, a); encodeUtf8( part[i].second, b);
+					leads.addRange( a[0], b[0]);
+				}
+				std::vector<Tree> branches;
+				if (have) { std::vector<Tree> sq; sq.push_back( level); sq.push_back( Tree::leaf( c)); branches.push_back( Tree::cat( sq)); }
+				if (!part.empty())
+				{
+					leads.cpRef = (int)m_cpSets->size(); m_cpSets->push_back( part);
+					branches.push_back( Tree::leaf( leads));
+				}
+				if (!branches.empty()) { level = Tree::alt( branches); have = true; }
+			}
+			if (have) { std::vector<Tree> sq; sq.push_back( level); sq.push_back( Tree::leaf( c)); alts.push_back( Tree::cat( sq)); }
 		}
 		if (haveAscii) alts.insert( alts.begin(), Tree::leaf( ascii));
 		return Tree::alt( alts);
+	}
+	// \\p{Name}, \\pL, \\P{..}, \\p{^..}: Unicode general category (m_at is behind the p / P)
+	void property( bool negated, CpRanges& r)
+	{
+		std::string name;
+		if (lookingAt( '{'))
+		{
+			size_t e = m_text.find( '}', m_at);
+			if (e == std::string::npos) error( "unterminated \\p{..}");
+			name = m_text.substr( m_at+1, e-m_at-1); m_at = e+1;
+		}
+		else if (!done()) { name = std::string( 1, (char)cur()); ++m_at; }
+		if (!name.empty() && name[0] == '^') { negated = !negated; name.erase( 0, 1); }
+		for (const UcCategory* c=UC_CATEGORIES; c->name; ++c)
+		{
+			if (name != c->name) continue;
+			CpRanges t;
+			for (uint32_t i=0; i<c->count; ++i) t.push_back( std::make_pair( c->ranges[i].lo, c->ranges[i].hi));
+			if (negated) t = complement( t);
+			r.insert( r.end(), t.begin(), t.end());
+			return;
+		}
+		error( "unknown unicode property \\p{" + name + "}");
 	}
 	static void shorthand( char e, CpRanges& r)
 	{
@@ -342,6 +412,7 @@ private:
 				unsigned char e = cur(); ++m_at;
 				if (e=='d'||e=='w'||e=='s') { shorthand( (char)e, r); continue; }
 				if (e=='D'||e=='W'||e=='S') { CpRanges t; shorthand( (char)e, t); t = complement( t); r.insert( r.end(), t.begin(), t.end()); continue; }
+				if (e=='p'||e=='P') { property( e == 'P', r); continue; }
 				lo = (e == 'b') ? 8 : escapedChar( e);
 			}
 			else lo = literalChar();
@@ -404,7 +475,7 @@ private:
 				case 'z': return assertNode( A_EOD);
 				case 'd': case 'w': case 's': { CpRanges r; shorthand( (char)e, r); return fromRanges( r); }
 				case 'D': case 'W': case 'S': { CpRanges r; shorthand( (char)e, r); return fromRanges( complement( r)); }
-				case 'p': case 'P': error( "unicode properties need UCP, which is not supported");
+				case 'p': case 'P': { CpRanges r; property( e == 'P', r); return fromRanges( r); }
 			}
 			CpRanges r; uint32_t v = escapedChar( e); r.push_back( std::make_pair( v, v));
 			fold( r);
@@ -636,6 +707,7 @@ Automaton makeAutomaton( const Tree& tree, const std::string&)
 		for (unsigned c=0; c<256; ++c) if (g.positions[ p].has( c)) byCtx[ ctxOfByte( c)].add( c);
 		for (int k=0; k<3; ++k) if (!byCtx[k].empty())
 		{
+			byCtx[k].cpRef = g.positions[ p].cpRef;
 			parts[ p].push_back( (uint32_t)a.pos.size()); a.pos.push_back( byCtx[k]); ctxOf.push_back( k);
 		}
 	}
@@ -823,6 +895,7 @@ void LexCompiler::compile()
 	}
 
 	// 1. per pattern automata
+	std::vector<CpRanges> cpSets;			// code point sets of the leaves with ByteSet::cpRef
 	std::vector<Automaton> autos;
 	std::map<std::string,std::vector<uint32_t> > literalWords;
 	T.patterns.clear();
@@ -862,7 +935,7 @@ void LexCompiler::compile()
 			for (int c=0; c<CTX_COUNT; ++c) { autos.back().start[c] = 0; autos.back().accept[c] = 0; }
 			continue;
 		}
-		Syntax syn( d.expression, m_options);
+		Syntax syn( d.expression, m_options, &cpSets);
 		Tree tree = syn.run();
 		DevLexPattern dp; std::memset( &dp, 0, sizeof(dp));
 		dp.id = d.id; dp.defIndex = (uint32_t)di;
@@ -980,7 +1053,7 @@ void LexCompiler::compile()
 			if (!ok || !anyStart) { singles.push_back( pi); continue; }
 			std::string key;
 			for (unsigned c=0; c<256; c+=8) { unsigned char b = 0; for (unsigned x=0; x<8; ++x) if (a.pos[ 0].has( c+x)) b |= (unsigned char)(1u << x); key.push_back( (char)b); }
-			key.push_back( (char)(a.follow[ 0] & 1ull));
+			key.push_back( (char)(a.follow[ 0] & 1ull)); key.push_back( (char)(a.pos[ 0].cpRef & 0xFF)); key.push_back( (char)((a.pos[ 0].cpRef >> 8) & 0xFF));
 			for (int c=0; c<CTX_COUNT; ++c) key.push_back( (char)(a.start[ c] & 1ull));
 			groups[ key].push_back( pi);
 		}
@@ -1105,6 +1178,70 @@ void LexCompiler::compile()
 		T.nofClasses = (uint32_t)classOf.size();
 	}
 
+	// 3b. classes by code point.  A position with a code point set (ByteSet::cpRef) is entered at the lead byte of a
+	//     well-formed character and looks at its code point; every other position looks at the lead byte as a byte.
+	//     Code points that no position tells apart are one class, numbered behind the byte classes.
+	const uint32_t nofByteClasses = T.nofClasses;
+	std::vector<uint32_t> repCpOfClass;		// class id - nofByteClasses -> a code point of the class
+	T.cpBlocks.clear(); T.cpPages.clear();
+	if (!cpSets.empty())
+	{
+		std::vector<uint32_t> cut;
+		for (uint32_t cp=0x80; cp<0x800; cp+=64) cut.push_back( cp);			// one lead byte each
+		for (uint32_t cp=0x800; cp<0x10000; cp=(cp+0x1000) & ~0xFFFu) cut.push_back( cp);
+		for (uint32_t cp=0x10000; cp<0x110000; cp=(cp+0x40000) & ~0x3FFFFu) cut.push_back( cp);
+		cut.push_back( 0x110000);
+		for (size_t i=0; i<cpSets.size(); ++i) for (size_t k=0; k<cpSets[ i].size(); ++k) { cut.push_back( cpSets[ i][ k].first); cut.push_back( cpSets[ i][ k].second+1); }
+		std::sort( cut.begin(), cut.end()); cut.erase( std::unique( cut.begin(), cut.end()), cut.end());
+		auto inSet = [&]( int ref, uint32_t cp) -> bool
+		{
+			const CpRanges& r = cpSets[ ref];
+			size_t lo = 0, hi = r.size();
+			while (lo < hi) { size_t mid = (lo+hi)/2; if (r[ mid].second < cp) lo = mid+1; else hi = mid; }
+			return lo < r.size() && r[ lo].first <= cp;
+		};
+		std::vector<uint8_t> flat( 0x110000, 0xFF);
+		std::map<uint64_t,uint32_t> classOfSig;
+		for (size_t ai=0; ai+1<cut.size(); ++ai)
+		{
+			const uint32_t cp = cut[ ai];
+			if (cp < 0x80 || cp >= 0x110000) continue;
+			unsigned char enc[4]; encodeUtf8( cp, enc);
+			uint64_t sig = 1469598103934665603ull;
+			uint32_t gp = 0;
+			for (size_t pi=0; pi<autos.size(); ++pi) for (size_t k=0; k<autos[ pi].pos.size(); ++k, ++gp)
+			{
+				const ByteSet& b = autos[ pi].pos[ k];
+				if (b.cpRef >= 0 ? inSet( b.cpRef, cp) : b.has( enc[0])) sig = (sig ^ (gp+1)) * 1099511628211ull + 0x9E3779B97F4A7C15ull;
+			}
+			std::map<uint64_t,uint32_t>::const_iterator it = classOfSig.find( sig);
+			uint32_t cls;
+			if (it == classOfSig.end())
+			{
+				cls = T.nofClasses++;
+				if (cls > 254) throw std::runtime_error( "too many distinct character classes");
+				classOfSig[ sig] = cls; T.classCtx.push_back( (uint8_t)CTX_OTHER); repCpOfClass.push_back( cp);
+			}
+			else cls = it->second;
+			for (uint32_t c=cp; c<cut[ ai+1]; ++c) flat[ c] = (uint8_t)cls;
+		}
+		std::map<std::string,uint16_t> pageOf;
+		for (uint32_t blk=0; blk<0x110000/64; ++blk)
+		{
+			std::string key( (const char*)&flat[ (size_t)blk*64], 64);
+			std::map<std::string,uint16_t>::const_iterator it = pageOf.find( key);
+			uint16_t page;
+			if (it == pageOf.end())
+			{
+				if (pageOf.size() >= 0xFFFF) throw std::runtime_error( "too many distinct character class pages");
+				page = (uint16_t)pageOf.size(); pageOf[ key] = page;
+				T.cpPages.insert( T.cpPages.end(), key.begin(), key.end());
+			}
+			else page = it->second;
+			T.cpBlocks.push_back( page);
+		}
+	}
+
 	// 4. masks
 	T.charMask.assign( (size_t)T.nofPasses * T.nofClasses * 64, 0);
 	T.startMask.assign( (size_t)T.nofPasses * CTX_COUNT * 64, 0);
@@ -1114,7 +1251,7 @@ void LexCompiler::compile()
 	std::vector<std::map<uint64_t,uint64_t> > exBySrc( totalWords);	// src bit -> dst set (edges that are neither self loop nor shift)
 	std::vector<std::map<uint64_t,uint64_t> > exOfWord( totalWords);	// dst set -> src set
 	std::vector<unsigned char> repOfClass( T.nofClasses, 0);
-	for (unsigned c=256; c-->0;) repOfClass[ T.byteClass[ c]] = (unsigned char)c;
+	for (unsigned c=256; c-->0;) repOfClass[ T.byteClass[ c]] = (unsigned char)c;	// (byte classes; the classes by code point come behind them)
 	for (size_t pi=0; pi<autos.size(); ++pi)
 	{
 		const Automaton& a = autos[ pi];
@@ -1133,7 +1270,20 @@ void LexCompiler::compile()
 		{
 			for (uint32_t cls=0; cls<T.nofClasses; ++cls)
 			{
-				if (a.pos[k].has( repOfClass[ cls])) T.charMask[ ((size_t)pass*T.nofClasses + cls)*64 + lane] |= 1ull << bit[ k];
+				bool member;
+				if (cls < nofByteClasses) member = a.pos[k].cpRef < 0 && a.pos[k].has( repOfClass[ cls]);
+				else
+				{
+					const uint32_t cp = repCpOfClass[ cls - nofByteClasses];
+					if (a.pos[k].cpRef >= 0)
+					{
+						const CpRanges& r = cpSets[ a.pos[k].cpRef];
+						member = false;
+						for (size_t q=0; q<r.size() && !member; ++q) member = r[ q].first <= cp && cp <= r[ q].second;
+					}
+					else { unsigned char enc[4]; encodeUtf8( cp, enc); member = a.pos[k].has( enc[0]); }
+				}
+				if (member) T.charMask[ ((size_t)pass*T.nofClasses + cls)*64 + lane] |= 1ull << bit[ k];
 			}
 			uint64_t f = a.follow[ k];
 			if (f & (1ull << k)) { T.selfLoop[ pass*64 + lane] |= 1ull << bit[ k]; f &= ~(1ull << k); }
@@ -1231,7 +1381,7 @@ void LexCompiler::compile()
 }
 
 // ---------------------------------------------------------------- compiled tables as a blob
-static const char L1_MAGIC[ 9] = "SPAL1v04";
+static const char L1_MAGIC[ 9] = "SPAL1v05";
 
 void LexCompiler::save( std::vector<uint8_t>& out) const
 {
@@ -1240,7 +1390,7 @@ void LexCompiler::save( std::vector<uint8_t>& out) const
 	const LexTables& T = m_tables;
 	w.u32( m_options);
 	w.u32( T.nofPasses); w.u32( T.nofClasses); w.u32( T.maxExceptions); w.u32( T.nofLiterals); w.u32( T.nofPositions); w.u32( T.reportsOrdered ? 1u : 0u);
-	w.vec( T.byteClass); w.vec( T.classCtx); w.vec( T.charMask); w.vec( T.startMask); w.vec( T.acceptMask); w.vec( T.shiftDst); w.vec( T.selfLoop);
+	w.vec( T.byteClass); w.vec( T.classCtx); w.vec( T.cpBlocks); w.vec( T.cpPages); w.vec( T.charMask); w.vec( T.startMask); w.vec( T.acceptMask); w.vec( T.shiftDst); w.vec( T.selfLoop);
 	w.vec( T.exCount); w.vec( T.exSrc); w.vec( T.exDst); w.vec( T.wordPatBegin); w.vec( T.wordPats); w.vec( T.patOfBit);
 	w.vec( T.patterns); w.vec( T.symbols); w.vec( T.symbolText); w.vec( T.literals); w.vec( T.literalText); w.vec( T.litPats); w.vec( T.approx);
 	w.u32( (uint32_t)m_defs.size());
@@ -1266,7 +1416,7 @@ void LexCompiler::load( const void* blob, size_t size)
 	LexTables T;
 	m_options = r.u32();
 	T.nofPasses = r.u32(); T.nofClasses = r.u32(); T.maxExceptions = r.u32(); T.nofLiterals = r.u32(); T.nofPositions = r.u32(); T.reportsOrdered = r.u32() != 0;
-	r.vec( T.byteClass); r.vec( T.classCtx); r.vec( T.charMask); r.vec( T.startMask); r.vec( T.acceptMask); r.vec( T.shiftDst); r.vec( T.selfLoop);
+	r.vec( T.byteClass); r.vec( T.classCtx); r.vec( T.cpBlocks); r.vec( T.cpPages); r.vec( T.charMask); r.vec( T.startMask); r.vec( T.acceptMask); r.vec( T.shiftDst); r.vec( T.selfLoop);
 	r.vec( T.exCount); r.vec( T.exSrc); r.vec( T.exDst); r.vec( T.wordPatBegin); r.vec( T.wordPats); r.vec( T.patOfBit);
 	r.vec( T.patterns); r.vec( T.symbols); r.vec( T.symbolText); r.vec( T.literals); r.vec( T.literalText); r.vec( T.litPats); r.vec( T.approx);
 	// the shapes the kernel indexes by must fit together (a blob of another build would fault on the device)
@@ -1280,6 +1430,12 @@ void LexCompiler::load( const void* blob, size_t size)
 		throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
 	}
 	for (size_t i=0; i<T.byteClass.size(); ++i) if (T.byteClass[ i] >= T.nofClasses) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	if (!T.cpBlocks.empty())
+	{
+		if (T.cpBlocks.size() != 0x110000/64 || T.cpPages.size() % 64) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+		for (size_t i=0; i<T.cpBlocks.size(); ++i) if ((size_t)T.cpBlocks[ i]*64 + 64 > T.cpPages.size()) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+		for (size_t i=0; i<T.cpPages.size(); ++i) if (T.cpPages[ i] != 0xFF && T.cpPages[ i] >= T.nofClasses) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	}
 	m_defs.clear(); m_symbols.clear(); m_names.clear();
 	const uint32_t nd = r.u32();
 	for (uint32_t i=0; i<nd; ++i)

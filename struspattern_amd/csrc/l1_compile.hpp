@@ -21,6 +21,10 @@ struct LexTables
 	uint32_t maxExceptions;			// per word, over all passes
 	std::vector<uint8_t> byteClass;		// 256 -> class id
 	std::vector<uint8_t> classCtx;		// class id -> CTX_*
+	// classes by code point for the lead byte of a well-formed multi-byte character (only when some expression holds
+	// a large code point set, e.g. \p{Lu}): class = cpPages[ cpBlocks[ cp>>6]*64 + (cp&63)], 0xFF = none (use the byte's class)
+	std::vector<uint16_t> cpBlocks;		// empty or 0x110000/64 entries
+	std::vector<uint8_t> cpPages;
 	std::vector<uint64_t> charMask;		// [pass][class][64]
 	std::vector<uint64_t> startMask;	// [pass][CTX_COUNT][64]
 	std::vector<uint64_t> acceptMask;	// [pass][CTX_COUNT][64]

@@ -66,6 +66,8 @@ struct L1Params
 	uint32_t nofApprox;
 	uint32_t* charCp;		// characters of document d: charCp / charPos [ begin(d)+d .. ), code point and byte offset
 	uint32_t* charPos;
+	const uint16_t* cpBlocks;	// classes by code point (LexTables::cpBlocks / cpPages), or null
+	const uint8_t* cpPages;
 	uint32_t splitPatterns;		// some expression is cut into several patterns entries (same defIndex): their reports are merged
 };
 

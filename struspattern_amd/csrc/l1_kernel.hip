@@ -89,6 +89,24 @@ __device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* do
 	return P.classCtx[ P.byteClass[ doc[ pos]]];
 }
 
+// class by code point of the well-formed multi-byte character that begins at `at` (L1Params::cpBlocks), 0xFF = none:
+// the byte is classed as a byte then
+__device__ __forceinline__ u32 cpClassAt( const L1Params& P, const unsigned char* doc, u32 len, u32 at)
+{
+	const u32 c = doc[ at];
+	const u32 want = (c >= 0xC2u && c <= 0xDFu) ? 2u : (c >= 0xE0u && c <= 0xEFu) ? 3u : (c >= 0xF0u && c <= 0xF4u) ? 4u : 1u;
+	if (want == 1u || at + want > len) return 0xFFu;
+	u32 v = c & (0xFFu >> (want+1u));
+	for (u32 i=1; i<want; ++i)
+	{
+		const u32 x = doc[ at+i];
+		if ((x & 0xC0u) != 0x80u) return 0xFFu;
+		v = (v << 6) | (x & 0x3Fu);
+	}
+	if (want == 2u ? v < 0x80u : want == 3u ? v < 0x800u : (v < 0x10000u || v > 0x10FFFFu)) return 0xFFu;		// overlong / out of range
+	return P.cpPages[ (u32)P.cpBlocks[ v >> 6]*64u + (v & 63u)];
+}
+
 // ---------------------------------------------------------------- stage 2: leftmost start per report
 // lane-parallel: lane i resolves report base+i
 struct LaneReport { u32 to, from, id, levelBind, prefixLen, suffixLen, pi, def, skip; };	// one queued report per lane, pattern attributes attached
@@ -125,6 +143,7 @@ __device__ __forceinline__ void resolveStarts( const u32* queue, const unsigned 
 				Rp |= (R & ed) ? es : 0ull;
 			}
 			u32 cls = P.byteClass[ doc[ j-2]];
+			if (P.cpBlocks && doc[ j-2] >= 0xC2u) { const u32 c = cpClassAt( P, doc, docLen, (u32)(j-2)); if (c != 0xFFu) cls = c; }
 			R = Rp & mask & T.at( (pass*P.nofClasses + cls)*64 + ln);
 			--j;
 		}
@@ -528,6 +547,11 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 			const u32 clsL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)clsReg) >> shm) & 0xFFu;
 			const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> shm) & 0xFFu;
 			ccv = clsL | (ctxL << 8);
+		}
+		if (P.cpBlocks && mine >= 0xC2u && mine <= 0xF4u && tile + LANE < len)
+		{
+			const u32 c = cpClassAt( P, w.doc, len, tile + LANE);		// a large code point set in some expression: class by code point
+			if (c != 0xFFu) ccv = (ccv & ~0xFFu) | c;
 		}
 		// one byte step; the virtual step behind the last byte (matches that end with the document) is a
 		// separate instance so that the hot one carries no end-of-document conditions

@@ -42,7 +42,28 @@ class Tables:
             ln, pc = take(2)
             word = bytes(take(ln))
             self.literals[word] = take(pc)
+        nblk = take(1)[0]
+        self.cpBlocks = take(nblk)
+        npg = take(1)[0]
+        self.cpPages = take(npg)
         assert p == len(d)
+
+    def cls(self, text, pos):
+        """class of the byte at pos: by code point for the lead byte of a well-formed multi-byte character when
+        the tables have classes by code point, else by byte"""
+        b = text[pos]
+        if self.cpBlocks and 0xC2 <= b <= 0xF4:
+            want = 2 if b <= 0xDF else 3 if b <= 0xEF else 4
+            if pos + want <= len(text) and all((text[pos + i] & 0xC0) == 0x80 for i in range(1, want)):
+                v = b & (0xFF >> (want + 1))
+                for i in range(1, want):
+                    v = (v << 6) | (text[pos + i] & 0x3F)
+                ok = v >= 0x80 if want == 2 else v >= 0x800 if want == 3 else 0x10000 <= v <= 0x10FFFF
+                if ok:
+                    c = self.cpPages[self.cpBlocks[v >> 6] * 64 + (v & 63)]
+                    if c != 0xFF:
+                        return c
+        return self.byteClass[b]
 
     def ctx(self, text, pos):
         if pos < 0 or pos >= len(text):
@@ -58,7 +79,7 @@ class Tables:
         prevctx = CTX_EDGE
         for i in range(len(text) + 1):
             ctx = self.ctx(text, i)
-            cls = self.byteClass[text[i]] if i < len(text) else 0
+            cls = self.cls(text, i) if i < len(text) else 0
             new = list(state)
             for w in range(nwords):
                 st = state[w]
@@ -119,7 +140,7 @@ class Tables:
                 at = (p * self.E + e) * 64 + ln
                 if R & self.exDst[at]:
                     Rp |= self.exSrc[at]
-            cls = self.byteClass[text[j - 2]]
+            cls = self.cls(text, j - 2)
             R = Rp & pat["mask"] & self.charMask[(p * self.nofClasses + cls) * 64 + ln]
             j -= 1
         return frm

@@ -80,6 +80,24 @@ def test_options_and_utf8():
         assert _product_reports(pats, t, opts) == _oracle_reports(pats, t, opts), (pats, text, opts)
 
 
+def test_unicode_property_classes():
+    """\\p{..} (general categories from Python's unicodedata, tools/gen_unicode_tables.py): a large code point set is
+    one automaton position entered at the lead byte and classed by the decoded code point; malformed sequences
+    (truncated, overlong, surrogates, stray continuation bytes) fall back to byte classes and match no property."""
+    pats = ["\\b\\p{Lu}\\p{Ll}*\\b", "\\b\\p{Ll}+\\b", "[\\p{Nd}x]+", "\\P{L}+", "[^\\p{L}\\s]", "\\p{Lu}\\p{Ll}+", "\\pL\\p{^L}", "[\u00e4\u00f6]\\p{Greek}?".replace("\\p{Greek}?", "")]
+    texts = ["\u00c4rger \u00fcber \u00d6l und Stra\u00dfe 123x \u0391\u0392\u03b3\u03b4 \u0416\u0443\u043a \u0663\u0664 \u4f60\u597d \U0001d400\U0001d41a!",
+             "abc DEF Ghi", "\u00e9\u00c9x", "", "A", "\u00df"]
+    for t in texts:
+        b = t.encode("utf8")
+        assert _product_reports(pats, b) == _oracle_reports(pats, b), t
+    for b in (b"\xc3", b"A\xc3(b", b"\xe0\x80\x80A\xed\xa0\x80b", b"\x80\xbfAb\xf4\x90\x80\x80", b"\xc3\x84\xc3", b"\xf0\x9d\x90"):
+        assert _product_reports(pats, b) == _oracle_reports(pats, b), b
+    lx = spa.PatternLexerInstance()
+    lx.defineLexem(1, "\\p{Nope}", 0, 1, "content")
+    with pytest.raises(spa.PatternError):
+        lx.compile()
+
+
 def test_wide_alternations_are_cut_into_several_words():
     """An expression of more than 64 byte positions is cut at an alternation into entries of one 64-bit word each
     (same definition index); their reports are merged into one per end offset with the leftmost start."""
@@ -101,7 +119,7 @@ def test_wide_alternations_are_cut_into_several_words():
 
 
 def test_compile_errors_are_reported():
-    for bad in ["(abc", "abc)", "[abc", "a{3,1}", "*a", "\\p{Lu}", "(?=a)b", "a\\"]:
+    for bad in ["(abc", "abc)", "[abc", "a{3,1}", "*a", "\\p{Lx}", "(?=a)b", "a\\"]:
         lx = spa.PatternLexerInstance()
         lx.defineLexem(1, bad, 0, 1, "content")
         with pytest.raises(spa.PatternError):

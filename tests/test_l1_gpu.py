@@ -99,6 +99,30 @@ def test_approximate_table_survives_invalid_utf8():
         assert lx.createContext().match(text).tolist() == o.match(text).tolist(), text
 
 
+def test_unicode_property_classes():
+    """\\p{..}: positions classed by the decoded code point (lead bytes at every offset of the 64-byte tiles, documents
+    of many tiles, malformed sequences); lexems vs the oracle."""
+    def build(x):
+        x.defineLexem(1, "\\b\\p{Lu}\\p{Ll}*\\b", 0, 1, "content")
+        x.defineLexem(2, "\\b\\p{Ll}+\\b", 0, 1, "content")
+        x.defineLexem(3, "\\p{Lu}\\p{Ll}+", 0, 2, "content")
+        x.defineLexem(4, "[\\p{Nd}_]+", 0, 1, "content")
+        x.defineLexem(5, "[^\\p{L}\\p{N}\\s]", 0, 1, "predecessor")
+        x.defineLexem(6, "\\p{Greek}".replace("\\p{Greek}", "[\u03b1-\u03c9]+"), 0, 3, "content")
+        x.compile()
+    lx, o = _both(build)
+    rng = random.Random(11)
+    words = ["\u00c4rger", "\u00fcber", "\u00d6l", "Stra\u00dfe", "\u0391\u03b2\u03b3", "\u0416\u0443\u043a", "\u0663\u0664", "\u4f60\u597d", "\U0001d400\U0001d41a", "Abc", "x9_",
+             "abc", "DEF", "!", "\u20ac", " ", " ", "\n"]
+    docs = ["".join(rng.choice(words) + rng.choice(["", " "]) for _ in range(n)).encode("utf8") for n in (0, 1, 7, 60, 400, 3000)]
+    docs += [b"\xc3", b"A\xc3(b", b"\xe0\x80\x80A\xed\xa0\x80b", b"\x80\xbfAb\xf4\x90\x80\x80", b"x" * 63 + "\u00c4b".encode("utf8"), b"x" * 62 + "\U0001d400b \u4f60".encode("utf8")]
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in docs])
+    got = lx.createContext().matchDocs(b"".join(docs), offs)
+    for di, d in enumerate(docs):
+        assert got.doc(di).tolist() == o.match(d).tolist(), d[:80]
+
+
 def test_wide_alternations_cut_into_several_words():
     """Expressions beyond 64 byte positions (cut at an alternation into several automaton words): several words of
     one expression report at the same end offset with different starts (suffix-related alternatives sit in
