@@ -732,61 +732,65 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 			PROF_ACC( 1, tLit);
 			litEnds &= __ballot( litCount != 0);
 		}
-		// every report that ends inside this tile: end offsets tile .. tile+63 (a full tile) or .. len (the last one)
+		// every report that ends inside this tile: end offsets tile .. tile+63 (a full tile) or .. len (the last one).
+		// Two sorted streams -- the automaton's reports (lanes of lr) and the tile's literals (lanes of lit*, one
+		// pattern after the other where a literal defines several) -- merged by (end offset, pattern index).
 		const u32 lastTo = (tile + 64 > len) ? len : tile + 63u;
+		const u64 NOKEY = ~0ull;
+		u32 kL = 64, pb = 0, pc = 0, lj = 0, lfrom = 0, lid = 0, llb = 0;
+		u64 keyL = NOKEY;
+		auto literalAt = [&]()			// the first literal end of litEnds becomes the current literal
+		{
+			keyL = NOKEY;
+			if (!litEnds) return;
+			kL = (u32)__builtin_ctzll( litEnds);
+			pb = (u32)__builtin_amdgcn_readlane( litBegin, kL); pc = (u32)__builtin_amdgcn_readlane( litCount, kL);
+			lfrom = (u32)__builtin_amdgcn_readlane( litFrom, kL);
+			lid = (u32)__builtin_amdgcn_readlane( litId0, kL); llb = (u32)__builtin_amdgcn_readlane( litLb0, kL);
+			lj = 0;
+			keyL = ((u64)(tile + kL) << 32) | (u32)__builtin_amdgcn_readlane( litPi0, kL);
+		};
+		literalAt();
 		while (!w.err)
 		{
-			u32 toA = 0xFFFFFFFFu;
-			if (qi < nq) toA = (u32)__builtin_amdgcn_readlane( lr.to, qi - qb);
-			const u32 kL = litEnds ? (u32)__builtin_ctzll( litEnds) : 64u;
-			const u32 toL = litEnds ? tile + kL : 0xFFFFFFFFu;
-			const u32 toNext = toA < toL ? toA : toL;
-			if (toNext > lastTo) break;
-			// the literal's patterns (ascending) merged with the automaton's reports of the same end offset (ascending)
-			const u32 pb = toL == toNext ? (u32)__builtin_amdgcn_readlane( litBegin, kL) : 0u;
-			const u32 pc = toL == toNext ? (u32)__builtin_amdgcn_readlane( litCount, kL) : 0u;
-			const u32 lfrom = toL == toNext ? (u32)__builtin_amdgcn_readlane( litFrom, kL) : 0u;
-			u32 lj = 0;
-			u32 lpi = pc ? (u32)__builtin_amdgcn_readlane( litPi0, kL) : 0xFFFFFFFFu;
-			u32 lid = pc ? (u32)__builtin_amdgcn_readlane( litId0, kL) : 0u, llb = pc ? (u32)__builtin_amdgcn_readlane( litLb0, kL) : 0u;
-			while (!w.err)
+			const u32 x = qi - qb;
+			u64 keyA = NOKEY;
+			if (qi < nq) keyA = ((u64)(u32)__builtin_amdgcn_readlane( lr.to, x) << 32) | (u32)__builtin_amdgcn_readlane( lr.pi, x);
+			const bool lit = keyL < keyA;
+			const u64 key = lit ? keyL : keyA;
+			const u32 toNext = (u32)(key >> 32);
+			if (toNext > lastTo) break;		// (also when both streams are at their end)
+			const u32 hid = lit ? lid : (u32)__builtin_amdgcn_readlane( lr.id, x);
+			const u32 hlb = lit ? llb : (u32)__builtin_amdgcn_readlane( lr.levelBind, x);
+			const u32 hpre = lit ? 0u : (u32)__builtin_amdgcn_readlane( lr.prefixLen, x);
+			const u32 hsuf = lit ? 0u : (u32)__builtin_amdgcn_readlane( lr.suffixLen, x);
+			const u32 hfrom = lit ? lfrom : (u32)__builtin_amdgcn_readlane( lr.from, x);
+			const u64 tH = PROF_T();
+			if (lit || !__builtin_amdgcn_readlane( lr.skip, x)) handleReport( w, P, hid, hlb, hpre, hsuf, hfrom, toNext);
+			PROF_ACC( 3, tH);
+			if (lit)
 			{
-				const u32 x = qi - qb;
-				u32 api = 0xFFFFFFFFu;
-				if (qi < nq && (u32)__builtin_amdgcn_readlane( lr.to, x) == toNext) api = (u32)__builtin_amdgcn_readlane( lr.pi, x);
-				if (api == 0xFFFFFFFFu && lj >= pc) break;
-				const bool lit = (lj < pc && lpi < api);
-				const u32 hid = lit ? lid : (u32)__builtin_amdgcn_readlane( lr.id, x);
-				const u32 hlb = lit ? llb : (u32)__builtin_amdgcn_readlane( lr.levelBind, x);
-				const u32 hpre = lit ? 0u : (u32)__builtin_amdgcn_readlane( lr.prefixLen, x);
-				const u32 hsuf = lit ? 0u : (u32)__builtin_amdgcn_readlane( lr.suffixLen, x);
-				const u32 hfrom = lit ? lfrom : (u32)__builtin_amdgcn_readlane( lr.from, x);
-				const u64 tH = PROF_T();
-				if (lit || !__builtin_amdgcn_readlane( lr.skip, x)) handleReport( w, P, hid, hlb, hpre, hsuf, hfrom, toNext);
-				PROF_ACC( 3, tH);
-				if (lit)
+				++lj;
+				if (lj < pc)
 				{
-					++lj;
-					if (lj < pc)
-					{
-						lpi = ldu( &P.litPats[ pb + lj]);
-						const DevLexPattern* pat = &P.patterns[ lpi];
-						lid = ldu( &pat->id); llb = ldu( &pat->levelBind);
-					}
+					const u32 lpi = ldu( &P.litPats[ pb + lj]);
+					const DevLexPattern* pat = &P.patterns[ lpi];
+					lid = ldu( &pat->id); llb = ldu( &pat->levelBind);
+					keyL = ((u64)toNext << 32) | lpi;
 				}
-				else
+				else { litEnds &= litEnds - 1; literalAt(); }
+			}
+			else
+			{
+				++qi;
+				if (qi == qb + qn && qi < nq)
 				{
-					++qi;
-					if (qi == qb + qn && qi < nq)
-					{
-						qb = qi;
-						const u64 tR = PROF_T();
-						nextBatch( w.queue, w.doc, w.docLen, P, T, nq, qb, qn, lr);
-						PROF_ACC( 2, tR);
-					}
+					qb = qi;
+					const u64 tR = PROF_T();
+					nextBatch( w.queue, w.doc, w.docLen, P, T, nq, qb, qn, lr);
+					PROF_ACC( 2, tR);
 				}
 			}
-			if (toL == toNext) litEnds &= litEnds - 1;
 		}
 	}
 	if (!w.err && qi != nq) w.err = L1D_ERR_INTERNAL;
