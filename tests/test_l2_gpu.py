@@ -204,10 +204,12 @@ def _random_tree(rng, nfeat, depth, maxdepth):
     return rg, push
 
 
-@pytest.mark.parametrize("seed,maxdepth,ntrees,n", [(61, 3, 60, 250), (62, 5, 60, 250), (63, 8, 16, 120)])
-def test_random_expression_trees(seed, maxdepth, ntrees, n):
+@pytest.mark.parametrize("seed,maxdepth,ntrees,n,nfeat,ndocs", [
+    (61, 3, 60, 250, 6, 16), (62, 5, 60, 250, 6, 16), (63, 8, 16, 120, 6, 16),
+    (64, 8, 1000, 200, 60, 32),         # BASELINE.json configs[3] shape: depth-8 trees, a thousand of them over a mid-size alphabet
+    (66, 8, 10000, 300, 2000, 16)])     # ... and at its tree count (10 000 trees)
+def test_random_expression_trees(seed, maxdepth, ntrees, n, nfeat, ndocs):
     rng = np.random.default_rng(seed)
-    nfeat = 6
     trees = [_random_tree(rng, nfeat, 0, maxdepth)[1] for _ in range(ntrees)]
 
     def build(m):
@@ -215,7 +217,6 @@ def test_random_expression_trees(seed, maxdepth, ntrees, n):
             push(m)
             m.definePattern("tree_%d" % i, "", True)
         m.compile()
-    ndocs = 16
     lex = np.zeros((ndocs * n, 4), np.uint32)
     offs = np.arange(ndocs + 1, dtype=np.uint64) * n
     for d in range(ndocs):
