@@ -14,7 +14,7 @@
 #include <vector>
 
 namespace spa {
-hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, hipStream_t stream, hipEvent_t betweenKernels);
+hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels);
 }
 using namespace spa;
 
@@ -277,6 +277,7 @@ int sp_lexer_ctx_grow_arena( sp_lexer_ctx_t* c)
 } // extern "C"
 
 namespace {
+enum {SPA_L1_POST_WAVES_PER_EU_DEFAULT=6};
 void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, size_t ndocs, size_t nbytes, hipStream_t stream)
 {
 	HIP_CHECK( hipSetDevice( c->device));
@@ -285,16 +286,21 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	const unsigned wpb = c->blockThreads / 64;
 	unsigned nblocks = (wavesWanted + wpb-1) / wpb;
 	if (nblocks == 0) nblocks = 1;
-	unsigned nwaves = nblocks*wpb;
+	// the post-processing kernel (and the approximate-matching kernel) has its own number of waves: one event array each
+	unsigned postPerCU = 4*SPA_L1_POST_WAVES_PER_EU_DEFAULT;	// (matches the register budget of the kernel, l1_kernel.hip)
+	if (const char* e = getenv( "SPA_L1_POST_WAVES_PER_CU")) { int v = atoi( e); if (v >= 1 && v <= 40) postPerCU = (unsigned)v; }
+	unsigned nwaves = (unsigned)((ndocs < (size_t)c->numCUs*postPerCU) ? ndocs : (size_t)c->numCUs*postPerCU);
+	nwaves = (nwaves + 3u) & ~3u;
+	if (nwaves == 0) nwaves = 4;
 	uint64_t perWaveWords = 4ull*c->eventCap;		// the handler's event array (the report queue is per document: dQueue)
 	{
 		size_t maxWaves = ((size_t)48 << 30) / (perWaveWords*4);
 		if (maxWaves < 4) maxWaves = 4;
-		if (nwaves > maxWaves) { nblocks = (unsigned)(maxWaves/wpb); if (!nblocks) nblocks = 1; nwaves = nblocks*wpb; }
+		if (nwaves > maxWaves) nwaves = (unsigned)(maxWaves & ~(size_t)3);
 	}
 	if (c->arenaWaves < nwaves || c->arenaWords != perWaveWords)
 	{
-		size_t full = (size_t)c->numCUs*20;
+		size_t full = (size_t)c->numCUs*postPerCU;
 		if (full * perWaveWords*4 > ((size_t)48 << 30)) full = ((size_t)48 << 30) / (perWaveWords*4);
 		unsigned alloc = nwaves < full ? (unsigned)full : nwaves;
 		c->arenaWaves = 0;
@@ -344,7 +350,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = c->ldsWords;
 	P.ldsAccept = c->ldsAccept; P.ldsStart = c->ldsStart; P.ldsShift = c->ldsShift; P.ldsSelf = c->ldsSelf;
 	P.ldsExSrc = c->ldsExSrc; P.ldsExDst = c->ldsExDst;
-	HIP_CHECK( launchL1Lex( P, nblocks, c->blockThreads, stream, c->evMid));
+	HIP_CHECK( launchL1Lex( P, nblocks, c->blockThreads, nwaves, stream, c->evMid));
 	HIP_CHECK( hipEventRecord( c->evStop, stream));
 	c->evValid = true; c->lastStream = stream; c->lastNdocs = ndocs;
 }

@@ -1107,7 +1107,7 @@ __device__ void approxDocument( LexWave& w, const L1Params& P, u32* cps, u32* cp
 
 __device__ void approxDocuments( const L1Params& P)
 {
-	const u32 waveSlot = blockIdx.x, nWaveSlots = gridDim.x;		// one wave per workgroup
+	const u32 waveSlot = blockIdx.x;		// one wave per workgroup
 	LexWave w;
 	w.events = (Event*)(P.arenaBase + (u64)waveSlot * P.arenaWords);
 	w.queue = 0; w.nQueue = 0; w.queueCap = 0;
@@ -1116,13 +1116,11 @@ __device__ void approxDocuments( const L1Params& P)
 #endif
 	for (u32 round=0; round<=P.ndocs; ++round)
 	{
-		u32 doc = waveSlot;
-		if (round)
-		{
-			u32 nx = 0;
-			if (LANE == 0) nx = atomicAdd( (u32*)&P.counters[ L1C_CURSOR], 1u);
-			doc = nWaveSlots + uni( nx);
-		}
+		// every document comes from the device-side cursor (a workgroup that only becomes resident when others have
+		// finished finds it exhausted and leaves at once: no document waits for a particular wave)
+		u32 doc = 0;
+		if (LANE == 0) doc = atomicAdd( (u32*)&P.counters[ L1C_CURSOR], 1u);
+		doc = uni( doc);
 		if (doc >= P.ndocs) break;
 		u64 beg, end;
 		docBounds( P, doc, beg, end);
@@ -1162,21 +1160,16 @@ __device__ void scanDocuments( const L1Params& P)
 {
 	LexTab<LDS> T;
 	stageTables( P, T);
-	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
 	LexWave w;
 	w.events = 0; w.nEvents = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
-	// every wave starts with document `waveSlot` and takes its next ones from a device-side cursor;
 	// the loop is bounded so that it ends whatever the cursor holds
 	for (u32 round=0; round<=P.ndocs; ++round)
 	{
-		u32 doc = waveSlot;
-		if (round)
-		{
-			u32 nx = 0;
-			if (LANE == 0) nx = atomicAdd( (u32*)&P.counters[ L1C_CURSOR], 1u);
-			doc = nWaveSlots + uni( nx);
-		}
+		// every document comes from the device-side cursor (a workgroup that only becomes resident when others have
+		// finished finds it exhausted and leaves at once: no document waits for a particular wave)
+		u32 doc = 0;
+		if (LANE == 0) doc = atomicAdd( (u32*)&P.counters[ L1C_CURSOR], 1u);
+		doc = uni( doc);
 		if (doc >= P.ndocs) break;
 		u64 beg, end;
 		docBounds( P, doc, beg, end);
@@ -1208,7 +1201,6 @@ __device__ void postDocuments( const L1Params& P)
 	LexTab<LDS> T;
 	stageTables( P, T);
 	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-	const u32 nWaveSlots = gridDim.x * (blockDim.x >> 6);
 	LexWave w;
 	w.events = (Event*)(P.arenaBase + (u64)waveSlot * P.arenaWords);
 #ifdef SPA_PROF
@@ -1216,13 +1208,11 @@ __device__ void postDocuments( const L1Params& P)
 #endif
 	for (u32 round=0; round<=P.ndocs; ++round)
 	{
-		u32 doc = waveSlot;
-		if (round)
-		{
-			u32 nx = 0;
-			if (LANE == 0) nx = atomicAdd( (u32*)&P.counters[ L1C_CURSOR2], 1u);
-			doc = nWaveSlots + uni( nx);
-		}
+		// every document comes from the device-side cursor (a workgroup that only becomes resident when others have
+		// finished finds it exhausted and leaves at once: no document waits for a particular wave)
+		u32 doc = 0;
+		if (LANE == 0) doc = atomicAdd( (u32*)&P.counters[ L1C_CURSOR2], 1u);
+		doc = uni( doc);
 		if (doc >= P.ndocs) break;
 		if (ldu( (const u32*)&P.docStatus[ doc]) != 0) continue;		// failed in the scan kernel
 		u64 beg, end;
@@ -1270,15 +1260,23 @@ SPA_L1_KERNEL( p32, 32, 256)
 extern "C" __global__ __launch_bounds__(64) void spa_l1_approx_kernel( L1Params P) { approxDocuments( P); }
 // the post-processing kernel reads the automaton's tables from global memory (start of match only)
 enum {POST_WAVES=4};
-extern "C" __global__ __launch_bounds__(64*POST_WAVES) void spa_l1_post_kernel( L1Params P) { postDocuments<false>( P); }
+// The post-processing kernel is bound by the latency of its dependent chains, not by issue slots: it gains from
+// more resident waves as long as the register budget does not spill much.  Measured on 12288 x 64 KiB documents
+// (tests/micro/sweep_l1_post.py): 100 registers / 16 waves per CU 72 ms, 96 / 20: 65 ms, 80 / 24: 59.4 ms,
+// 72 / 28: 58.9 ms, 64 / 32: 100 ms (60 spills).
+#ifndef SPA_L1_POST_WAVES_PER_EU
+#define SPA_L1_POST_WAVES_PER_EU 6
+#endif
+#define SPA_L1_POST_OCC __attribute__((amdgpu_waves_per_eu( SPA_L1_POST_WAVES_PER_EU, SPA_L1_POST_WAVES_PER_EU)))
+extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel( L1Params P) { postDocuments<false>( P); }
 
 namespace spa {
-hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, hipStream_t stream, hipEvent_t betweenKernels)
+hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels)
 {
 	if (P.nofApprox)
 	{
 		// approximate literal table: one kernel, one wave per workgroup
-		hipLaunchKernelGGL( spa_l1_approx_kernel, dim3( nblocks * (nthreads/64)), dim3( 64), 0, stream, P);
+		hipLaunchKernelGGL( spa_l1_approx_kernel, dim3( postWaves), dim3( 64), 0, stream, P);
 		hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
 		return betweenKernels ? hipEventRecord( betweenKernels, stream) : hipSuccess;
@@ -1305,8 +1303,8 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	if (betweenKernels) { e = hipEventRecord( betweenKernels, stream); if (e != hipSuccess) return e; }
-	// the same number of waves (one arena slot each), in workgroups of POST_WAVES
-	hipLaunchKernelGGL( spa_l1_post_kernel, dim3( (nblocks * (nthreads/64) + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
+	// its own number of waves (one event array each), in workgroups of POST_WAVES
+	hipLaunchKernelGGL( spa_l1_post_kernel, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
 	return hipGetLastError();
 }
 }

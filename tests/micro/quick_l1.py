@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo')
 import struspattern_amd as spa
 from struspattern_amd import synth
 vocab = synth.vocabulary(30000, 1)
-for npat, ndocs in ((10000, 4096),):
+for npat, ndocs in ((10000, int(sys.argv[1]) if len(sys.argv) > 1 else 4096),):
     pats = synth.lexer_patterns(npat, vocab, 1)
     t0=time.time(); text, offs = synth.text_documents(ndocs, 65536, vocab, 2); tg=time.time()-t0
     lx = spa.PatternLexerInstance(); t0=time.time(); synth.apply_lexer_patterns(lx, pats); tc=time.time()-t0
