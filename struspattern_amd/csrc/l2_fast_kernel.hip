@@ -1016,21 +1016,27 @@ static __device__ __forceinline__ void runKernel()
 } // anonymous namespace
 
 // ================================================================== kernel instances (LDS capacities: rules, bucket entries)
+#ifdef SPA_L2_FAST_WAVES_PER_EU
+#define SPA_L2_FAST_OCC __attribute__((amdgpu_waves_per_eu( SPA_L2_FAST_WAVES_PER_EU, SPA_L2_FAST_WAVES_PER_EU)))
+#else
+#define SPA_L2_FAST_OCC
+#endif
 #define SPA_FAST_INSTANCE( NAME, RR, TT) \
-	extern "C" __global__ __launch_bounds__(64) void NAME( FastParams kernelArgs) { Engine<RR,TT>::runKernel(); }
+	extern "C" __global__ __launch_bounds__(64) SPA_L2_FAST_OCC void NAME( FastParams kernelArgs) { Engine<RR,TT>::runKernel(); }
 SPA_FAST_INSTANCE( spa_l2_fast_kernel_s, 192, 320)
 SPA_FAST_INSTANCE( spa_l2_fast_kernel_m, 320, 512)
 SPA_FAST_INSTANCE( spa_l2_fast_kernel_l, 512, 1024)
+SPA_FAST_INSTANCE( spa_l2_fast_kernel_n, 256, 480)		// 10 KB of LDS: 16 waves per CU
 SPA_FAST_INSTANCE( spa_l2_fast_kernel_t, 8, 128)		// tests: everything beyond a handful of rules runs through the spill area
 
 namespace spa {
 static const void* fastInstance( unsigned variant)
 {
-	return variant == 0 ? (const void*)spa_l2_fast_kernel_s : variant == 1 ? (const void*)spa_l2_fast_kernel_m : variant == 2 ? (const void*)spa_l2_fast_kernel_l : (const void*)spa_l2_fast_kernel_t;
+	return variant == 0 ? (const void*)spa_l2_fast_kernel_s : variant == 1 ? (const void*)spa_l2_fast_kernel_m : variant == 2 ? (const void*)spa_l2_fast_kernel_l : variant == 4 ? (const void*)spa_l2_fast_kernel_n : (const void*)spa_l2_fast_kernel_t;
 }
 void fastCapacities( unsigned variant, uint32_t& R, uint32_t& T)
 {
-	if (variant == 0) { R = 192; T = 320; } else if (variant == 1) { R = 320; T = 512; } else if (variant == 2) { R = 512; T = 1024; } else { R = 8; T = 128; }
+	if (variant == 0) { R = 192; T = 320; } else if (variant == 1) { R = 320; T = 512; } else if (variant == 2) { R = 512; T = 1024; } else if (variant == 4) { R = 256; T = 480; } else { R = 8; T = 128; }
 }
 // resident single-wave workgroups per CU of a kernel instance (registers and LDS both limit it)
 int fastBlocksPerCU( unsigned variant)
@@ -1045,6 +1051,7 @@ hipError_t launchL2Fast( const FastParams& P, unsigned variant, unsigned nblocks
 	if (variant == 0) hipLaunchKernelGGL( spa_l2_fast_kernel_s, dim3( nblocks), dim3( 64), 0, stream, P);
 	else if (variant == 1) hipLaunchKernelGGL( spa_l2_fast_kernel_m, dim3( nblocks), dim3( 64), 0, stream, P);
 	else if (variant == 2) hipLaunchKernelGGL( spa_l2_fast_kernel_l, dim3( nblocks), dim3( 64), 0, stream, P);
+	else if (variant == 4) hipLaunchKernelGGL( spa_l2_fast_kernel_n, dim3( nblocks), dim3( 64), 0, stream, P);
 	else hipLaunchKernelGGL( spa_l2_fast_kernel_t, dim3( nblocks), dim3( 64), 0, stream, P);
 	return hipGetLastError();
 }
