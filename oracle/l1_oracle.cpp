@@ -165,12 +165,18 @@ private:
 	}
 	Ranges foldCase( const Ranges& in) const
 	{
+		// CASELESS: the other members of every code point's case class (unicode_categories.inc)
 		if (!(m_opt & OptCaseless)) return in;
 		Ranges o = in;
 		for (size_t i=0; i<in.size(); ++i)
 		{
-			for (uint32_t c='a'; c<='z'; ++c) if (c >= in[i].first && c <= in[i].second) addRange( o, c-32, c-32);
-			for (uint32_t c='A'; c<='Z'; ++c) if (c >= in[i].first && c <= in[i].second) addRange( o, c+32, c+32);
+			for (uint32_t k=0; k<UC_CASEPAIR_COUNT; ++k)
+			{
+				const UcCasePair& p = UC_CASEPAIRS[ k];
+				if (p.cp < in[i].first || p.cp > in[i].second) continue;
+				if (p.other > maxCp() || (!m_utf8 && p.cp > 0x7F)) continue;
+				addRange( o, p.other, p.other);
+			}
 		}
 		return o;
 	}

@@ -223,12 +223,22 @@ private:
 	}
 	void fold( CpRanges& r) const
 	{
+		// CASELESS: every code point of the set brings the other members of its case class (Unicode case folding,
+		// csrc/unicode_categories.inc; in UTF-8 mode also beyond ASCII: K k KELVIN SIGN, S s LONG S, ...)
 		if (!m_caseless) return;
 		size_t n = r.size();
 		for (size_t i=0; i<n; ++i)
 		{
-			for (uint32_t c='a'; c<='z'; ++c) if (c >= r[i].first && c <= r[i].second) r.push_back( std::make_pair( c-32, c-32));
-			for (uint32_t c='A'; c<='Z'; ++c) if (c >= r[i].first && c <= r[i].second) r.push_back( std::make_pair( c+32, c+32));
+			const uint32_t lo = r[i].first, hi = r[i].second;
+			size_t a = 0, b = UC_CASEPAIR_COUNT;
+			while (a < b) { size_t mid = (a+b)/2; if (UC_CASEPAIRS[ mid].cp < lo) a = mid+1; else b = mid; }
+			for (; a < UC_CASEPAIR_COUNT && UC_CASEPAIRS[ a].cp <= hi; ++a)
+			{
+				const uint32_t o = UC_CASEPAIRS[ a].other;
+				if (o > topCp()) continue;
+				if (!m_utf8 && UC_CASEPAIRS[ a].cp > 0x7F) continue;
+				r.push_back( std::make_pair( o, o));
+			}
 		}
 	}
 	Tree fromRanges( CpRanges r) const

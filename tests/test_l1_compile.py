@@ -98,6 +98,18 @@ def test_unicode_property_classes():
         lx.compile()
 
 
+def test_caseless_folds_beyond_ascii():
+    """CASELESS in UTF-8 mode uses Unicode case classes (tools/gen_unicode_tables.py): literals, classes, ranges."""
+    pats = ["stra\u00dfe", "[a-z]+k", "\u00c4\u00d6[\u00fc]+", "\u03a3\u03af\u03c3\u03c5\u03c6\u03bf\u03c2", "[\u0430-\u044f]+", "x\u017f"]
+    texts = ["STRASSE Stra\u00dfe STRA\u00dfE stra\u1e9ee", "abc\u212a xyzK", "\u00e4\u00f6\u00dc\u00fc\u00dc \u00c4\u00d6\u00fc", "\u03c3\u03af\u03c3\u03c5\u03c6\u03bf\u03c3 \u03a3\u038a\u03a3\u03a5\u03a6\u039f\u03a3",
+             "\u041f\u0440\u0438\u0432\u0435\u0442 \u043c\u0438\u0440", "XS xs x\u017f Xs"]
+    for t in texts:
+        b = t.encode("utf8")
+        assert _product_reports(pats, b, ("DOTALL", "CASELESS")) == _oracle_reports(pats, b, ("DOTALL", "CASELESS")), t
+    assert len(_product_reports(pats, texts[3].encode("utf8"), ("DOTALL", "CASELESS"))) > 0
+    assert len(_product_reports(pats, texts[4].encode("utf8"), ("DOTALL", "CASELESS"))) > 0
+
+
 def test_wide_alternations_are_cut_into_several_words():
     """An expression of more than 64 byte positions is cut at an alternation into entries of one 64-bit word each
     (same definition index); their reports are merged into one per end offset with the leftmost start."""
