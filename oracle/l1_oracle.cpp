@@ -104,14 +104,27 @@ private:
 	// --- sets: collected as code point ranges, then lowered to bytes
 	typedef std::vector<std::pair<uint32_t,uint32_t> > Ranges;
 	static void addRange( Ranges& r, uint32_t lo, uint32_t hi) { r.push_back( std::make_pair( lo, hi)); }
+	// UCP (PCRE): \\d = Nd, \\w = L | N | _, \\s = Z | \\h | \\v
+	static void addCategory( Ranges& r, const char* name)
+	{
+		for (const UcCategory* c=UC_CATEGORIES; c->name; ++c)
+		{
+			if (std::strcmp( c->name, name)) continue;
+			for (uint32_t i=0; i<c->count; ++i) addRange( r, c->ranges[i].lo, c->ranges[i].hi);
+		}
+	}
 	void addClassEscape( Ranges& r, unsigned char e, bool& negated) const
 	{
 		negated = false;
 		switch (e)
 		{
-			case 'D': negated = true; /*fall*/ case 'd': addRange( r, '0', '9'); break;
-			case 'W': negated = true; /*fall*/ case 'w': addRange( r, '0','9'); addRange( r,'A','Z'); addRange( r,'a','z'); addRange( r,'_','_'); break;
-			case 'S': negated = true; /*fall*/ case 's': addRange( r, 9, 13); addRange( r, ' ', ' '); break;
+			case 'D': negated = true; /*fall*/ case 'd': addRange( r, '0', '9'); if (m_opt & OptUcp) addCategory( r, "Nd"); break;
+			case 'W': negated = true; /*fall*/ case 'w': addRange( r, '0','9'); addRange( r,'A','Z'); addRange( r,'a','z'); addRange( r,'_','_');
+				if (m_opt & OptUcp) { addCategory( r, "L"); addCategory( r, "N"); }
+				break;
+			case 'S': negated = true; /*fall*/ case 's': addRange( r, 9, 13); addRange( r, ' ', ' ');
+				if (m_opt & OptUcp) { addCategory( r, "Z"); addRange( r, 0x85, 0x85); }
+				break;
 		}
 	}
 	// \\p{Name} / \\pL / \\P{..} / \\p{^..}: a Unicode general category (m_pos is behind the 'p' or 'P')
@@ -597,6 +610,7 @@ Regex::Regex( const std::string& expr, unsigned options)
 {
 	RegexParser parser( expr, options);
 	Ast ast = parser.parse();
+	m_ucp = (options & OptUcp) != 0;
 	NfaBuilder b( m_nodes);
 	NfaBuilder::F f = b.build( ast);
 	int acc = b.node( Accept);
@@ -618,7 +632,7 @@ bool Regex::fixedContext( unsigned group, uint32_t& prefixLen, uint32_t& suffixL
 	return true;
 }
 
-static inline bool isWordByte( int c) { return c >= 0 && (isalnum( c) || c == '_'); }
+static inline bool isWordByte( int c) { return c >= 0 && c < 0x80 && (isalnum( c) || c == '_'); }
 
 // Semantics of SURVEY.md App. A.2: every end offset once, leftmost start, no empty matches.
 void Regex::scan( const unsigned char* src, size_t len, std::vector<std::pair<uint32_t,uint32_t> >& out) const
@@ -628,6 +642,33 @@ void Regex::scan( const unsigned char* src, size_t len, std::vector<std::pair<ui
 	std::vector<uint32_t> cur( nn, INF), nxt( nn, INF);
 	std::vector<int> work;
 	bool live = false;
+	// UCP: \\b looks at characters: every byte of a well-formed multi-byte character is "word" iff the character is L | N
+	std::vector<char> wordAt;
+	if (m_ucp)
+	{
+		wordAt.assign( len, 0);
+		for (size_t at=0; at<len;)
+		{
+			unsigned char c = src[ at];
+			unsigned want = (c >= 0xC2 && c <= 0xDF) ? 2 : (c >= 0xE0 && c <= 0xEF) ? 3 : (c >= 0xF0 && c <= 0xF4) ? 4 : 1;
+			bool ok = want > 1 && at + want <= len;
+			uint32_t v = c & (0xFFu >> (want+1));
+			for (unsigned k=1; ok && k<want; ++k) { if ((src[ at+k] & 0xC0) != 0x80) ok = false; else v = (v << 6) | (src[ at+k] & 0x3F); }
+			if (ok) ok = want == 2 ? v >= 0x80 : want == 3 ? v >= 0x800 : (v >= 0x10000 && v <= 0x10FFFF);
+			if (!ok) { wordAt[ at] = (char)(c < 0x80 && isWordByte( c)); ++at; continue; }
+			bool w = false;
+			static const char* cats[2] = {"L", "N"};
+			for (int ci=0; ci<2 && !w; ++ci) for (const UcCategory* uc=UC_CATEGORIES; uc->name && !w; ++uc)
+			{
+				if (std::strcmp( uc->name, cats[ ci])) continue;
+				for (uint32_t k=0; k<uc->count && !w; ++k) w = uc->ranges[k].lo <= v && v <= uc->ranges[k].hi;
+			}
+			for (unsigned k=0; k<want; ++k) wordAt[ at+k] = (char)w;
+			at += want;
+		}
+	}
+	auto isWordPrev = [&]( size_t i) -> bool { return i > 0 && (m_ucp ? wordAt[ i-1] != 0 : isWordByte( src[ i-1])); };
+	auto isWordNext = [&]( size_t i) -> bool { return i < len && (m_ucp ? wordAt[ i] != 0 : isWordByte( src[ i])); };
 	for (size_t i=0; i<=len; ++i)
 	{
 		int prev = i > 0 ? src[ i-1] : -1;
@@ -647,8 +688,8 @@ void Regex::scan( const unsigned char* src, size_t len, std::vector<std::pair<ui
 			{
 				case Char: case Accept: continue;
 				case Eps: case Split: break;
-				case AssertWB: pass = (isWordByte( prev) != isWordByte( next)); break;
-				case AssertNWB: pass = (isWordByte( prev) == isWordByte( next)); break;
+				case AssertWB: pass = (isWordPrev( i) != isWordNext( i)); break;
+				case AssertNWB: pass = (isWordPrev( i) == isWordNext( i)); break;
 				case AssertBOL: pass = (prev == -1 || prev == '\n'); break;
 				case AssertEOL: pass = (next == -1 || next == '\n'); break;
 				case AssertBOD: pass = (prev == -1); break;
@@ -964,7 +1005,7 @@ static bool plainLiteral( const std::string& expr)
 // SURVEY.md 8(f) and are rejected here.
 void LexerInstance::compile()
 {
-	if (m_options & (OptUcp|OptByteChar|OptAllowEmpty)) throw std::runtime_error( "option not supported by this oracle (UCP, BYTECHAR, ALLOWEMPTY)");
+	if (m_options & (OptByteChar|OptAllowEmpty)) throw std::runtime_error( "option not supported by this oracle (BYTECHAR, ALLOWEMPTY)");
 	m_regex.clear(); m_literal.clear(); m_approx = false;
 	for (size_t i=0; i<m_defs.size(); ++i) if (m_defs[i].editdist) m_approx = true;
 	if (m_approx)

@@ -59,6 +59,7 @@ private:
 	friend class RegexParser;
 	std::vector<Node> m_nodes;
 	int m_start;
+	bool m_ucp;
 	std::map<unsigned,std::pair<int,int> > m_groupFixed;	// group -> (prefix len, suffix len) or (-1,-1)
 };
 

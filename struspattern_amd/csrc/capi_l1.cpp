@@ -115,8 +115,8 @@ size_t sp_lexer_dump_tables( const sp_lexer_t* l, uint64_t** out)
 	const LexTables& T = l->compiler.tables();
 	std::vector<uint64_t> b;
 	b.push_back( T.nofPasses); b.push_back( T.nofClasses); b.push_back( T.maxExceptions); b.push_back( T.patterns.size());
-	b.push_back( T.nofPositions); b.push_back( 0); b.push_back( 0); b.push_back( 0);
-	for (size_t i=0; i<256; ++i) b.push_back( T.byteClass.size() == 256 ? T.byteClass[i] : 0);
+	b.push_back( T.nofPositions); b.push_back( 0); b.push_back( 0); b.push_back( T.ucp ? 1 : 0);
+	for (size_t i=0; i<T.byteClass.size(); ++i) b.push_back( T.byteClass[i]);
 	for (size_t i=0; i<T.classCtx.size(); ++i) b.push_back( T.classCtx[i]);
 	b.insert( b.end(), T.charMask.begin(), T.charMask.end());
 	b.insert( b.end(), T.startMask.begin(), T.startMask.end());
@@ -345,6 +345,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.approx = T.approx.empty() ? 0 : (const DevApproxPattern*)c->dApprox.ptr; P.nofApprox = (uint32_t)T.approx.size();
 	P.charCp = (uint32_t*)c->dCharCp.ptr; P.charPos = (uint32_t*)c->dCharPos.ptr;
 	P.cpBlocks = T.cpBlocks.empty() ? 0 : (const uint16_t*)c->dCpBlocks.ptr; P.cpPages = (const uint8_t*)c->dCpPages.ptr;
+	P.ucp = T.ucp ? 1u : 0u;
 	P.splitPatterns = (T.patterns.size() != c->inst->compiler.nofDefinitions()) ? 1u : 0u;
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
 	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = c->ldsWords;

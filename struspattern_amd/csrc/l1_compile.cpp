@@ -39,7 +39,8 @@ struct ByteSet
 };
 
 // assertion kinds, combined as a bit set = conjunction
-enum {A_WB=1, A_NWB=2, A_BOL=4, A_EOL=8, A_BOD=16, A_EOD=32};
+enum {A_WB=1, A_NWB=2, A_BOL=4, A_EOL=8, A_BOD=16, A_EOD=32,
+      A_SAMEWORD=64};	// between the bytes of one multi-byte character (UCP): both sides are of a word character or both are not
 
 enum TreeOp {T_EMPTY, T_SET, T_CAT, T_ALT, T_STAR, T_PLUS, T_OPT, T_ASSERT, T_GROUP};
 struct Tree
@@ -67,14 +68,15 @@ int encodeUtf8( uint32_t cp, unsigned char* b)
 	b[0] = (unsigned char)(0xF0 | (cp >> 18)); b[1] = (unsigned char)(0x80 | ((cp >> 12) & 0x3F));
 	b[2] = (unsigned char)(0x80 | ((cp >> 6) & 0x3F)); b[3] = (unsigned char)(0x80 | (cp & 0x3F)); return 4;
 }
-void splitUtf8( uint32_t lo, uint32_t hi, std::vector<Tree>& alts)
+// `glue`: node put between the bytes of one character (empty tree = none)
+void splitUtf8( uint32_t lo, uint32_t hi, std::vector<Tree>& alts, const Tree& glue)
 {
 	// cut at encoded-length boundaries, then at continuation-byte boundaries until every byte of the
 	// sequence ranges independently
 	static const uint32_t lenMax[3] = {0x7F, 0x7FF, 0xFFFF};
 	for (int i=0; i<3; ++i)
 	{
-		if (lo <= lenMax[i] && hi > lenMax[i]) { splitUtf8( lo, lenMax[i], alts); splitUtf8( lenMax[i]+1, hi, alts); return; }
+		if (lo <= lenMax[i] && hi > lenMax[i]) { splitUtf8( lo, lenMax[i], alts, glue); splitUtf8( lenMax[i]+1, hi, alts, glue); return; }
 	}
 	if (hi >= 0x80)
 	{
@@ -83,15 +85,15 @@ void splitUtf8( uint32_t lo, uint32_t hi, std::vector<Tree>& alts)
 			uint32_t m = (1u << (6*i)) - 1;
 			if ((lo & ~m) != (hi & ~m))
 			{
-				if (lo & m) { splitUtf8( lo, lo|m, alts); splitUtf8( (lo|m)+1, hi, alts); return; }
-				if ((hi & m) != m) { splitUtf8( lo, (hi & ~m)-1, alts); splitUtf8( hi & ~m, hi, alts); return; }
+				if (lo & m) { splitUtf8( lo, lo|m, alts, glue); splitUtf8( (lo|m)+1, hi, alts, glue); return; }
+				if ((hi & m) != m) { splitUtf8( lo, (hi & ~m)-1, alts, glue); splitUtf8( hi & ~m, hi, alts, glue); return; }
 			}
 		}
 	}
 	unsigned char a[4], b[4];
 	int n = encodeUtf8( lo, a); encodeUtf8( hi, b);
 	std::vector<Tree> seq;
-	for (int i=0; i<n; ++i) { ByteSet s; s.addRange( a[i], b[i]); seq.push_back( Tree::leaf( s)); }
+	for (int i=0; i<n; ++i) { ByteSet s; s.addRange( a[i], b[i]); if (i && glue.op != T_EMPTY) seq.push_back( glue); seq.push_back( Tree::leaf( s)); }
 	alts.push_back( Tree::cat( seq));
 }
 
@@ -99,9 +101,10 @@ void splitUtf8( uint32_t lo, uint32_t hi, std::vector<Tree>& alts)
 class Syntax
 {
 public:
-	Syntax( const std::string& text, unsigned options, std::vector<CpRanges>* cpSets)
+	// sameWord: put A_SAMEWORD between the bytes of every multi-byte character (UCP expressions with \\b / \\B)
+	Syntax( const std::string& text, unsigned options, std::vector<CpRanges>* cpSets, bool sameWord)
 		:m_text(text),m_at(0),m_caseless((options & LEX_CASELESS)!=0),m_dotall((options & LEX_DOTALL)!=0)
-		,m_multiline((options & LEX_MULTILINE)!=0),m_utf8(true),m_groups(0),m_cpSets(cpSets){}
+		,m_multiline((options & LEX_MULTILINE)!=0),m_utf8(true),m_ucp((options & LEX_UCP)!=0),m_sameWord(sameWord),m_groups(0),m_cpSets(cpSets){}
 
 	Tree run()
 	{
@@ -114,7 +117,7 @@ public:
 private:
 	const std::string& m_text;
 	size_t m_at;
-	bool m_caseless, m_dotall, m_multiline, m_utf8;
+	bool m_caseless, m_dotall, m_multiline, m_utf8, m_ucp, m_sameWord;
 	unsigned m_groups;
 	std::vector<CpRanges>* m_cpSets;
 
@@ -241,6 +244,13 @@ private:
 			}
 		}
 	}
+	Tree glue() const { return m_sameWord ? assertNode( A_SAMEWORD) : Tree(); }
+	// a then b as bytes of one character
+	Tree inChar( const Tree& a, const Tree& b) const
+	{
+		std::vector<Tree> sq; sq.push_back( a); if (m_sameWord) sq.push_back( assertNode( A_SAMEWORD)); sq.push_back( b);
+		return Tree::cat( sq);
+	}
 	Tree fromRanges( CpRanges r) const
 	{
 		norm( r);
@@ -268,19 +278,16 @@ private:
 				// (6 positions) reports exactly what the 26 positions of the exact range split report
 				ByteSet l2, l3, l4, c;
 				l2.addRange( 0xC2, 0xDF); l3.addRange( 0xE0, 0xEF); l4.addRange( 0xF0, 0xF4); c.addRange( 0x80, 0xBF);
-				std::vector<Tree> s4; s4.push_back( Tree::leaf( l4)); s4.push_back( Tree::leaf( c));
-				std::vector<Tree> a3; a3.push_back( Tree::cat( s4)); a3.push_back( Tree::leaf( l3));
-				std::vector<Tree> s3; s3.push_back( Tree::alt( a3)); s3.push_back( Tree::leaf( c));
-				std::vector<Tree> a2; a2.push_back( Tree::cat( s3)); a2.push_back( Tree::leaf( l2));
-				std::vector<Tree> s2; s2.push_back( Tree::alt( a2)); s2.push_back( Tree::leaf( c));
-				alts.push_back( Tree::cat( s2));
+				std::vector<Tree> a3; a3.push_back( inChar( Tree::leaf( l4), Tree::leaf( c))); a3.push_back( Tree::leaf( l3));
+				std::vector<Tree> a2; a2.push_back( inChar( Tree::alt( a3), Tree::leaf( c))); a2.push_back( Tree::leaf( l2));
+				alts.push_back( inChar( Tree::alt( a2), Tree::leaf( c)));
 				continue;
 			}
 			rest.push_back( std::make_pair( lo, hi));
 		}
 		if (rest.size() <= 4)
 		{
-			for (size_t i=0; i<rest.size(); ++i) splitUtf8( rest[i].first, rest[i].second, alts);
+			for (size_t i=0; i<rest.size(); ++i) splitUtf8( rest[i].first, rest[i].second, alts, glue());
 		}
 		else
 		{
@@ -305,7 +312,7 @@ private:
 					leads.addRange( a[0], b[0]);
 				}
 				std::vector<Tree> branches;
-				if (have) { std::vector<Tree> sq; sq.push_back( level); sq.push_back( Tree::leaf( c)); branches.push_back( Tree::cat( sq)); }
+				if (have) branches.push_back( inChar( level, Tree::leaf( c)));
 				if (!part.empty())
 				{
 					leads.cpRef = (int)m_cpSets->size(); m_cpSets->push_back( part);
@@ -313,7 +320,7 @@ private:
 				}
 				if (!branches.empty()) { level = Tree::alt( branches); have = true; }
 			}
-			if (have) { std::vector<Tree> sq; sq.push_back( level); sq.push_back( Tree::leaf( c)); alts.push_back( Tree::cat( sq)); }
+			if (have) alts.push_back( inChar( level, Tree::leaf( c)));
 		}
 		if (haveAscii) alts.insert( alts.begin(), Tree::leaf( ascii));
 		return Tree::alt( alts);
@@ -341,13 +348,26 @@ private:
 		}
 		error( "unknown unicode property \\p{" + name + "}");
 	}
-	static void shorthand( char e, CpRanges& r)
+	static void category( const char* name, CpRanges& r)
+	{
+		for (const UcCategory* c=UC_CATEGORIES; c->name; ++c)
+		{
+			if (std::strcmp( name, c->name)) continue;
+			for (uint32_t i=0; i<c->count; ++i) r.push_back( std::make_pair( c->ranges[i].lo, c->ranges[i].hi));
+		}
+	}
+	// \\d \\w \\s; with UCP by Unicode properties (PCRE: \\d = Nd, \\w = L | N | _, \\s = Z | \\h | \\v)
+	void shorthand( char e, CpRanges& r) const
 	{
 		switch (e | 32)
 		{
-			case 'd': r.push_back( std::make_pair( '0','9')); break;
-			case 'w': r.push_back( std::make_pair( '0','9')); r.push_back( std::make_pair( 'A','Z')); r.push_back( std::make_pair( 'a','z')); r.push_back( std::make_pair( '_','_')); break;
-			case 's': r.push_back( std::make_pair( 9, 13)); r.push_back( std::make_pair( ' ',' ')); break;
+			case 'd': r.push_back( std::make_pair( '0','9')); if (m_ucp) category( "Nd", r); break;
+			case 'w': r.push_back( std::make_pair( '0','9')); r.push_back( std::make_pair( 'A','Z')); r.push_back( std::make_pair( 'a','z')); r.push_back( std::make_pair( '_','_'));
+				if (m_ucp) { category( "L", r); category( "N", r); }
+				break;
+			case 's': r.push_back( std::make_pair( 9, 13)); r.push_back( std::make_pair( ' ',' '));
+				if (m_ucp) { category( "Z", r); r.push_back( std::make_pair( 0x85u, 0x85u)); }
+				break;
 		}
 	}
 	uint32_t literalChar()
@@ -674,6 +694,7 @@ bool condHolds( unsigned cond, int prev, int next)
 {
 	if ((cond & A_WB) && ctxIsWord( prev) == ctxIsWord( next)) return false;
 	if ((cond & A_NWB) && ctxIsWord( prev) != ctxIsWord( next)) return false;
+	if ((cond & A_SAMEWORD) && ctxIsWord( prev) != ctxIsWord( next)) return false;
 	if ((cond & A_BOL) && !(prev == CTX_EDGE || prev == CTX_NEWLINE)) return false;
 	if ((cond & A_EOL) && !(next == CTX_EDGE || next == CTX_NEWLINE)) return false;
 	if ((cond & A_BOD) && prev != CTX_EDGE) return false;
@@ -685,6 +706,7 @@ bool condHolds( unsigned cond, int prev, int next)
 struct Automaton
 {
 	std::vector<ByteSet> pos;		// byte set per position
+	std::vector<int> ctxDef;		// definite context of the position (it was split by context because it touches an assertion), or -1
 	std::vector<uint64_t> follow;		// follow[i] = successors of position i
 	uint64_t start[ CTX_COUNT];		// positions a match may begin with, by context of the byte before
 	uint64_t accept[ CTX_COUNT];		// positions a match may end with, by context of the byte after
@@ -692,7 +714,7 @@ struct Automaton
 
 struct TooWide {};		// more than 64 byte positions: the caller may cut the expression at an alternation
 
-Automaton makeAutomaton( const Tree& tree, const std::string&)
+Automaton makeAutomaton( const Tree& tree, const std::string&, bool ucp)
 {
 	Glushkov g;
 	Sets root = g.build( tree);
@@ -714,7 +736,13 @@ Automaton makeAutomaton( const Tree& tree, const std::string&)
 			continue;
 		}
 		ByteSet byCtx[3];
-		for (unsigned c=0; c<256; ++c) if (g.positions[ p].has( c)) byCtx[ ctxOfByte( c)].add( c);
+		for (unsigned c=0; c<256; ++c) if (g.positions[ p].has( c))
+		{
+			byCtx[ ctxOfByte( c)].add( c);
+			// UCP: a byte beyond ASCII belongs to a word character or to another one -- which, the position's class says
+			// at run time (classes by code point for lead bytes, twin classes for continuation bytes)
+			if (ucp && c >= 0x80) byCtx[ CTX_WORD].add( c);
+		}
 		for (int k=0; k<3; ++k) if (!byCtx[k].empty())
 		{
 			byCtx[k].cpRef = g.positions[ p].cpRef;
@@ -722,6 +750,7 @@ Automaton makeAutomaton( const Tree& tree, const std::string&)
 		}
 	}
 	if (a.pos.size() > 64) throw TooWide();
+	a.ctxDef = ctxOf;
 	a.follow.assign( a.pos.size(), 0);
 	for (int c=0; c<CTX_COUNT; ++c) { a.start[c] = 0; a.accept[c] = 0; }
 	for (size_t i=0; i<g.edges.size(); ++i)
@@ -775,9 +804,9 @@ Tree* widestAlternation( Tree& t)
 	return best;
 }
 // automata of an expression: one, or several that accept its language between them
-void makeAutomata( const Tree& tree, const std::string& expr, std::vector<Automaton>& out, unsigned depth=0)
+void makeAutomata( const Tree& tree, const std::string& expr, bool ucp, std::vector<Automaton>& out, unsigned depth=0)
 {
-	try { out.push_back( makeAutomaton( tree, expr)); return; }
+	try { out.push_back( makeAutomaton( tree, expr, ucp)); return; }
 	catch (const TooWide&) {}
 	Tree lo = tree, hi = tree;
 	Tree* a = widestAlternation( lo);
@@ -793,9 +822,30 @@ void makeAutomata( const Tree& tree, const std::string& expr, std::vector<Automa
 	if (cut == 0) cut = 1;
 	std::vector<Tree> first( a->kids.begin(), a->kids.begin() + cut), second( a->kids.begin() + cut, a->kids.end());
 	*a = Tree::alt( first); *b = Tree::alt( second);
-	makeAutomata( lo, expr, out, depth+1);
-	makeAutomata( hi, expr, out, depth+1);
+	makeAutomata( lo, expr, ucp, out, depth+1);
+	makeAutomata( hi, expr, ucp, out, depth+1);
 	if (out.size() > 32) throw std::runtime_error( "failed to compile pattern \"" + expr + "\": expression too complex (more than 32 words of 64 byte positions)");
+}
+
+bool hasWordAssertion( const Tree& t)
+{
+	if (t.op == T_ASSERT && (t.assertion & (A_WB|A_NWB))) return true;
+	for (size_t i=0; i<t.kids.size(); ++i) if (hasWordAssertion( t.kids[ i])) return true;
+	return false;
+}
+// UCP: is the code point a word character (\\w = L | N | _)?
+bool ucpWordCp( uint32_t cp)
+{
+	if (cp < 0x80) return isWordChar( cp);
+	static const char* cats[2] = {"L", "N"};
+	for (int ci=0; ci<2; ++ci) for (const UcCategory* c=UC_CATEGORIES; c->name; ++c)
+	{
+		if (std::strcmp( c->name, cats[ ci])) continue;
+		size_t lo = 0, hi = c->count;
+		while (lo < hi) { size_t mid = (lo+hi)/2; if (c->ranges[ mid].hi < cp) lo = mid+1; else hi = mid; }
+		if (lo < c->count && c->ranges[ lo].lo <= cp) return true;
+	}
+	return false;
 }
 
 bool sameNoCase( const std::string& a, const char* b)
@@ -887,7 +937,6 @@ void LexCompiler::defineOption( const std::string& name, double)
 // src/patternLexer.cpp:1068-1118 (+ PatternTable::complete :333-412)
 void LexCompiler::compile()
 {
-	if (m_options & LEX_UCP) throw std::runtime_error( "option UCP is not supported by this lexer");
 	if (m_options & LEX_BYTECHAR) throw std::runtime_error( "option BYTECHAR (one byte character map) is not supported by this lexer yet");
 	if (m_options & LEX_ALLOWEMPTY) throw std::runtime_error( "option ALLOWEMPTY is not supported by this lexer");
 	LexTables& T = m_tables;
@@ -905,6 +954,8 @@ void LexCompiler::compile()
 	}
 
 	// 1. per pattern automata
+	const bool ucp = (m_options & LEX_UCP) != 0;
+	if (ucp && approxTable) throw std::runtime_error( "approximate matching (~N) together with UCP is not supported by this lexer");
 	std::vector<CpRanges> cpSets;			// code point sets of the leaves with ByteSet::cpRef
 	std::vector<Automaton> autos;
 	std::map<std::string,std::vector<uint32_t> > literalWords;
@@ -945,8 +996,16 @@ void LexCompiler::compile()
 			for (int c=0; c<CTX_COUNT; ++c) { autos.back().start[c] = 0; autos.back().accept[c] = 0; }
 			continue;
 		}
-		Syntax syn( d.expression, m_options, &cpSets);
+		const size_t cpSetsBefore = cpSets.size();
+		Syntax syn( d.expression, m_options, &cpSets, false);
 		Tree tree = syn.run();
+		if (ucp && hasWordAssertion( tree))
+		{
+			// \\b / \\B by Unicode word characters: the bytes of one character have to agree on it
+			cpSets.resize( cpSetsBefore);
+			Syntax again( d.expression, m_options, &cpSets, true);
+			tree = again.run();
+		}
 		DevLexPattern dp; std::memset( &dp, 0, sizeof(dp));
 		dp.id = d.id; dp.defIndex = (uint32_t)di;
 		dp.levelBind = (d.level & 0xFF) | ((uint32_t)d.posbind << 8);
@@ -972,7 +1031,7 @@ void LexCompiler::compile()
 			continue;
 		}
 		std::vector<Automaton> parts;
-		makeAutomata( tree, d.expression, parts);
+		makeAutomata( tree, d.expression, ucp, parts);
 		for (size_t k=0; k<parts.size(); ++k) { T.patterns.push_back( dp); autos.push_back( parts[ k]); }
 	}
 	if (T.patterns.size() >= (1u << 24)) throw std::runtime_error( "too many patterns");
@@ -1161,25 +1220,42 @@ void LexCompiler::compile()
 		for (uint32_t k=0; k<(uint32_t)autos[ pi].pos.size(); ++k) T.patOfBit[ (size_t)T.patterns[ pi].word*64 + bitOf[ pi][ k]] = (uint32_t)pi;	// a shared bit never accepts: any owner will do
 	}
 
-	// 3. byte classes: bytes that no position distinguishes (and that share a context) are one class
+	// 3. byte classes: bytes that no position distinguishes (and that share a context) are one class.  With UCP the
+	//    continuation bytes 80..BF exist twice: as bytes of a character that is not a word character (symbols 128..191,
+	//    context OTHER) and of one that is (symbols 256..319, context WORD) -- the kernel knows which from the lead byte.
+	const unsigned nofSymbols = ucp ? 320u : 256u;
+	auto symByte = []( unsigned sym) -> unsigned { return sym < 256 ? sym : 0x80u + (sym - 256u); };
+	auto symCtx = []( unsigned sym) -> int { return sym < 256 ? ctxOfByte( sym) : (int)CTX_WORD; };
+	// does position k of automaton a take the symbol (a byte in a context)?  Positions classed by code point take no byte.
+	auto takesSymbol = [&]( const Automaton& a, size_t k, unsigned sym) -> bool
 	{
-		std::vector<uint64_t> sig( 256, 1469598103934665603ull);
+		const unsigned c = symByte( sym);
+		if (a.pos[ k].cpRef >= 0 || !a.pos[ k].has( c)) return false;
+		return c < 0x80 || a.ctxDef[ k] < 0 || a.ctxDef[ k] == symCtx( sym);
+	};
+	{
+		std::vector<uint64_t> sig( nofSymbols, 1469598103934665603ull);
 		uint32_t gp = 0;
 		for (size_t pi=0; pi<autos.size(); ++pi) for (size_t k=0; k<autos[ pi].pos.size(); ++k, ++gp)
 		{
-			for (unsigned c=0; c<256; ++c) if (autos[ pi].pos[k].has( c)) sig[ c] = (sig[ c] ^ (gp+1)) * 1099511628211ull + 0x9E3779B97F4A7C15ull;
+			for (unsigned c=0; c<nofSymbols; ++c)
+			{
+				// (a position classed by code point still tells its lead bytes apart from the others: harmless refinement)
+				const bool in = autos[ pi].pos[k].cpRef >= 0 ? (c < 256 && autos[ pi].pos[k].has( c)) : takesSymbol( autos[ pi], k, c);
+				if (in) sig[ c] = (sig[ c] ^ (gp+1)) * 1099511628211ull + 0x9E3779B97F4A7C15ull;
+			}
 		}
 		std::map<std::pair<uint64_t,int>,uint32_t> classOf;
-		T.byteClass.assign( 256, 0); T.classCtx.clear();
-		for (unsigned c=0; c<256; ++c)
+		T.byteClass.assign( nofSymbols, 0); T.classCtx.clear();
+		for (unsigned c=0; c<nofSymbols; ++c)
 		{
-			std::pair<uint64_t,int> key( sig[ c], ctxOfByte( c));
+			std::pair<uint64_t,int> key( sig[ c], symCtx( c));
 			std::map<std::pair<uint64_t,int>,uint32_t>::const_iterator it = classOf.find( key);
 			uint32_t cls;
 			if (it == classOf.end())
 			{
 				cls = (uint32_t)classOf.size();
-				if (cls > 255) throw std::runtime_error( "too many distinct byte classes");
+				if (cls > 254) throw std::runtime_error( "too many distinct byte classes");
 				classOf[ key] = cls; T.classCtx.push_back( (uint8_t)key.second);
 			}
 			else cls = it->second;
@@ -1194,7 +1270,8 @@ void LexCompiler::compile()
 	const uint32_t nofByteClasses = T.nofClasses;
 	std::vector<uint32_t> repCpOfClass;		// class id - nofByteClasses -> a code point of the class
 	T.cpBlocks.clear(); T.cpPages.clear();
-	if (!cpSets.empty())
+	T.ucp = ucp;
+	if (!cpSets.empty() || ucp)
 	{
 		std::vector<uint32_t> cut;
 		for (uint32_t cp=0x80; cp<0x800; cp+=64) cut.push_back( cp);			// one lead byte each
@@ -1202,6 +1279,16 @@ void LexCompiler::compile()
 		for (uint32_t cp=0x10000; cp<0x110000; cp=(cp+0x40000) & ~0x3FFFFu) cut.push_back( cp);
 		cut.push_back( 0x110000);
 		for (size_t i=0; i<cpSets.size(); ++i) for (size_t k=0; k<cpSets[ i].size(); ++k) { cut.push_back( cpSets[ i][ k].first); cut.push_back( cpSets[ i][ k].second+1); }
+		if (ucp)
+		{
+			// the context of a character beyond ASCII: word character or not
+			static const char* cats[2] = {"L", "N"};
+			for (int ci=0; ci<2; ++ci) for (const UcCategory* c=UC_CATEGORIES; c->name; ++c)
+			{
+				if (std::strcmp( c->name, cats[ ci])) continue;
+				for (uint32_t i=0; i<c->count; ++i) { cut.push_back( c->ranges[ i].lo); cut.push_back( c->ranges[ i].hi+1); }
+			}
+		}
 		std::sort( cut.begin(), cut.end()); cut.erase( std::unique( cut.begin(), cut.end()), cut.end());
 		auto inSet = [&]( int ref, uint32_t cp) -> bool
 		{
@@ -1217,12 +1304,14 @@ void LexCompiler::compile()
 			const uint32_t cp = cut[ ai];
 			if (cp < 0x80 || cp >= 0x110000) continue;
 			unsigned char enc[4]; encodeUtf8( cp, enc);
-			uint64_t sig = 1469598103934665603ull;
+			const int cpCtx = (ucp && ucpWordCp( cp)) ? (int)CTX_WORD : (int)CTX_OTHER;
+			uint64_t sig = 1469598103934665603ull ^ (uint64_t)cpCtx;
 			uint32_t gp = 0;
 			for (size_t pi=0; pi<autos.size(); ++pi) for (size_t k=0; k<autos[ pi].pos.size(); ++k, ++gp)
 			{
 				const ByteSet& b = autos[ pi].pos[ k];
-				if (b.cpRef >= 0 ? inSet( b.cpRef, cp) : b.has( enc[0])) sig = (sig ^ (gp+1)) * 1099511628211ull + 0x9E3779B97F4A7C15ull;
+				const bool in = (b.cpRef >= 0 ? inSet( b.cpRef, cp) : b.has( enc[0])) && (autos[ pi].ctxDef[ k] < 0 || autos[ pi].ctxDef[ k] == cpCtx);
+				if (in) sig = (sig ^ (gp+1)) * 1099511628211ull + 0x9E3779B97F4A7C15ull;
 			}
 			std::map<uint64_t,uint32_t>::const_iterator it = classOfSig.find( sig);
 			uint32_t cls;
@@ -1230,7 +1319,7 @@ void LexCompiler::compile()
 			{
 				cls = T.nofClasses++;
 				if (cls > 254) throw std::runtime_error( "too many distinct character classes");
-				classOfSig[ sig] = cls; T.classCtx.push_back( (uint8_t)CTX_OTHER); repCpOfClass.push_back( cp);
+				classOfSig[ sig] = cls; T.classCtx.push_back( (uint8_t)cpCtx); repCpOfClass.push_back( cp);
 			}
 			else cls = it->second;
 			for (uint32_t c=cp; c<cut[ ai+1]; ++c) flat[ c] = (uint8_t)cls;
@@ -1260,8 +1349,8 @@ void LexCompiler::compile()
 	T.selfLoop.assign( (size_t)T.nofPasses * 64, 0);
 	std::vector<std::map<uint64_t,uint64_t> > exBySrc( totalWords);	// src bit -> dst set (edges that are neither self loop nor shift)
 	std::vector<std::map<uint64_t,uint64_t> > exOfWord( totalWords);	// dst set -> src set
-	std::vector<unsigned char> repOfClass( T.nofClasses, 0);
-	for (unsigned c=256; c-->0;) repOfClass[ T.byteClass[ c]] = (unsigned char)c;	// (byte classes; the classes by code point come behind them)
+	std::vector<unsigned> repOfClass( T.nofClasses, 0);
+	for (unsigned c=nofSymbols; c-->0;) repOfClass[ T.byteClass[ c]] = c;	// (byte classes by a symbol of theirs; the classes by code point come behind them)
 	for (size_t pi=0; pi<autos.size(); ++pi)
 	{
 		const Automaton& a = autos[ pi];
@@ -1281,7 +1370,7 @@ void LexCompiler::compile()
 			for (uint32_t cls=0; cls<T.nofClasses; ++cls)
 			{
 				bool member;
-				if (cls < nofByteClasses) member = a.pos[k].cpRef < 0 && a.pos[k].has( repOfClass[ cls]);
+				if (cls < nofByteClasses) member = takesSymbol( a, k, repOfClass[ cls]);
 				else
 				{
 					const uint32_t cp = repCpOfClass[ cls - nofByteClasses];
@@ -1292,6 +1381,7 @@ void LexCompiler::compile()
 						for (size_t q=0; q<r.size() && !member; ++q) member = r[ q].first <= cp && cp <= r[ q].second;
 					}
 					else { unsigned char enc[4]; encodeUtf8( cp, enc); member = a.pos[k].has( enc[0]); }
+					if (member && a.ctxDef[ k] >= 0 && a.ctxDef[ k] != (int)T.classCtx[ cls]) member = false;
 				}
 				if (member) T.charMask[ ((size_t)pass*T.nofClasses + cls)*64 + lane] |= 1ull << bit[ k];
 			}
@@ -1391,7 +1481,7 @@ void LexCompiler::compile()
 }
 
 // ---------------------------------------------------------------- compiled tables as a blob
-static const char L1_MAGIC[ 9] = "SPAL1v05";
+static const char L1_MAGIC[ 9] = "SPAL1v06";
 
 void LexCompiler::save( std::vector<uint8_t>& out) const
 {
@@ -1399,7 +1489,7 @@ void LexCompiler::save( std::vector<uint8_t>& out) const
 	BlobWriter w( L1_MAGIC);
 	const LexTables& T = m_tables;
 	w.u32( m_options);
-	w.u32( T.nofPasses); w.u32( T.nofClasses); w.u32( T.maxExceptions); w.u32( T.nofLiterals); w.u32( T.nofPositions); w.u32( T.reportsOrdered ? 1u : 0u);
+	w.u32( T.nofPasses); w.u32( T.nofClasses); w.u32( T.maxExceptions); w.u32( T.nofLiterals); w.u32( T.nofPositions); w.u32( T.reportsOrdered ? 1u : 0u); w.u32( T.ucp ? 1u : 0u);
 	w.vec( T.byteClass); w.vec( T.classCtx); w.vec( T.cpBlocks); w.vec( T.cpPages); w.vec( T.charMask); w.vec( T.startMask); w.vec( T.acceptMask); w.vec( T.shiftDst); w.vec( T.selfLoop);
 	w.vec( T.exCount); w.vec( T.exSrc); w.vec( T.exDst); w.vec( T.wordPatBegin); w.vec( T.wordPats); w.vec( T.patOfBit);
 	w.vec( T.patterns); w.vec( T.symbols); w.vec( T.symbolText); w.vec( T.literals); w.vec( T.literalText); w.vec( T.litPats); w.vec( T.approx);
@@ -1425,12 +1515,12 @@ void LexCompiler::load( const void* blob, size_t size)
 	BlobReader r( blob, size, L1_MAGIC);
 	LexTables T;
 	m_options = r.u32();
-	T.nofPasses = r.u32(); T.nofClasses = r.u32(); T.maxExceptions = r.u32(); T.nofLiterals = r.u32(); T.nofPositions = r.u32(); T.reportsOrdered = r.u32() != 0;
+	T.nofPasses = r.u32(); T.nofClasses = r.u32(); T.maxExceptions = r.u32(); T.nofLiterals = r.u32(); T.nofPositions = r.u32(); T.reportsOrdered = r.u32() != 0; T.ucp = r.u32() != 0;
 	r.vec( T.byteClass); r.vec( T.classCtx); r.vec( T.cpBlocks); r.vec( T.cpPages); r.vec( T.charMask); r.vec( T.startMask); r.vec( T.acceptMask); r.vec( T.shiftDst); r.vec( T.selfLoop);
 	r.vec( T.exCount); r.vec( T.exSrc); r.vec( T.exDst); r.vec( T.wordPatBegin); r.vec( T.wordPats); r.vec( T.patOfBit);
 	r.vec( T.patterns); r.vec( T.symbols); r.vec( T.symbolText); r.vec( T.literals); r.vec( T.literalText); r.vec( T.litPats); r.vec( T.approx);
 	// the shapes the kernel indexes by must fit together (a blob of another build would fault on the device)
-	if (T.byteClass.size() != 256 || T.classCtx.size() != T.nofClasses
+	if (T.byteClass.size() != (T.ucp ? 320u : 256u) || (T.ucp && T.cpBlocks.empty()) || T.classCtx.size() != T.nofClasses
 	||  T.charMask.size() != (size_t)T.nofPasses*T.nofClasses*64 || T.startMask.size() != (size_t)T.nofPasses*CTX_COUNT*64 || T.acceptMask.size() != T.startMask.size()
 	||  T.shiftDst.size() != (size_t)T.nofPasses*64 || T.selfLoop.size() != T.shiftDst.size() || T.exCount.size() != T.nofPasses
 	||  T.exSrc.size() != (size_t)T.nofPasses*(T.maxExceptions ? T.maxExceptions : 1)*64 || T.exDst.size() != T.exSrc.size()

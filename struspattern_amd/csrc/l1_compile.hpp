@@ -19,7 +19,8 @@ struct LexTables
 	uint32_t nofPasses;
 	uint32_t nofClasses;
 	uint32_t maxExceptions;			// per word, over all passes
-	std::vector<uint8_t> byteClass;		// 256 -> class id
+	bool ucp;				// option UCP: contexts (word / not) and \w \d \s by Unicode properties
+	std::vector<uint8_t> byteClass;		// 256 -> class id; with UCP 320: [256..319] = continuation bytes 80..BF of a word character
 	std::vector<uint8_t> classCtx;		// class id -> CTX_*
 	// classes by code point for the lead byte of a well-formed multi-byte character (only when some expression holds
 	// a large code point set, e.g. \p{Lu}): class = cpPages[ cpBlocks[ cp>>6]*64 + (cp&63)], 0xFF = none (use the byte's class)

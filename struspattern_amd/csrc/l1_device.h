@@ -68,6 +68,7 @@ struct L1Params
 	uint32_t* charPos;
 	const uint16_t* cpBlocks;	// classes by code point (LexTables::cpBlocks / cpPages), or null
 	const uint8_t* cpPages;
+	uint32_t ucp;			// option UCP: contexts by Unicode word characters, byteClass has the 64 twin entries [256..319]
 	uint32_t splitPatterns;		// some expression is cut into several patterns entries (same defIndex): their reports are merged
 };
 

@@ -83,12 +83,6 @@ struct LexWave
 #endif
 };
 
-__device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* doc, u32 len, long pos)
-{
-	if (pos < 0 || pos >= (long)len) return CTX_EDGE;
-	return P.classCtx[ P.byteClass[ doc[ pos]]];
-}
-
 // class by code point of the well-formed multi-byte character that begins at `at` (L1Params::cpBlocks), 0xFF = none:
 // the byte is classed as a byte then
 __device__ __forceinline__ u32 cpClassAt( const L1Params& P, const unsigned char* doc, u32 len, u32 at)
@@ -107,11 +101,85 @@ __device__ __forceinline__ u32 cpClassAt( const L1Params& P, const unsigned char
 	return P.cpPages[ (u32)P.cpBlocks[ v >> 6]*64u + (v & 63u)];
 }
 
+// class and context of the byte at `pos`: the lead byte of a well-formed character by its code point when the tables
+// have such classes; with UCP a continuation byte by whether its character is a word character (twin classes 256..319)
+__device__ __forceinline__ void classCtxAt( const L1Params& P, const unsigned char* doc, u32 len, long pos, u32& cls, int& ctx)
+{
+	if (pos < 0 || pos >= (long)len) { cls = 0; ctx = CTX_EDGE; return; }
+	const u32 b = doc[ pos];
+	cls = P.byteClass[ b]; ctx = P.classCtx[ cls];
+	if (!P.cpBlocks || b < 0x80u) return;
+	if (b >= 0xC2u)
+	{
+		const u32 c = cpClassAt( P, doc, len, (u32)pos);
+		if (c != 0xFFu) { cls = c; ctx = P.classCtx[ c]; }
+		return;
+	}
+	if (!P.ucp || b > 0xBFu) return;
+	for (long d=1; d<=3 && pos-d >= 0; ++d)
+	{
+		const u32 l = doc[ pos-d];
+		if (l >= 0xC2u && l <= 0xF4u)
+		{
+			const u32 want = l <= 0xDFu ? 2u : l <= 0xEFu ? 3u : 4u;
+			if (want > (u32)d)
+			{
+				const u32 c = cpClassAt( P, doc, len, (u32)(pos-d));
+				if (c != 0xFFu && P.classCtx[ c] == (u32)CTX_WORD) { cls = P.byteClass[ 256u + (b - 0x80u)]; ctx = CTX_WORD; }
+			}
+			return;
+		}
+		if ((l & 0xC0u) != 0x80u) return;
+	}
+}
+template <bool CP>
+__device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* doc, u32 len, long pos)
+{
+	if (pos < 0 || pos >= (long)len) return CTX_EDGE;
+	if (CP && P.ucp) { u32 cls; int ctx; classCtxAt( P, doc, len, pos, cls, ctx); return ctx; }
+	return P.classCtx[ P.byteClass[ doc[ pos]]];
+}
+// class | context << 8 of the byte of my lane in the 64-byte tile at `tile` (`mine`), from the in-register byte tables and
+// -- in the kernel instances for tables with classes by code point (CP) -- from the decoded character; wcarry: continuation
+// bytes at the start of the next tile that belong to a word character of this one (UCP)
+template <bool CP>
+__device__ __forceinline__ u32 tileClassCtx( const L1Params& P, const unsigned char* doc, u32 len, u32 tile, u32 mine, u32 clsReg, u32 ctxReg, u64& wcarry)
+{
+	const u32 shm = (mine & 3u)*8;
+	const u32 clsL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)clsReg) >> shm) & 0xFFu;
+	const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> shm) & 0xFFu;
+	u32 ccv = clsL | (ctxL << 8);
+	if (CP)
+	{
+		u32 n = 0; bool word = false;
+		if (mine >= 0xC2u && mine <= 0xF4u && tile + LANE < len)
+		{
+			const u32 c = cpClassAt( P, doc, len, tile + LANE);
+			if (c != 0xFFu)
+			{
+				u32 ctx = ctxL;
+				if (P.ucp) { ctx = P.classCtx[ c]; word = ctx == (u32)CTX_WORD; n = mine <= 0xDFu ? 2u : mine <= 0xEFu ? 3u : 4u; }
+				ccv = c | (ctx << 8);
+			}
+		}
+		if (P.ucp)
+		{
+			const u64 m2 = __ballot( word && n >= 2u), m3 = __ballot( word && n >= 3u), m4 = __ballot( word && n >= 4u);
+			const u64 covered = (m2 << 1) | (m3 << 2) | (m4 << 3) | wcarry;
+			wcarry = (m2 >> 63) | (m3 >> 62) | (m4 >> 61);
+			if (((covered >> LANE) & 1ull) && mine >= 0x80u && mine <= 0xBFu && tile + LANE < len)
+			{
+				ccv = (u32)P.byteClass[ 256u + (mine - 0x80u)] | ((u32)CTX_WORD << 8);
+			}
+		}
+	}
+	return ccv;
+}
 // ---------------------------------------------------------------- stage 2: leftmost start per report
 // lane-parallel: lane i resolves report base+i
 struct LaneReport { u32 to, from, id, levelBind, prefixLen, suffixLen, pi, def, skip; };	// one queued report per lane, pattern attributes attached
 
-template <bool LDS>
+template <bool LDS, bool CP>
 __device__ __forceinline__ void resolveStarts( const u32* queue, const unsigned char* doc, u32 docLen, const L1Params& P, const LexTab<LDS>& T, u32 base, u32 count, LaneReport& out)
 {
 	u32 i = base + LANE;
@@ -132,7 +200,7 @@ __device__ __forceinline__ void resolveStarts( const u32* queue, const unsigned 
 		long j = (long)to;			// R = positions that consumed byte j-1
 		while (R && j > 0)
 		{
-			int prevctx = ctxAt( P, doc, docLen, j-2);
+			int prevctx = ctxAt<CP>( P, doc, docLen, j-2);
 			if (R & T.at( T.oStart + (pass*CTX_COUNT + prevctx)*64 + ln)) from = (u32)(j-1);
 			if (j-1 == 0) break;
 			u64 Rp = ((R & shiftDst) >> 1) | (R & selfLoop);
@@ -143,7 +211,7 @@ __device__ __forceinline__ void resolveStarts( const u32* queue, const unsigned 
 				Rp |= (R & ed) ? es : 0ull;
 			}
 			u32 cls = P.byteClass[ doc[ j-2]];
-			if (P.cpBlocks && doc[ j-2] >= 0xC2u) { const u32 c = cpClassAt( P, doc, docLen, (u32)(j-2)); if (c != 0xFFu) cls = c; }
+			if (CP && doc[ j-2] >= 0x80u) { int cx; classCtxAt( P, doc, docLen, j-2, cls, cx); }
 			R = Rp & mask & T.at( (pass*P.nofClasses + cls)*64 + ln);
 			--j;
 		}
@@ -154,11 +222,11 @@ __device__ __forceinline__ void resolveStarts( const u32* queue, const unsigned 
 // The next batch of up to 64 reports with their starts.  An expression cut into several patterns entries reports
 // once per entry: the reports of one expression and one end offset are adjacent; the last of them takes the
 // leftmost start of the group, the others are marked to be skipped, and a group is never cut by a batch boundary.
-template <bool LDS>
+template <bool LDS, bool CP>
 __device__ __forceinline__ void nextBatch( const u32* queue, const unsigned char* doc, u32 docLen, const L1Params& P, const LexTab<LDS>& T, u32 nq, u32 qb, u32& qn, LaneReport& lr)
 {
 	qn = (nq - qb) < 64u ? (nq - qb) : 64u;
-	resolveStarts( queue, doc, docLen, P, T, qb, qn, lr);
+	resolveStarts<LDS,CP>( queue, doc, docLen, P, T, qb, qn, lr);
 	if (!P.splitPatterns) return;
 	if (qb + qn < nq)
 	{
@@ -507,7 +575,7 @@ __device__ __forceinline__ void tileLiterals(  const LexWave& w, const L1Params&
 }
 
 // ---------------------------------------------------------------- stage 1: forward scan
-template <int PASSES, bool LDS>
+template <int PASSES, bool LDS, bool CP>
 __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& T)
 {
 	u64 state[ PASSES];
@@ -535,24 +603,14 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 		shiftDst[ p] = on ? T.at( T.oShift + p*64 + LANE) : 0; selfLoop[ p] = on ? T.at( T.oSelf + p*64 + LANE) : 0;
 		nExOf[ p] = on ? uni( P.exCount[ p]) : 0;
 	}
+	u64 wcarry = 0;
 	for (u32 tile=0; tile<=len && !w.err; tile+=64)
 	{
 		// 64 document bytes per load, one per lane; replayed byte by byte through a scalar register
 		u32 mine = (tile + LANE < len) ? w.doc[ tile + LANE] : 0u;
 		u32 inTile = (len - tile) < 64 ? (len - tile) : 64;	// document bytes in this tile
 		// class and context of my byte (lane-parallel lookup in the register tables), replayed per byte with one readlane
-		u32 ccv;
-		{
-			const u32 shm = (mine & 3u)*8;
-			const u32 clsL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)clsReg) >> shm) & 0xFFu;
-			const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> shm) & 0xFFu;
-			ccv = clsL | (ctxL << 8);
-		}
-		if (P.cpBlocks && mine >= 0xC2u && mine <= 0xF4u && tile + LANE < len)
-		{
-			const u32 c = cpClassAt( P, w.doc, len, tile + LANE);		// a large code point set in some expression: class by code point
-			if (c != 0xFFu) ccv = (ccv & ~0xFFu) | c;
-		}
+		const u32 ccv = tileClassCtx<CP>( P, w.doc, len, tile, mine, clsReg, ctxReg, wcarry);
 		// one byte step; the virtual step behind the last byte (matches that end with the document) is a
 		// separate instance so that the hot one carries no end-of-document conditions
 		auto step = [&]( auto atEndTag, const u32 k)
@@ -704,18 +762,19 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 // The document's raw reports (scan kernel) and its literal reports (found here, tile by tile) go through the
 // reference's handler in the order the reference's callback sees them: ascending end offset, ascending pattern
 // index inside one end offset.
-template <bool LDS>
+template <bool LDS, bool CP>
 __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& T)
 {
 	const u32 len = w.docLen;
-	u32 ctxReg = 0;			// byte -> context: lane l keeps the entries of bytes 4l..4l+3
-	for (u32 k=0; k<4; ++k) ctxReg |= (u32)P.classCtx[ P.byteClass[ 4*LANE + k]] << (8*k);
+	u32 ctxReg = 0, clsReg = 0;		// byte -> context, class: lane l keeps the entries of bytes 4l..4l+3
+	for (u32 k=0; k<4; ++k) { const u32 c = P.byteClass[ 4*LANE + k]; clsReg |= c << (8*k); ctxReg |= (u32)P.classCtx[ c] << (8*k); }
+	u64 wcarry = 0;
 	LitCarry carry; carry.in = false; carry.hash = 0; carry.len = 0; carry.start = 0;
 	const u32 nq = w.nQueue;
 	u32 qi = 0, qb = 0, qn = 0;		// next report; the batch [qb, qb+qn) is resolved in lr
 	LaneReport lr;
 	lr.to = 0; lr.from = 0; lr.id = 0; lr.levelBind = 0; lr.prefixLen = 0; lr.suffixLen = 0; lr.pi = 0; lr.def = 0; lr.skip = 0;
-	if (nq) nextBatch( w.queue, w.doc, w.docLen, P, T, nq, 0, qn, lr);
+	if (nq) nextBatch<LDS,CP>( w.queue, w.doc, w.docLen, P, T, nq, 0, qn, lr);
 	u32 ahead = (LANE < len) ? w.doc[ LANE] : 0u;		// the next tile's bytes are loaded one tile ahead
 	for (u32 tile=0; tile<=len && !w.err; tile+=64)
 	{
@@ -725,8 +784,9 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 		u64 litEnds = 0; u32 litFrom = 0, litBegin = 0, litCount = 0, litPi0 = 0, litId0 = 0, litLb0 = 0;
 		if (P.nofLiterals)
 		{
-			const u32 shm = (mine & 3u)*8;
-			const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> shm) & 0xFFu;
+			u32 ctxL;
+			if (CP && P.ucp) ctxL = tileClassCtx<true>( P, w.doc, len, tile, mine, clsReg, ctxReg, wcarry) >> 8;
+			else { const u32 shm = (mine & 3u)*8; ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> shm) & 0xFFu; }
 			const u64 tLit = PROF_T();
 			tileLiterals( w, P, tile, mine, LANE < inTile && ctxL == (u32)CTX_WORD, carry, litEnds, litFrom, litBegin, litCount, litPi0, litId0, litLb0);
 			PROF_ACC( 1, tLit);
@@ -787,7 +847,7 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 				{
 					qb = qi;
 					const u64 tR = PROF_T();
-					nextBatch( w.queue, w.doc, w.docLen, P, T, nq, qb, qn, lr);
+					nextBatch<LDS,CP>( w.queue, w.doc, w.docLen, P, T, nq, qb, qn, lr);
 					PROF_ACC( 2, tR);
 				}
 			}
@@ -1155,7 +1215,7 @@ __device__ __forceinline__ void stageTables( const L1Params& P, LexTab<LDS>& T)
 }
 
 // SCAN: automaton over the document's bytes, raw reports into the document's slice of the report queue
-template <int PASSES, bool LDS>
+template <int PASSES, bool LDS, bool CP>
 __device__ void scanDocuments( const L1Params& P)
 {
 	LexTab<LDS> T;
@@ -1178,7 +1238,7 @@ __device__ void scanDocuments( const L1Params& P)
 		w.queue = P.reportQueue + 4*qb;
 		w.queueCap = (u32)(queueBase( P, end, doc+1) - qb);
 		w.nQueue = 0; w.err = 0;
-		scanDocument<PASSES,LDS>( w, P, T);
+		scanDocument<PASSES,LDS,CP>( w, P, T);
 		if (LANE == 0)
 		{
 			P.reportCount[ doc] = w.err ? 0u : w.nQueue;
@@ -1195,7 +1255,7 @@ __device__ void scanDocuments( const L1Params& P)
 }
 
 // POST: literals, start of match, handler, ordinal positions, lexems
-template <bool LDS>
+template <bool LDS, bool CP>
 __device__ void postDocuments( const L1Params& P)
 {
 	LexTab<LDS> T;
@@ -1223,7 +1283,7 @@ __device__ void postDocuments( const L1Params& P)
 		w.queueCap = w.nQueue; w.nEvents = 0; w.err = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
 		w.e.id = 0; w.e.pos = 0; w.e.size = 0; w.e.lb = 0;
 		const u64 tDoc = PROF_T();
-		postDocument<LDS>( w, P, T);
+		postDocument<LDS,CP>( w, P, T);
 		spillLanes( w, 0);
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		if (!w.err) emitLexems( w, P, doc);
@@ -1245,8 +1305,10 @@ __device__ void postDocuments( const L1Params& P)
 
 // One scan instance per pass count (the per-pass rows of a byte step live in registers, so the count is a
 // template parameter).
+// (a second set, _cp, for tables with classes by code point: \\p{..} sets, UCP -- the plain set pays nothing for them)
 #define SPA_L1_KERNEL( NAME, N, T) \
-extern "C" __global__ __launch_bounds__(T) void spa_l1_scan_kernel_##NAME( L1Params P) { if (P.ldsWords) scanDocuments<N,true>( P); else scanDocuments<N,false>( P); }
+extern "C" __global__ __launch_bounds__(T) void spa_l1_scan_kernel_##NAME( L1Params P) { if (P.ldsWords) scanDocuments<N,true,false>( P); else scanDocuments<N,false,false>( P); } \
+extern "C" __global__ __launch_bounds__(T) void spa_l1_scan_kernel_##NAME##_cp( L1Params P) { if (P.ldsWords) scanDocuments<N,true,true>( P); else scanDocuments<N,false,true>( P); }
 SPA_L1_KERNEL( p1, 1, 1024)
 SPA_L1_KERNEL( p2, 2, 1024)
 SPA_L1_KERNEL( p3, 3, 1024)
@@ -1268,7 +1330,8 @@ enum {POST_WAVES=4};
 #define SPA_L1_POST_WAVES_PER_EU 6
 #endif
 #define SPA_L1_POST_OCC __attribute__((amdgpu_waves_per_eu( SPA_L1_POST_WAVES_PER_EU, SPA_L1_POST_WAVES_PER_EU)))
-extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel( L1Params P) { postDocuments<false>( P); }
+extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel( L1Params P) { postDocuments<false,false>( P); }
+extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel_cp( L1Params P) { postDocuments<false,true>( P); }
 
 namespace spa {
 hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels)
@@ -1283,8 +1346,13 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 	}
 	const size_t lds = (size_t)P.ldsWords * 8;
 #define SPA_L1_LAUNCH( N) do { \
-	if (lds > 65536) { hipError_t e = hipFuncSetAttribute( (const void*)spa_l1_scan_kernel_##N, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
-	hipLaunchKernelGGL( spa_l1_scan_kernel_##N, dim3( nblocks), dim3( nthreads), lds, stream, P); } while (0)
+	if (P.cpBlocks) { \
+		if (lds > 65536) { hipError_t e = hipFuncSetAttribute( (const void*)spa_l1_scan_kernel_##N##_cp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
+		hipLaunchKernelGGL( spa_l1_scan_kernel_##N##_cp, dim3( nblocks), dim3( nthreads), lds, stream, P); \
+	} else { \
+		if (lds > 65536) { hipError_t e = hipFuncSetAttribute( (const void*)spa_l1_scan_kernel_##N, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
+		hipLaunchKernelGGL( spa_l1_scan_kernel_##N, dim3( nblocks), dim3( nthreads), lds, stream, P); \
+	} } while (0)
 	switch (P.nofPasses)
 	{
 		case 1: SPA_L1_LAUNCH( p1); break;
@@ -1304,7 +1372,8 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 	if (e != hipSuccess) return e;
 	if (betweenKernels) { e = hipEventRecord( betweenKernels, stream); if (e != hipSuccess) return e; }
 	// its own number of waves (one event array each), in workgroups of POST_WAVES
-	hipLaunchKernelGGL( spa_l1_post_kernel, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
+	if (P.cpBlocks) hipLaunchKernelGGL( spa_l1_post_kernel_cp, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
+	else hipLaunchKernelGGL( spa_l1_post_kernel, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
 	return hipGetLastError();
 }
 }

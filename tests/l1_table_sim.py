@@ -13,8 +13,10 @@ class Tables:
     def __init__(self, dump):
         d = [int(x) for x in dump]
         self.nofPasses, self.nofClasses, self.maxEx, self.nofPatterns, self.nofPositions, self.nofLiterals = d[0:6]
+        self.ucp = bool(d[7])
         p = 8
-        self.byteClass = d[p:p + 256]; p += 256
+        nsym = 320 if self.ucp else 256     # UCP: [256..319] = continuation bytes 80..BF of a word character
+        self.byteClass = d[p:p + nsym]; p += nsym
         self.classCtx = d[p:p + self.nofClasses]; p += self.nofClasses
         P, C = self.nofPasses, self.nofClasses
         E = max(self.maxEx, 1)
@@ -48,27 +50,48 @@ class Tables:
         self.cpPages = take(npg)
         assert p == len(d)
 
-    def cls(self, text, pos):
-        """class of the byte at pos: by code point for the lead byte of a well-formed multi-byte character when
-        the tables have classes by code point, else by byte"""
+    def _lead(self, text, pos):
+        """(class by code point or None, length) of the well-formed character starting at pos"""
         b = text[pos]
-        if self.cpBlocks and 0xC2 <= b <= 0xF4:
-            want = 2 if b <= 0xDF else 3 if b <= 0xEF else 4
-            if pos + want <= len(text) and all((text[pos + i] & 0xC0) == 0x80 for i in range(1, want)):
-                v = b & (0xFF >> (want + 1))
-                for i in range(1, want):
-                    v = (v << 6) | (text[pos + i] & 0x3F)
-                ok = v >= 0x80 if want == 2 else v >= 0x800 if want == 3 else 0x10000 <= v <= 0x10FFFF
-                if ok:
-                    c = self.cpPages[self.cpBlocks[v >> 6] * 64 + (v & 63)]
-                    if c != 0xFF:
-                        return c
+        if not (self.cpBlocks and 0xC2 <= b <= 0xF4):
+            return None, 1
+        want = 2 if b <= 0xDF else 3 if b <= 0xEF else 4
+        if pos + want <= len(text) and all((text[pos + i] & 0xC0) == 0x80 for i in range(1, want)):
+            v = b & (0xFF >> (want + 1))
+            for i in range(1, want):
+                v = (v << 6) | (text[pos + i] & 0x3F)
+            ok = v >= 0x80 if want == 2 else v >= 0x800 if want == 3 else 0x10000 <= v <= 0x10FFFF
+            if ok:
+                c = self.cpPages[self.cpBlocks[v >> 6] * 64 + (v & 63)]
+                if c != 0xFF:
+                    return c, want
+        return None, 1
+
+    def cls(self, text, pos):
+        """class of the byte at pos: by code point for the lead byte of a well-formed multi-byte character when the
+        tables have classes by code point; with UCP the twin class for a continuation byte of a word character"""
+        b = text[pos]
+        c, _ = self._lead(text, pos)
+        if c is not None:
+            return c
+        if self.ucp and 0x80 <= b <= 0xBF:
+            for d in range(1, 4):
+                if pos - d < 0:
+                    break
+                l = text[pos - d]
+                if 0xC2 <= l <= 0xF4:
+                    lc, n = self._lead(text, pos - d)
+                    if lc is not None and n > d and self.classCtx[lc] == 0:
+                        return self.byteClass[256 + b - 0x80]
+                    break
+                if (l & 0xC0) != 0x80:
+                    break
         return self.byteClass[b]
 
     def ctx(self, text, pos):
         if pos < 0 or pos >= len(text):
             return CTX_EDGE
-        return self.classCtx[self.byteClass[text[pos]]]
+        return self.classCtx[self.cls(text, pos)]
 
     def raw_reports(self, text):
         """[(patternidx 1-based, from, to)] in (to, idx) order."""

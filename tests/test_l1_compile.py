@@ -98,6 +98,23 @@ def test_unicode_property_classes():
         lx.compile()
 
 
+def test_ucp_unicode_word_characters():
+    """Option UCP: \\w \\d \\s by Unicode properties, \\b / \\B between characters by whether they are word
+    characters (L | N | _): every byte of a multi-byte character carries its character's context."""
+    pats = ["\\b\\w+\\b", "\\b\\p{Lu}\\p{Ll}*\\b", "\\d+", "\\s+", "\\B[a-z\u00df]", "[\u00e4\u00f6\u00fc]\\b", "x\\b.", "\\b\u00e9", "\\bber\\b", "\\b\u00fcber\\b", "\\W+"]
+    opts = ("DOTALL", "UCP")
+    texts = ["\u00c4rger \u00fcber \u00d6l und Stra\u00dfe 123x \u0663\u0664 \u0391\u0392\u03b3\u03b4 \u0416\u0443\u043a x y ber",
+             "x\u00e9 \u00e9x x.\u00e9 \u20ac\u00e9", "\u65e5\u672c\u8a9e text\u3000end", "", "\U0001d400\U0001d41ab \U0001f600x", "a\u0085b\u00a0c"]
+    for t in texts:
+        b = t.encode("utf8")
+        assert _product_reports(pats, b, opts) == _oracle_reports(pats, b, opts), t
+    for b in (b"\xc3", b"A\xc3(b", b"\xe0\x80\x80A\xed\xa0\x80b", b"\x80\xbfAb\xf4\x90\x80\x80", b"\xc3\x84\xc3 x\xc3\xa9\xa9", b"ab\xf0\x9d\x90"):
+        assert _product_reports(pats, b, opts) == _oracle_reports(pats, b, opts), b
+    # without the option the same expressions see ASCII word characters only
+    assert _product_reports(["\\b\\w+\\b"], "\u00fcber".encode("utf8")) == [(1, 2, 5)]
+    assert _product_reports(["\\b\\w+\\b"], "\u00fcber".encode("utf8"), opts) == [(1, 0, 5)]
+
+
 def test_caseless_folds_beyond_ascii():
     """CASELESS in UTF-8 mode uses Unicode case classes (tools/gen_unicode_tables.py): literals, classes, ranges."""
     pats = ["stra\u00dfe", "[a-z]+k", "\u00c4\u00d6[\u00fc]+", "\u03a3\u03af\u03c3\u03c5\u03c6\u03bf\u03c2", "[\u0430-\u044f]+", "x\u017f"]

@@ -123,6 +123,33 @@ def test_unicode_property_classes():
         assert got.doc(di).tolist() == o.match(d).tolist(), d[:80]
 
 
+def test_ucp_unicode_word_characters():
+    """Option UCP on the GPU: contexts per character (lead bytes by code point, continuation bytes by their character,
+    across tile boundaries), whole-word literals over Unicode word runs, start of match walking back over them."""
+    def build(x):
+        x.defineOption("UCP", 0) if isinstance(x, spa.PatternLexerInstance) else x.defineOption("UCP")
+        x.defineLexem(1, "\\b\\w+\\b", 0, 1, "content")
+        x.defineLexem(2, "\\b\\p{Lu}\\p{Ll}*\\b", 0, 2, "content")
+        x.defineLexem(3, "\\d+", 0, 3, "content")
+        x.defineLexem(4, "\\b\u00fcber\\b", 0, 4, "content")
+        x.defineLexem(5, "\\bber\\b", 0, 4, "content")
+        x.defineLexem(6, "\\B[a-z\u00df]+\\b", 0, 1, "predecessor")
+        x.defineLexem(7, "\\W+", 0, 1, "predecessor")
+        x.compile()
+    lx, o = _both(build)
+    rng = random.Random(12)
+    words = ["\u00c4rger", "\u00fcber", "\u00d6l", "Stra\u00dfe", "\u0391\u03b2\u03b3", "\u0416\u0443\u043a", "\u0663\u0664", "\u4f60\u597d", "\U0001d400\U0001d41a", "Abc", "x9_",
+             "ber", "DEF", "!", "\u20ac", " ", " ", "\n", "\u00a0", "\u3000"]
+    docs = ["".join(rng.choice(words) + rng.choice(["", " "]) for _ in range(n)).encode("utf8") for n in (0, 1, 7, 60, 400, 3000)]
+    docs += [b"\xc3", b"A\xc3(b", b"\xe0\x80\x80A\xed\xa0\x80b", b"\x80\xbfAb\xf4\x90\x80\x80", b"x" * 63 + "\u00c4b".encode("utf8"), b"x" * 62 + "\U0001d400b \u4f60".encode("utf8"),
+             b"x" * 61 + "\u4f60\u597d".encode("utf8") + b"y" * 70]
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in docs])
+    got = lx.createContext().matchDocs(b"".join(docs), offs)
+    for di, d in enumerate(docs):
+        assert got.doc(di).tolist() == o.match(d).tolist(), d[:80]
+
+
 def test_wide_alternations_cut_into_several_words():
     """Expressions beyond 64 byte positions (cut at an alternation into several automaton words): several words of
     one expression report at the same end offset with different starts (suffix-related alternatives sit in
