@@ -1005,9 +1005,10 @@ static bool plainLiteral( const std::string& expr)
 // SURVEY.md 8(f) and are rejected here.
 void LexerInstance::compile()
 {
-	if (m_options & (OptByteChar|OptAllowEmpty)) throw std::runtime_error( "option not supported by this oracle (BYTECHAR, ALLOWEMPTY)");
+	if (m_options & OptAllowEmpty) throw std::runtime_error( "option not supported by this oracle (ALLOWEMPTY)");
 	m_regex.clear(); m_literal.clear(); m_approx = false;
 	for (size_t i=0; i<m_defs.size(); ++i) if (m_defs[i].editdist) m_approx = true;
+	if (m_options & OptByteChar) m_approx = true;		// forceOneByteCharMap (patternLexer.cpp:1055-1058): the same route
 	if (m_approx)
 	{
 		if (m_options & OptCaseless) throw std::runtime_error( "edit distance matching (~N) with CASELESS is not supported by this oracle");
@@ -1019,7 +1020,7 @@ void LexerInstance::compile()
 			std::vector<uint32_t> cps;
 			const unsigned char* s = (const unsigned char*)d.expression.data();
 			for (size_t at=0; at<d.expression.size();) { uint32_t cp; unsigned n; decodeChar( s, d.expression.size(), at, cp, n); cps.push_back( cp); at += n; }
-			if (cps.size() > 24 || d.editdist > 3 || d.editdist >= cps.size()) throw std::runtime_error( "edit distance literal: at most 24 characters, distance at most 3 and below the length: " + d.expression);
+			if (cps.size() > 24 || d.editdist > 3 || (d.editdist && d.editdist >= cps.size())) throw std::runtime_error( "edit distance literal: at most 24 characters, distance at most 3 and below the length: " + d.expression);
 			m_literal.push_back( cps);
 		}
 		m_compiled = true;

@@ -937,7 +937,6 @@ void LexCompiler::defineOption( const std::string& name, double)
 // src/patternLexer.cpp:1068-1118 (+ PatternTable::complete :333-412)
 void LexCompiler::compile()
 {
-	if (m_options & LEX_BYTECHAR) throw std::runtime_error( "option BYTECHAR (one byte character map) is not supported by this lexer yet");
 	if (m_options & LEX_ALLOWEMPTY) throw std::runtime_error( "option ALLOWEMPTY is not supported by this lexer");
 	LexTables& T = m_tables;
 	T = LexTables();
@@ -946,6 +945,7 @@ void LexCompiler::compile()
 	//    (src/patternLexer.cpp:333-352); supported for tables of plain literals
 	bool approxTable = false;
 	for (size_t di=0; di<m_defs.size(); ++di) if (m_defs[ di].editdist) approxTable = true;
+	if (m_options & LEX_BYTECHAR) approxTable = true;		// forceOneByteCharMap (:1055-1058): the same route without an edit distance
 	if (approxTable)
 	{
 		if (m_options & LEX_CASELESS) throw std::runtime_error( "approximate matching (~N) together with CASELESS is not supported by this lexer");
@@ -967,7 +967,7 @@ void LexCompiler::compile()
 		{
 			if (d.expression.empty() || d.expression.find_first_of( "\\.[](){}|*+?^$") != std::string::npos || d.resultIndex)
 			{
-				throw std::runtime_error( "failed to compile pattern \"" + d.expression + "\": a table with approximate matching (~N) holds plain literal expressions only in this lexer");
+				throw std::runtime_error( "failed to compile pattern \"" + d.expression + "\": a table with approximate matching (~N) or option BYTECHAR holds plain literal expressions only in this lexer");
 			}
 			DevApproxPattern ap; std::memset( &ap, 0, sizeof(ap));
 			ap.id = d.id; ap.levelBind = (d.level & 0xFF) | ((uint32_t)d.posbind << 8); ap.editdist = d.editdist; ap.byteLen = (uint32_t)d.expression.size();

@@ -89,6 +89,28 @@ def test_random_approximate_literal_tables(seed):
         assert got.doc(di).tolist() == want, (defs, d)
 
 
+def test_bytechar_option_on_literal_tables():
+    """Option BYTECHAR (forceOneByteCharMap, patternLexer.cpp:1055-1058) sends every expression through the
+    one-byte character hash and the re-match: built for tables of plain literals (hash collisions between characters
+    beyond ASCII -- code points equal modulo 128 -- must be filtered by the re-match), rejected for anything else."""
+    def build(x):
+        x.defineOption("BYTECHAR", 0) if isinstance(x, spa.PatternLexerInstance) else x.defineOption("BYTECHAR")
+        x.defineLexem(1, "a\u00f6\u00fc", 0, 1, "content")
+        x.defineLexem(2, "\u00f6", 0, 2, "content")
+        x.defineLexem(3, "abc", 0, 1, "content")
+        x.compile()
+    lx, o = _both(build)
+    # U+0176 and U+01F6 hash like U+00F6 (246 mod 128), U+017C like U+00FC
+    for t in ("a\u00f6\u00fc a\u0176\u017c \u01f6 \u00f6 abc abca\u00f6\u00fc", "", "\u00f6\u00f6\u00f6", "a\u0176\u00fc"):
+        b = t.encode("utf8")
+        assert lx.createContext().match(b).tolist() == o.match(b).tolist(), t
+    lx = spa.PatternLexerInstance()
+    lx.defineOption("BYTECHAR", 0)
+    lx.defineLexem(1, "a+", 0, 1, "content")
+    with pytest.raises(spa.PatternError):
+        lx.compile()
+
+
 def test_approximate_table_survives_invalid_utf8():
     def build(x):
         x.defineLexem(1, "ab\u00f6 ~1", 0, 1, "content")
