@@ -422,7 +422,8 @@ class PatternLexerContext:
         arr = (ctypes.c_uint64 * 8)()
         if self._L.sp_lexer_ctx_batch_counters(self._h, arr) != 0:
             raise PatternError("reading batch counters failed: " + self._err())
-        return {"lexems": arr[0], "bytes": arr[1], "raw_reports": arr[2], "failed_docs": arr[3], "prof": [arr[4], arr[5], arr[6], arr[7]]}
+        return {"lexems": arr[0], "bytes": arr[1], "raw_reports": arr[2], "failed_docs": arr[3], "scan_units": arr[4], "rescanned_docs": arr[5],
+                "prof": [arr[4], arr[5], arr[6], arr[7]]}
 
     def batchStatus(self, ndocs):
         st = np.zeros(ndocs, np.int32)

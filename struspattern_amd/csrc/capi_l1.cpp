@@ -41,7 +41,7 @@ struct sp_lexer_ctx
 	int device;
 	std::string lasterror;
 	DeviceBuffer dByteClass, dClassCtx, dCharMask, dStartMask, dAcceptMask, dShiftDst, dSelfLoop, dExSrc, dExDst, dExCount,
-		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit, dApprox, dCharCp, dCharPos, dCpBlocks, dCpPages;
+		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit, dApprox, dCharCp, dCharPos, dCpBlocks, dCpPages, dUnitStart, dDocSequential;
 	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst; unsigned blockThreads;
 	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus, dQueue, dReportCount;
 	uint32_t queueMul;		// report queue between the two kernels: queueMul/16 reports per text byte (+64 per document)
@@ -312,8 +312,15 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	if (c->lexemCapacity < want) { c->lexemCapacity = 0; c->dLexems.alloc( want*sizeof(sp_lexem_t)); c->lexemCapacity = want; }	// (capacity follows the buffer also when the allocation fails)
 	c->dDocRange.reserve( (ndocs+1)*2*sizeof(uint64_t));
 	c->dDocStatus.reserve( (ndocs+1)*sizeof(int32_t));
-	c->dReportCount.reserve( (ndocs+1)*sizeof(uint32_t));
-	c->dQueue.reserve( ((((uint64_t)nbytes * c->queueMul) >> 4) + 64ull*(ndocs+2)) * 16);
+	// documents longer than a chunk are scanned as several units (SPA_L1_CHUNK_BYTES: tests)
+	uint32_t chunkBytes = 65536;
+	if (const char* e = getenv( "SPA_L1_CHUNK_BYTES")) { long v = atol( e); if (v >= 64 && v <= (1l << 30)) chunkBytes = (uint32_t)v & ~63u; }
+	const uint64_t maxUnits = (uint64_t)ndocs + (uint64_t)nbytes / chunkBytes + 2;
+	if (maxUnits >= 0xFFFFFFFFull) throw std::runtime_error( "too many scan units in one batch");
+	c->dReportCount.reserve( (maxUnits+1)*sizeof(uint32_t));
+	c->dUnitStart.reserve( (ndocs+2)*sizeof(uint32_t));
+	c->dDocSequential.reserve( (ndocs+1)*sizeof(uint32_t));
+	c->dQueue.reserve( ((((uint64_t)nbytes * c->queueMul) >> 4) + 64ull*(maxUnits+2)) * 16);
 	if (!T.approx.empty())
 	{
 		// approximate literal table: the decoded characters of every document (code point, byte offset)
@@ -346,6 +353,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.charCp = (uint32_t*)c->dCharCp.ptr; P.charPos = (uint32_t*)c->dCharPos.ptr;
 	P.cpBlocks = T.cpBlocks.empty() ? 0 : (const uint16_t*)c->dCpBlocks.ptr; P.cpPages = (const uint8_t*)c->dCpPages.ptr;
 	P.ucp = T.ucp ? 1u : 0u;
+	P.unitStart = (uint32_t*)c->dUnitStart.ptr; P.chunkBytes = chunkBytes; P.docSequential = (uint32_t*)c->dDocSequential.ptr; P.sequentialPass = 0;
 	P.splitPatterns = (T.patterns.size() != c->inst->compiler.nofDefinitions()) ? 1u : 0u;
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
 	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = c->ldsWords;
@@ -378,7 +386,13 @@ int sp_lexer_ctx_batch_counters( sp_lexer_ctx_t* c, uint64_t counters[8])
 	return guardedCall1( c->lasterror, SP_ERR_DEVICE, [&]{
 		HIP_CHECK( hipSetDevice( c->device));
 		HIP_CHECK( hipStreamSynchronize( c->lastStream));
-		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, L1C_COUNT*sizeof(uint64_t), hipMemcpyDeviceToHost));
+		uint64_t all[ L1C_ALLOC];
+		HIP_CHECK( hipMemcpy( all, c->dCounters.ptr, L1C_ALLOC*sizeof(uint64_t), hipMemcpyDeviceToHost));
+		for (int i=0; i<L1C_COUNT; ++i) counters[ i] = all[ i];
+#ifndef SPA_PROF
+		// (the phase profile of a PROF build lives in 4..7) scan units of the batch and documents scanned again in one piece
+		counters[ 4] = (uint32_t)all[ L1C_UNITS]; counters[ 5] = all[ L1C_SEQDOCS];
+#endif
 	});
 }
 

@@ -6,7 +6,8 @@
 
 namespace spa {
 
-enum {L1C_LEXEMS=0, L1C_BYTES=1, L1C_RAW=2, L1C_FAILED=3, L1C_COUNT=8, L1C_CURSOR=8 /*document cursor of the scan kernel, behind the counters*/, L1C_CURSOR2=9 /*of the post-processing kernel*/, L1C_ALLOC=10};
+enum {L1C_LEXEMS=0, L1C_BYTES=1, L1C_RAW=2, L1C_FAILED=3, L1C_COUNT=8, L1C_CURSOR=8 /*document cursor of the scan kernel, behind the counters*/, L1C_CURSOR2=9 /*of the post-processing kernel*/,
+      L1C_CURSOR3=10 /*of the sequential re-scan*/, L1C_UNITS=11 /*scan units = chunks of all documents*/, L1C_CHUNKED=12 /*some document has more than one chunk*/, L1C_SEQDOCS=13 /*documents scanned again in one piece*/, L1C_ALLOC=14};
 
 struct L1Params
 {
@@ -68,6 +69,13 @@ struct L1Params
 	uint32_t* charPos;
 	const uint16_t* cpBlocks;	// classes by code point (LexTables::cpBlocks / cpPages), or null
 	const uint8_t* cpPages;
+	// documents longer than chunkBytes are scanned as several units (unit = one chunk of one document): unitStart[d] = first
+	// unit of document d (ndocs+1 entries, written by the units kernel); the raw reports of unit u lie at
+	// reportQueue[ 4*((byte offset of the chunk * queueMul >> 4) + 64*u) ..), reportCount[u] of them
+	uint32_t* unitStart;
+	uint32_t chunkBytes;		// multiple of 64
+	uint32_t* docSequential;	// [ndocs]: 1 = a chunk's start state could not be proven from its warm-up; the document is scanned again in one piece
+	uint32_t sequentialPass;	// this launch of the scan kernel is that re-scan
 	uint32_t ucp;			// option UCP: contexts by Unicode word characters, byteClass has the 64 twin entries [256..319]
 	uint32_t splitPatterns;		// some expression is cut into several patterns entries (same defIndex): their reports are merged
 };

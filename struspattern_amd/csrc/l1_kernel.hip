@@ -49,7 +49,8 @@ typedef uint64_t u64;
 #define PROF_ACC( SLOT, T0) do { (void)(T0); } while (0)
 #endif
 
-enum {L1D_OK=0, L1D_ERR_ARENA=2, L1D_ERR_LEXEMSIZE=7, L1D_ERR_INTERNAL=8, L1D_ERR_OUTPUT=9};
+enum {L1D_OK=0, L1D_ERR_ARENA=2, L1D_ERR_LEXEMSIZE=7, L1D_ERR_INTERNAL=8, L1D_ERR_OUTPUT=9,
+      L1D_CHUNK_UNPROVEN=100};	// (internal: the document goes to the sequential re-scan)
 
 __device__ __forceinline__ u32 uni( u32 v) { return __builtin_amdgcn_readfirstlane( v); }
 __device__ __forceinline__ u32 ldu( const u32* p) { return __builtin_amdgcn_readfirstlane( *p); }
@@ -76,6 +77,7 @@ struct LexWave
 	u32 nQueue, nEvents, err, queueCap;
 	EventLanes e; u32 cnt;	// the cnt most recent events, lane L holds event nEvents-1-L
 	u32 tailPos, tailEnd;	// start and end of the last event (lane 0), valid while cnt > 0
+	u32 unit0, unit, unitEnd; u64 docBegin;	// post-processing of a chunked document: the unit whose reports are being read, one behind its last unit
 	const unsigned char* doc;
 	u32 docLen;
 #ifdef SPA_PROF
@@ -139,6 +141,33 @@ __device__ __forceinline__ int ctxAt( const L1Params& P, const unsigned char* do
 	if (CP && P.ucp) { u32 cls; int ctx; classCtxAt( P, doc, len, pos, cls, ctx); return ctx; }
 	return P.classCtx[ P.byteClass[ doc[ pos]]];
 }
+// UCP: which of the bytes q, q+1, q+2 are continuation bytes of a word character that begins before q (the carry a scan
+// starting at q takes over from the tile before)
+__device__ __forceinline__ u64 wordCarryAt( const L1Params& P, const unsigned char* doc, u32 len, u32 q)
+{
+	u64 carry = 0;
+	for (u32 d=0; d<3u && q+d<len; ++d)
+	{
+		const u32 pos = q + d;
+		if ((doc[ pos] & 0xC0u) != 0x80u) break;
+		for (u32 back=1; back<=3u && back<=pos; ++back)
+		{
+			const u32 l = doc[ pos-back];
+			if (l >= 0xC2u && l <= 0xF4u)
+			{
+				const u32 want = l <= 0xDFu ? 2u : l <= 0xEFu ? 3u : 4u;
+				if (pos-back < q && want > back)
+				{
+					const u32 c = cpClassAt( P, doc, len, pos-back);
+					if (c != 0xFFu && P.classCtx[ c] == (u32)CTX_WORD) carry |= 1ull << d;
+				}
+				break;
+			}
+			if ((l & 0xC0u) != 0x80u) break;
+		}
+	}
+	return carry;
+}
 // class | context << 8 of the byte of my lane in the 64-byte tile at `tile` (`mine`), from the in-register byte tables and
 // -- in the kernel instances for tables with classes by code point (CP) -- from the decoded character; wcarry: continuation
 // bytes at the start of the next tile that belong to a word character of this one (UCP)
@@ -149,7 +178,7 @@ __device__ __forceinline__ u32 tileClassCtx( const L1Params& P, const unsigned c
 	const u32 clsL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)clsReg) >> shm) & 0xFFu;
 	const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> shm) & 0xFFu;
 	u32 ccv = clsL | (ctxL << 8);
-	if (CP)
+	if (CP && P.cpBlocks)
 	{
 		u32 n = 0; bool word = false;
 		if (mine >= 0xC2u && mine <= 0xF4u && tile + LANE < len)
@@ -211,7 +240,7 @@ __device__ __forceinline__ void resolveStarts( const u32* queue, const unsigned 
 				Rp |= (R & ed) ? es : 0ull;
 			}
 			u32 cls = P.byteClass[ doc[ j-2]];
-			if (CP && doc[ j-2] >= 0x80u) { int cx; classCtxAt( P, doc, docLen, j-2, cls, cx); }
+			if (CP && P.cpBlocks && doc[ j-2] >= 0x80u) { int cx; classCtxAt( P, doc, docLen, j-2, cls, cx); }
 			R = Rp & mask & T.at( (pass*P.nofClasses + cls)*64 + ln);
 			--j;
 		}
@@ -575,9 +604,17 @@ __device__ __forceinline__ void tileLiterals(  const LexWave& w, const L1Params&
 }
 
 // ---------------------------------------------------------------- stage 1: forward scan
-template <int PASSES, bool LDS, bool CP>
-__device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& T)
+// Scans the bytes [segBeg, segEnd) of the document (CH: a chunk of it; else the whole document) and queues the raw reports
+// of the end offsets segBeg .. segEnd-1, and of segEnd when that is the document's end.  The state at the start of a
+// later chunk comes from a warm-up over the WARM bytes before it: S = the state reached from the empty state with starts
+// injected (a subset of the true state), F = the state reached from "every position live" without injection (a superset of
+// whatever the true state before the warm-up contributes).  The automaton is linear in its state set, so the true state
+// is S | (something inside F): F inside S proves S exact -- the usual case after a few words --, otherwise the document is
+// handed to the sequential re-scan (L1D_CHUNK_UNPROVEN).
+template <int PASSES, bool LDS, bool CP, bool CH>
+__device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& T, const u32 segBeg, const u32 segEnd)
 {
+	enum {WARM=256};
 	u64 state[ PASSES];
 #pragma unroll
 	for (int p=0; p<PASSES; ++p) state[ p] = 0;
@@ -604,11 +641,14 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 		nExOf[ p] = on ? uni( P.exCount[ p]) : 0;
 	}
 	u64 wcarry = 0;
-	for (u32 tile=0; tile<=len && !w.err; tile+=64)
+	auto runRange = [&]( auto emitTag, auto injectTag, const u32 from, const u32 to, const bool withEnd)
+	{
+	constexpr bool EMIT = decltype(emitTag)::value, INJECT = decltype(injectTag)::value;
+	for (u32 tile=from; (tile < to || (withEnd && tile == to)) && !w.err; tile+=64)
 	{
 		// 64 document bytes per load, one per lane; replayed byte by byte through a scalar register
 		u32 mine = (tile + LANE < len) ? w.doc[ tile + LANE] : 0u;
-		u32 inTile = (len - tile) < 64 ? (len - tile) : 64;	// document bytes in this tile
+		u32 inTile = (to - tile) < 64 ? (to - tile) : 64;	// bytes of the range in this tile
 		// class and context of my byte (lane-parallel lookup in the register tables), replayed per byte with one readlane
 		const u32 ccv = tileClassCtx<CP>( P, w.doc, len, tile, mine, clsReg, ctxReg, wcarry);
 		// one byte step; the virtual step behind the last byte (matches that end with the document) is a
@@ -647,7 +687,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 				anyAcc |= acc[ p];
 				if (!atEnd)
 				{
-					u64 nxt = ((st << 1) & shiftDst[ p]) | (st & selfLoop[ p]) | stRow[ p];
+					u64 nxt = ((st << 1) & shiftDst[ p]) | (st & selfLoop[ p]) | (INJECT ? stRow[ p] : 0ull);
 					const u32 nEx = nExOf[ p];
 					for (u32 e=0; e<nEx; ++e)
 					{
@@ -658,7 +698,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 					state[ p] = nxt & cmRow[ p];
 				}
 			}
-			if (__ballot( anyAcc != 0))
+			if (EMIT && __ballot( anyAcc != 0))
 			{
 				
 #pragma unroll
@@ -754,8 +794,50 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 			prevctx = ctx;
 		};
 		for (u32 k=0; k<inTile && !w.err; ++k) step( std::false_type(), k);
-		if (tile + 64 > len && !w.err) step( std::true_type(), inTile);
+		if (withEnd && tile + 64 > to && !w.err) step( std::true_type(), inTile);
 	}
+	};
+	if (CH && segBeg)
+	{
+		const u32 q = segBeg > (u32)WARM ? segBeg - (u32)WARM : 0u;
+		const u64 carry0 = (CP && P.ucp) ? wordCarryAt( P, w.doc, len, q) : 0ull;
+		u64 F[ PASSES];
+#pragma unroll
+		for (int p=0; p<PASSES; ++p) state[ p] = ~0ull;
+		wcarry = carry0;
+		runRange( std::false_type(), std::false_type(), q, segBeg, false);
+#pragma unroll
+		for (int p=0; p<PASSES; ++p) { F[ p] = state[ p]; state[ p] = 0; }
+		prevctx = q ? ctxAt<CP>( P, w.doc, len, (long)q - 1) : (int)CTX_EDGE;
+		wcarry = carry0;
+		runRange( std::false_type(), std::true_type(), q, segBeg, false);
+		if (q)
+		{
+			u64 bad = 0;
+#pragma unroll
+			for (int p=0; p<PASSES; ++p) bad |= F[ p] & ~state[ p];
+			if (__ballot( bad != 0)) { w.err = L1D_CHUNK_UNPROVEN; return; }
+		}
+	}
+	if (CH) runRange( std::true_type(), std::true_type(), segBeg, segEnd, segEnd == len);
+	else runRange( std::true_type(), std::true_type(), 0u, len, true);		// (the whole document: constants for the plain instance)
+}
+
+// the reports of a chunked document lie in one slice of the report queue per chunk: on to the next slice that holds any
+__device__ __forceinline__ void sliceOf( LexWave& w, const L1Params& P)
+{
+	w.queue = P.reportQueue + 4*(((w.docBegin + (u64)(w.unit - w.unit0) * P.chunkBytes) * P.queueMul >> 4) + 64ull*w.unit);
+	w.nQueue = ldu( &P.reportCount[ w.unit]);
+}
+__device__ __forceinline__ bool nextSlice( LexWave& w, const L1Params& P)
+{
+	while (w.unit + 1u < w.unitEnd)
+	{
+		++w.unit;
+		sliceOf( w, P);
+		if (w.nQueue) return true;
+	}
+	return false;
 }
 
 // ---------------------------------------------------------------- stages 1b-3: literals, start of match, handler
@@ -770,7 +852,7 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 	for (u32 k=0; k<4; ++k) { const u32 c = P.byteClass[ 4*LANE + k]; clsReg |= c << (8*k); ctxReg |= (u32)P.classCtx[ c] << (8*k); }
 	u64 wcarry = 0;
 	LitCarry carry; carry.in = false; carry.hash = 0; carry.len = 0; carry.start = 0;
-	const u32 nq = w.nQueue;
+	u32 nq = w.nQueue;
 	u32 qi = 0, qb = 0, qn = 0;		// next report; the batch [qb, qb+qn) is resolved in lr
 	LaneReport lr;
 	lr.to = 0; lr.from = 0; lr.id = 0; lr.levelBind = 0; lr.prefixLen = 0; lr.suffixLen = 0; lr.pi = 0; lr.def = 0; lr.skip = 0;
@@ -849,6 +931,12 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 					const u64 tR = PROF_T();
 					nextBatch<LDS,CP>( w.queue, w.doc, w.docLen, P, T, nq, qb, qn, lr);
 					PROF_ACC( 2, tR);
+				}
+				else if (CP && qi == nq && nextSlice( w, P))
+				{
+					// (a chunked document: the reports of its next chunk)
+					nq = w.nQueue; qi = 0; qb = 0;
+					nextBatch<LDS,CP>( w.queue, w.doc, w.docLen, P, T, nq, qb, qn, lr);
 				}
 			}
 		}
@@ -959,7 +1047,6 @@ __device__ __forceinline__ void docBounds( const L1Params& P, u32 doc, u64& beg,
 	beg = ((u64)ldu( (const u32*)&P.docOffsets[ doc]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc]);
 	end = ((u64)ldu( (const u32*)&P.docOffsets[ doc+1]+1) << 32) | ldu( (const u32*)&P.docOffsets[ doc+1]);
 }
-__device__ __forceinline__ u64 queueBase( const L1Params& P, u64 beg, u32 doc) { return ((beg * P.queueMul) >> 4) + 64ull*doc; }
 
 // ---------------------------------------------------------------- approximate literal tables
 // A table with an edit distance expression (`literal ~N`) takes the reference's other route (src/patternLexer.cpp
@@ -1215,40 +1302,95 @@ __device__ __forceinline__ void stageTables( const L1Params& P, LexTab<LDS>& T)
 }
 
 // SCAN: automaton over the document's bytes, raw reports into the document's slice of the report queue
-template <int PASSES, bool LDS, bool CP>
+// UNITS: one wave counts the chunks of every document: unitStart[], the number of units, whether any document has more than
+// one; and clears the per-document flags
+__device__ void countUnits( const L1Params& P)
+{
+	u32 running = 0, chunked = 0;
+	for (u32 base=0; base<P.ndocs; base+=64)
+	{
+		const u32 d = base + LANE;
+		u32 n = 0;
+		if (d < P.ndocs)
+		{
+			const u64 len = P.docOffsets[ d+1] - P.docOffsets[ d];
+			n = len ? (u32)((len + P.chunkBytes - 1) / P.chunkBytes) : 1u;
+			P.docStatus[ d] = 0; P.docSequential[ d] = 0;
+		}
+		const u32 incl = waveScanAdd( n);
+		if (d < P.ndocs) P.unitStart[ d] = running + incl - n;
+		running += uni( (u32)__shfl( (int)incl, 63));
+		if (__ballot( n > 1u)) chunked = 1;
+	}
+	if (LANE == 0)
+	{
+		P.unitStart[ P.ndocs] = running;
+		*(u32*)&P.counters[ L1C_UNITS] = running;
+		*(u32*)&P.counters[ L1C_CHUNKED] = chunked;
+	}
+}
+
+__device__ __forceinline__ u64 queueBase( const L1Params& P, u64 bytePos, u32 unit) { return ((bytePos * P.queueMul) >> 4) + 64ull*unit; }
+
+// SCAN: automaton over the bytes of a unit (a document, or a chunk of a long one), raw reports into the unit's slice of the
+// report queue.  Two sets of instances: the plain one (FULL = false) runs batches without classes by code point and without
+// chunked documents, the other one everything else; both are launched, the one that is not meant leaves at once.
+template <int PASSES, bool LDS, bool FULL>
 __device__ void scanDocuments( const L1Params& P)
 {
+	const u32 chunked = ldu( (const u32*)&P.counters[ L1C_CHUNKED]);
+	if (FULL != (P.cpBlocks != 0 || chunked != 0)) return;
 	LexTab<LDS> T;
 	stageTables( P, T);
 	LexWave w;
 	w.events = 0; w.nEvents = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
+	const u32 nunits = P.sequentialPass ? P.ndocs : ldu( (const u32*)&P.counters[ L1C_UNITS]);
 	// the loop is bounded so that it ends whatever the cursor holds
-	for (u32 round=0; round<=P.ndocs; ++round)
+	for (u32 round=0; round<=nunits; ++round)
 	{
-		// every document comes from the device-side cursor (a workgroup that only becomes resident when others have
+		// every unit comes from the device-side cursor (a workgroup that only becomes resident when others have
 		// finished finds it exhausted and leaves at once: no document waits for a particular wave)
-		u32 doc = 0;
-		if (LANE == 0) doc = atomicAdd( (u32*)&P.counters[ L1C_CURSOR], 1u);
-		doc = uni( doc);
-		if (doc >= P.ndocs) break;
+		u32 unit = 0;
+		if (LANE == 0) unit = atomicAdd( (u32*)&P.counters[ P.sequentialPass ? L1C_CURSOR3 : L1C_CURSOR], 1u);
+		unit = uni( unit);
+		if (unit >= nunits) break;
+		u32 doc = unit, u0 = unit, u1 = unit + 1;
+		if (FULL && P.sequentialPass)
+		{
+			// the re-scan of the documents whose chunks could not be joined: in one piece, into the slices of all its units
+			if (ldu( &P.docSequential[ doc]) == 0) continue;
+			if (LANE == 0) atomicAdd( (unsigned long long*)&P.counters[ L1C_SEQDOCS], 1ull);
+			u0 = ldu( &P.unitStart[ doc]); u1 = ldu( &P.unitStart[ doc+1]);
+		}
+		else if (FULL && chunked)
+		{
+			u32 lo = 0, hi = P.ndocs;			// last document whose first unit is <= unit
+			while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (ldu( &P.unitStart[ mid]) <= unit) lo = mid; else hi = mid; }
+			doc = lo;
+		}
 		u64 beg, end;
 		docBounds( P, doc, beg, end);
 		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
-		const u64 qb = queueBase( P, beg, doc);
+		u32 segBeg = 0, segEnd = w.docLen;
+		if (FULL && chunked && !P.sequentialPass)
+		{
+			segBeg = (unit - ldu( &P.unitStart[ doc])) * P.chunkBytes;
+			segEnd = (w.docLen - segBeg) < P.chunkBytes ? w.docLen : segBeg + P.chunkBytes;
+		}
+		const u64 qb = queueBase( P, beg + segBeg, u0);
 		w.queue = P.reportQueue + 4*qb;
-		w.queueCap = (u32)(queueBase( P, end, doc+1) - qb);
+		w.queueCap = (u32)(queueBase( P, beg + segEnd, u1) - qb);
 		w.nQueue = 0; w.err = 0;
-		scanDocument<PASSES,LDS,CP>( w, P, T);
+		scanDocument<PASSES,LDS,FULL,FULL>( w, P, T, segBeg, segEnd);
 		if (LANE == 0)
 		{
-			P.reportCount[ doc] = w.err ? 0u : w.nQueue;
-			P.docStatus[ doc] = (int32_t)w.err;
-			atomicAdd( (unsigned long long*)&P.counters[ L1C_RAW], (unsigned long long)w.nQueue);
-			if (w.err)
+			if (w.err == L1D_CHUNK_UNPROVEN) { P.docSequential[ doc] = 1; P.reportCount[ u0] = 0; }
+			else
 			{
-				P.docRange[ 2*(u64)doc] = 0; P.docRange[ 2*(u64)doc+1] = 0;
-				atomicAdd( (unsigned long long*)&P.counters[ L1C_BYTES], (unsigned long long)w.docLen);
-				atomicAdd( (unsigned long long*)&P.counters[ L1C_FAILED], 1ull);
+				P.reportCount[ u0] = w.err ? 0u : w.nQueue;
+				for (u32 u=u0+1; u<u1; ++u) P.reportCount[ u] = 0;
+				if (w.err) P.docStatus[ doc] = (int32_t)w.err;
+				atomicAdd( (unsigned long long*)&P.counters[ L1C_RAW], (unsigned long long)w.nQueue);
 			}
 		}
 	}
@@ -1258,6 +1400,9 @@ __device__ void scanDocuments( const L1Params& P)
 template <bool LDS, bool CP>
 __device__ void postDocuments( const L1Params& P)
 {
+	// (CP: the instance for batches with classes by code point or chunked documents, see scanDocuments)
+	const u32 chunked = ldu( (const u32*)&P.counters[ L1C_CHUNKED]);
+	if (CP != (P.cpBlocks != 0 || chunked != 0)) return;
 	LexTab<LDS> T;
 	stageTables( P, T);
 	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -1274,12 +1419,26 @@ __device__ void postDocuments( const L1Params& P)
 		if (LANE == 0) doc = atomicAdd( (u32*)&P.counters[ L1C_CURSOR2], 1u);
 		doc = uni( doc);
 		if (doc >= P.ndocs) break;
-		if (ldu( (const u32*)&P.docStatus[ doc]) != 0) continue;		// failed in the scan kernel
 		u64 beg, end;
 		docBounds( P, doc, beg, end);
 		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
-		w.queue = P.reportQueue + 4*queueBase( P, beg, doc);
-		w.nQueue = ldu( &P.reportCount[ doc]);
+		if (ldu( (const u32*)&P.docStatus[ doc]) != 0)
+		{
+			// failed in the scan kernel
+			if (LANE == 0)
+			{
+				P.docRange[ 2*(u64)doc] = 0; P.docRange[ 2*(u64)doc+1] = 0;
+				atomicAdd( (unsigned long long*)&P.counters[ L1C_BYTES], (unsigned long long)w.docLen);
+				atomicAdd( (unsigned long long*)&P.counters[ L1C_FAILED], 1ull);
+			}
+			continue;
+		}
+		w.docBegin = beg;
+		w.unit0 = chunked ? ldu( &P.unitStart[ doc]) : doc;
+		w.unitEnd = chunked ? ldu( &P.unitStart[ doc+1]) : doc + 1u;
+		w.unit = w.unit0;
+		sliceOf( w, P);
+		if (CP && !w.nQueue) (void)nextSlice( w, P);
 		w.queueCap = w.nQueue; w.nEvents = 0; w.err = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
 		w.e.id = 0; w.e.pos = 0; w.e.size = 0; w.e.lb = 0;
 		const u64 tDoc = PROF_T();
@@ -1305,7 +1464,8 @@ __device__ void postDocuments( const L1Params& P)
 
 // One scan instance per pass count (the per-pass rows of a byte step live in registers, so the count is a
 // template parameter).
-// (a second set, _cp, for tables with classes by code point: \\p{..} sets, UCP -- the plain set pays nothing for them)
+// (a second set, _cp, for batches with classes by code point -- \\p{..} sets, UCP -- or with documents scanned in chunks: the
+// plain set pays nothing for either)
 #define SPA_L1_KERNEL( NAME, N, T) \
 extern "C" __global__ __launch_bounds__(T) void spa_l1_scan_kernel_##NAME( L1Params P) { if (P.ldsWords) scanDocuments<N,true,false>( P); else scanDocuments<N,false,false>( P); } \
 extern "C" __global__ __launch_bounds__(T) void spa_l1_scan_kernel_##NAME##_cp( L1Params P) { if (P.ldsWords) scanDocuments<N,true,true>( P); else scanDocuments<N,false,true>( P); }
@@ -1320,6 +1480,7 @@ SPA_L1_KERNEL( p8, 8, 1024)
 SPA_L1_KERNEL( p16, 16, 256)
 SPA_L1_KERNEL( p32, 32, 256)
 extern "C" __global__ __launch_bounds__(64) void spa_l1_approx_kernel( L1Params P) { approxDocuments( P); }
+extern "C" __global__ __launch_bounds__(64) void spa_l1_units_kernel( L1Params P) { countUnits( P); }
 // the post-processing kernel reads the automaton's tables from global memory (start of match only)
 enum {POST_WAVES=4};
 // The post-processing kernel is bound by the latency of its dependent chains, not by issue slots: it gains from
@@ -1345,14 +1506,20 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 		return betweenKernels ? hipEventRecord( betweenKernels, stream) : hipSuccess;
 	}
 	const size_t lds = (size_t)P.ldsWords * 8;
+	// the units of the batch (chunks of long documents), then BOTH sets of instances: which one a batch needs is known on
+	// the device only (classes by code point: here; chunked documents: after the units kernel) -- the other one leaves at once
+	hipLaunchKernelGGL( spa_l1_units_kernel, dim3( 1), dim3( 64), 0, stream, P);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	L1Params S = P;
+	S.sequentialPass = 1;
+#define SPA_L1_LAUNCH_ONE( KERNEL, ARGS) do { \
+	if (lds > 65536) { e = hipFuncSetAttribute( (const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
+	hipLaunchKernelGGL( KERNEL, dim3( nblocks), dim3( nthreads), lds, stream, ARGS); } while (0)
 #define SPA_L1_LAUNCH( N) do { \
-	if (P.cpBlocks) { \
-		if (lds > 65536) { hipError_t e = hipFuncSetAttribute( (const void*)spa_l1_scan_kernel_##N##_cp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
-		hipLaunchKernelGGL( spa_l1_scan_kernel_##N##_cp, dim3( nblocks), dim3( nthreads), lds, stream, P); \
-	} else { \
-		if (lds > 65536) { hipError_t e = hipFuncSetAttribute( (const void*)spa_l1_scan_kernel_##N, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
-		hipLaunchKernelGGL( spa_l1_scan_kernel_##N, dim3( nblocks), dim3( nthreads), lds, stream, P); \
-	} } while (0)
+	if (!P.cpBlocks) SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N, P); \
+	SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, P); \
+	SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, S); } while (0)
 	switch (P.nofPasses)
 	{
 		case 1: SPA_L1_LAUNCH( p1); break;
@@ -1368,12 +1535,12 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 			else if (P.nofPasses <= 32) SPA_L1_LAUNCH( p32);
 			else return hipErrorInvalidValue;
 	}
-	hipError_t e = hipGetLastError();
+	e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	if (betweenKernels) { e = hipEventRecord( betweenKernels, stream); if (e != hipSuccess) return e; }
 	// its own number of waves (one event array each), in workgroups of POST_WAVES
-	if (P.cpBlocks) hipLaunchKernelGGL( spa_l1_post_kernel_cp, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
-	else hipLaunchKernelGGL( spa_l1_post_kernel, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
+	if (!P.cpBlocks) hipLaunchKernelGGL( spa_l1_post_kernel, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
+	hipLaunchKernelGGL( spa_l1_post_kernel_cp, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
 	return hipGetLastError();
 }
 }

@@ -121,6 +121,65 @@ def test_approximate_table_survives_invalid_utf8():
         assert lx.createContext().match(text).tolist() == o.match(text).tolist(), text
 
 
+def test_long_documents_are_scanned_in_chunks(monkeypatch):
+    """A document longer than a chunk (64 KiB) is scanned as several units by several waves: the state at the start of a
+    later chunk is proven from a 256-byte warm-up (from the empty state with starts injected vs. from "every position
+    live" without), and a document where that proof fails -- a pattern whose state survives the warm-up -- is scanned
+    again in one piece.  Lexems must not depend on where the chunks fall."""
+    vocab = synth.vocabulary(3000, 3)
+    pats = synth.lexer_patterns(300, vocab, 7)
+
+    def build(x):
+        synth.apply_lexer_patterns(x, pats)
+    lx, o = _both(build)
+    sizes = [0, 10, 200_000, 5000, 65536, 65537, 131072, 70_000]
+    text, offs = synth.text_documents(len(sizes), 1000, vocab, 5, utf8=True)
+    rng = random.Random(3)
+    words = [w for w in vocab[:2000]]
+    docs = []
+    for n in sizes:
+        t = []
+        while sum(len(x) + 1 for x in t) < n:
+            t.append(rng.choice(words) if rng.random() < 0.9 else rng.choice(["\u00e4\u00f6", "Z\u00fcrich", "12'345", "."]))
+        docs.append(" ".join(t).encode("utf8")[:n])
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in docs])
+    ctx = lx.createContext()
+    got = ctx.matchDocs(b"".join(docs), offs)
+    c = ctx.batchCounters()
+    assert c["scan_units"] == sum(max(1, -(-len(d) // 65536)) for d in docs) and c["rescanned_docs"] == 0
+    for di, d in enumerate(docs):
+        assert got.doc(di).tolist() == o.match(d).tolist(), (di, len(d))
+    # every chunk boundary position: 64-byte chunks over short documents, including inside multi-byte characters and words
+    monkeypatch.setenv("SPA_L1_CHUNK_BYTES", "64")
+    small = [d[:n] for d in docs for n in (63, 64, 65, 127, 128, 129, 300, 1000) if len(d) >= n]
+    offs = np.zeros(len(small) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in small])
+    got = ctx.matchDocs(b"".join(small), offs)
+    assert ctx.batchCounters()["scan_units"] > len(small)
+    for di, d in enumerate(small):
+        assert got.doc(di).tolist() == o.match(d).tolist(), (di, len(d))
+    monkeypatch.delenv("SPA_L1_CHUNK_BYTES")
+
+    # a state that outlives the warm-up: the chunks cannot be joined, the document is scanned again in one piece
+    def build2(x):
+        x.defineOption("DOTALL", 0) if isinstance(x, spa.PatternLexerInstance) else x.defineOption("DOTALL")
+        x.defineLexem(1, "<[^>]*>", 0, 2, "content")
+        x.defineLexem(2, "\\b\\w+\\b", 0, 1, "content")
+        x.compile()
+    lx2, o2 = _both(build2)
+    body = (" word" * 2000).encode()                       # 10 KB without a '>' across the boundary of the first chunk
+    docs2 = [b"y " * 30000 + b"<a " + body + b"> tail <b>" + b" z" * 40000, b"short <c> doc", b"xy " * 23400 + b" <d> y"]
+    offs = np.zeros(len(docs2) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in docs2])
+    ctx2 = lx2.createContext()
+    got = ctx2.matchDocs(b"".join(docs2), offs)
+    c = ctx2.batchCounters()
+    assert c["rescanned_docs"] >= 1
+    for di, d in enumerate(docs2):
+        assert got.doc(di).tolist() == o2.match(d).tolist(), di
+
+
 def test_unicode_property_classes():
     """\\p{..}: positions classed by the decoded code point (lead bytes at every offset of the 64-byte tiles, documents
     of many tiles, malformed sequences); lexems vs the oracle."""
