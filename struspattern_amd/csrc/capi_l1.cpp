@@ -282,7 +282,13 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 {
 	HIP_CHECK( hipSetDevice( c->device));
 	const LexTables& T = c->inst->compiler.tables();
-	unsigned wavesWanted = (unsigned)((ndocs < (size_t)c->numCUs*20) ? ndocs : (size_t)c->numCUs*20);
+	// documents longer than a chunk are scanned as several units (SPA_L1_CHUNK_BYTES: tests)
+	uint32_t chunkBytes = 65536;
+	if (const char* e = getenv( "SPA_L1_CHUNK_BYTES")) { long v = atol( e); if (v >= 64 && v <= (1l << 30)) chunkBytes = (uint32_t)v & ~63u; }
+	const uint64_t maxUnits = (uint64_t)ndocs + (uint64_t)nbytes / chunkBytes + 2;
+	if (maxUnits >= 0xFFFFFFFFull) throw std::runtime_error( "too many scan units in one batch");
+	// scan kernel: one wave per unit up to what the device holds (a wave without a unit leaves at once)
+	unsigned wavesWanted = (unsigned)((maxUnits < (uint64_t)c->numCUs*20) ? maxUnits : (uint64_t)c->numCUs*20);
 	const unsigned wpb = c->blockThreads / 64;
 	unsigned nblocks = (wavesWanted + wpb-1) / wpb;
 	if (nblocks == 0) nblocks = 1;
@@ -312,11 +318,6 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	if (c->lexemCapacity < want) { c->lexemCapacity = 0; c->dLexems.alloc( want*sizeof(sp_lexem_t)); c->lexemCapacity = want; }	// (capacity follows the buffer also when the allocation fails)
 	c->dDocRange.reserve( (ndocs+1)*2*sizeof(uint64_t));
 	c->dDocStatus.reserve( (ndocs+1)*sizeof(int32_t));
-	// documents longer than a chunk are scanned as several units (SPA_L1_CHUNK_BYTES: tests)
-	uint32_t chunkBytes = 65536;
-	if (const char* e = getenv( "SPA_L1_CHUNK_BYTES")) { long v = atol( e); if (v >= 64 && v <= (1l << 30)) chunkBytes = (uint32_t)v & ~63u; }
-	const uint64_t maxUnits = (uint64_t)ndocs + (uint64_t)nbytes / chunkBytes + 2;
-	if (maxUnits >= 0xFFFFFFFFull) throw std::runtime_error( "too many scan units in one batch");
 	c->dReportCount.reserve( (maxUnits+1)*sizeof(uint32_t));
 	c->dUnitStart.reserve( (ndocs+2)*sizeof(uint32_t));
 	c->dDocSequential.reserve( (ndocs+1)*sizeof(uint32_t));

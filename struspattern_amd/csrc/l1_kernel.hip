@@ -844,7 +844,7 @@ __device__ __forceinline__ bool nextSlice( LexWave& w, const L1Params& P)
 // The document's raw reports (scan kernel) and its literal reports (found here, tile by tile) go through the
 // reference's handler in the order the reference's callback sees them: ascending end offset, ascending pattern
 // index inside one end offset.
-template <bool LDS, bool CP>
+template <bool LDS, bool CP, bool CH>
 __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& T)
 {
 	const u32 len = w.docLen;
@@ -932,7 +932,7 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 					nextBatch<LDS,CP>( w.queue, w.doc, w.docLen, P, T, nq, qb, qn, lr);
 					PROF_ACC( 2, tR);
 				}
-				else if (CP && qi == nq && nextSlice( w, P))
+				else if (CH && qi == nq && nextSlice( w, P))
 				{
 					// (a chunked document: the reports of its next chunk)
 					nq = w.nQueue; qi = 0; qb = 0;
@@ -1333,13 +1333,13 @@ __device__ void countUnits( const L1Params& P)
 __device__ __forceinline__ u64 queueBase( const L1Params& P, u64 bytePos, u32 unit) { return ((bytePos * P.queueMul) >> 4) + 64ull*unit; }
 
 // SCAN: automaton over the bytes of a unit (a document, or a chunk of a long one), raw reports into the unit's slice of the
-// report queue.  Two sets of instances: the plain one (FULL = false) runs batches without classes by code point and without
-// chunked documents, the other one everything else; both are launched, the one that is not meant leaves at once.
-template <int PASSES, bool LDS, bool FULL>
+// report queue.  All sets of instances are launched, the ones that are not meant for the batch leave at once.
+template <int PASSES, bool LDS, bool CP, bool CH>
 __device__ void scanDocuments( const L1Params& P)
 {
+	// three sets of instances: plain (no classes by code point, no chunked document in the batch), chunks, classes by code point (+ chunks)
 	const u32 chunked = ldu( (const u32*)&P.counters[ L1C_CHUNKED]);
-	if (FULL != (P.cpBlocks != 0 || chunked != 0)) return;
+	if (CP != (P.cpBlocks != 0) || (!CP && CH != (chunked != 0))) return;
 	LexTab<LDS> T;
 	stageTables( P, T);
 	LexWave w;
@@ -1355,14 +1355,14 @@ __device__ void scanDocuments( const L1Params& P)
 		unit = uni( unit);
 		if (unit >= nunits) break;
 		u32 doc = unit, u0 = unit, u1 = unit + 1;
-		if (FULL && P.sequentialPass)
+		if (CH && P.sequentialPass)
 		{
 			// the re-scan of the documents whose chunks could not be joined: in one piece, into the slices of all its units
 			if (ldu( &P.docSequential[ doc]) == 0) continue;
 			if (LANE == 0) atomicAdd( (unsigned long long*)&P.counters[ L1C_SEQDOCS], 1ull);
 			u0 = ldu( &P.unitStart[ doc]); u1 = ldu( &P.unitStart[ doc+1]);
 		}
-		else if (FULL && chunked)
+		else if (CH && chunked)
 		{
 			u32 lo = 0, hi = P.ndocs;			// last document whose first unit is <= unit
 			while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (ldu( &P.unitStart[ mid]) <= unit) lo = mid; else hi = mid; }
@@ -1372,7 +1372,7 @@ __device__ void scanDocuments( const L1Params& P)
 		docBounds( P, doc, beg, end);
 		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
 		u32 segBeg = 0, segEnd = w.docLen;
-		if (FULL && chunked && !P.sequentialPass)
+		if (CH && chunked && !P.sequentialPass)
 		{
 			segBeg = (unit - ldu( &P.unitStart[ doc])) * P.chunkBytes;
 			segEnd = (w.docLen - segBeg) < P.chunkBytes ? w.docLen : segBeg + P.chunkBytes;
@@ -1381,7 +1381,7 @@ __device__ void scanDocuments( const L1Params& P)
 		w.queue = P.reportQueue + 4*qb;
 		w.queueCap = (u32)(queueBase( P, beg + segEnd, u1) - qb);
 		w.nQueue = 0; w.err = 0;
-		scanDocument<PASSES,LDS,FULL,FULL>( w, P, T, segBeg, segEnd);
+		scanDocument<PASSES,LDS,CP,CH>( w, P, T, segBeg, segEnd);
 		if (LANE == 0)
 		{
 			if (w.err == L1D_CHUNK_UNPROVEN) { P.docSequential[ doc] = 1; P.reportCount[ u0] = 0; }
@@ -1397,12 +1397,12 @@ __device__ void scanDocuments( const L1Params& P)
 }
 
 // POST: literals, start of match, handler, ordinal positions, lexems
-template <bool LDS, bool CP>
+template <bool LDS, bool CP, bool CH>
 __device__ void postDocuments( const L1Params& P)
 {
-	// (CP: the instance for batches with classes by code point or chunked documents, see scanDocuments)
+	// (the same three sets of instances as the scan kernel's)
 	const u32 chunked = ldu( (const u32*)&P.counters[ L1C_CHUNKED]);
-	if (CP != (P.cpBlocks != 0 || chunked != 0)) return;
+	if (CP != (P.cpBlocks != 0) || (!CP && CH != (chunked != 0))) return;
 	LexTab<LDS> T;
 	stageTables( P, T);
 	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -1438,11 +1438,11 @@ __device__ void postDocuments( const L1Params& P)
 		w.unitEnd = chunked ? ldu( &P.unitStart[ doc+1]) : doc + 1u;
 		w.unit = w.unit0;
 		sliceOf( w, P);
-		if (CP && !w.nQueue) (void)nextSlice( w, P);
+		if (CH && !w.nQueue) (void)nextSlice( w, P);
 		w.queueCap = w.nQueue; w.nEvents = 0; w.err = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
 		w.e.id = 0; w.e.pos = 0; w.e.size = 0; w.e.lb = 0;
 		const u64 tDoc = PROF_T();
-		postDocument<LDS,CP>( w, P, T);
+		postDocument<LDS,CP,CH>( w, P, T);
 		spillLanes( w, 0);
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		if (!w.err) emitLexems( w, P, doc);
@@ -1467,8 +1467,9 @@ __device__ void postDocuments( const L1Params& P)
 // (a second set, _cp, for batches with classes by code point -- \\p{..} sets, UCP -- or with documents scanned in chunks: the
 // plain set pays nothing for either)
 #define SPA_L1_KERNEL( NAME, N, T) \
-extern "C" __global__ __launch_bounds__(T) void spa_l1_scan_kernel_##NAME( L1Params P) { if (P.ldsWords) scanDocuments<N,true,false>( P); else scanDocuments<N,false,false>( P); } \
-extern "C" __global__ __launch_bounds__(T) void spa_l1_scan_kernel_##NAME##_cp( L1Params P) { if (P.ldsWords) scanDocuments<N,true,true>( P); else scanDocuments<N,false,true>( P); }
+extern "C" __global__ __launch_bounds__(T) void spa_l1_scan_kernel_##NAME( L1Params P) { if (P.ldsWords) scanDocuments<N,true,false,false>( P); else scanDocuments<N,false,false,false>( P); } \
+extern "C" __global__ __launch_bounds__(T) void spa_l1_scan_kernel_##NAME##_ch( L1Params P) { if (P.ldsWords) scanDocuments<N,true,false,true>( P); else scanDocuments<N,false,false,true>( P); } \
+extern "C" __global__ __launch_bounds__(T) void spa_l1_scan_kernel_##NAME##_cp( L1Params P) { if (P.ldsWords) scanDocuments<N,true,true,true>( P); else scanDocuments<N,false,true,true>( P); }
 SPA_L1_KERNEL( p1, 1, 1024)
 SPA_L1_KERNEL( p2, 2, 1024)
 SPA_L1_KERNEL( p3, 3, 1024)
@@ -1491,8 +1492,9 @@ enum {POST_WAVES=4};
 #define SPA_L1_POST_WAVES_PER_EU 6
 #endif
 #define SPA_L1_POST_OCC __attribute__((amdgpu_waves_per_eu( SPA_L1_POST_WAVES_PER_EU, SPA_L1_POST_WAVES_PER_EU)))
-extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel( L1Params P) { postDocuments<false,false>( P); }
-extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel_cp( L1Params P) { postDocuments<false,true>( P); }
+extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel( L1Params P) { postDocuments<false,false,false>( P); }
+extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel_ch( L1Params P) { postDocuments<false,false,true>( P); }
+extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel_cp( L1Params P) { postDocuments<false,true,true>( P); }
 
 namespace spa {
 hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels)
@@ -1517,9 +1519,8 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 	if (lds > 65536) { e = hipFuncSetAttribute( (const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
 	hipLaunchKernelGGL( KERNEL, dim3( nblocks), dim3( nthreads), lds, stream, ARGS); } while (0)
 #define SPA_L1_LAUNCH( N) do { \
-	if (!P.cpBlocks) SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N, P); \
-	SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, P); \
-	SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, S); } while (0)
+	if (P.cpBlocks) { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, P); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, S); } \
+	else { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N, P); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, P); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, S); } } while (0)
 	switch (P.nofPasses)
 	{
 		case 1: SPA_L1_LAUNCH( p1); break;
@@ -1539,8 +1540,12 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 	if (e != hipSuccess) return e;
 	if (betweenKernels) { e = hipEventRecord( betweenKernels, stream); if (e != hipSuccess) return e; }
 	// its own number of waves (one event array each), in workgroups of POST_WAVES
-	if (!P.cpBlocks) hipLaunchKernelGGL( spa_l1_post_kernel, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
-	hipLaunchKernelGGL( spa_l1_post_kernel_cp, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
+	if (P.cpBlocks) hipLaunchKernelGGL( spa_l1_post_kernel_cp, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
+	else
+	{
+		hipLaunchKernelGGL( spa_l1_post_kernel, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
+		hipLaunchKernelGGL( spa_l1_post_kernel_ch, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
+	}
 	return hipGetLastError();
 }
 }
