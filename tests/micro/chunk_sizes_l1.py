@@ -2,7 +2,7 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 import struspattern_amd as spa
 from struspattern_amd import synth
-ndocs=4096
+ndocs=int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 vocab = synth.vocabulary(30000, 1)
 pats = synth.lexer_patterns(10000, vocab, 1)
 text, offs = synth.text_documents(ndocs, 65536, vocab, 2)

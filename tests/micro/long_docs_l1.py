@@ -1,4 +1,4 @@
-# lexer on a batch of few long documents: scan in chunks (default) vs one wave per document (SPA_L1_CHUNK_BYTES = 1 GiB)
+# lexer on a batch of few long documents: scan in chunks (default, 32 KiB) vs one wave per document (SPA_L1_CHUNK_BYTES = 1 GiB)
 import os, sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 import struspattern_amd as spa
@@ -24,4 +24,4 @@ for chunk in ("1073741824", None):
         a, b = ctx.lastKernelMsSplit()
         best = (a, b) if best is None or a + b < sum(best) else best
     print("%s: %d docs x %.1f MB: scan %.1f ms post %.1f ms, %d units, %d documents scanned again, %d lexems" % (
-        "one wave per document" if chunk else "64 KiB chunks", ndocs, docbytes/1e6, best[0], best[1], c["scan_units"], c["rescanned_docs"], c["lexems"]), flush=True)
+        "one wave per document" if chunk else "32 KiB chunks", ndocs, docbytes/1e6, best[0], best[1], c["scan_units"], c["rescanned_docs"], c["lexems"]), flush=True)

@@ -122,7 +122,7 @@ def test_approximate_table_survives_invalid_utf8():
 
 
 def test_long_documents_are_scanned_in_chunks(monkeypatch):
-    """A document longer than a chunk (64 KiB) is scanned as several units by several waves: the state at the start of a
+    """A document longer than a chunk (32 KiB) is scanned as several units by several waves: the state at the start of a
     later chunk is proven from a 256-byte warm-up (from the empty state with starts injected vs. from "every position
     live" without), and a document where that proof fails -- a pattern whose state survives the warm-up -- is scanned
     again in one piece.  Lexems must not depend on where the chunks fall."""
@@ -147,7 +147,7 @@ def test_long_documents_are_scanned_in_chunks(monkeypatch):
     ctx = lx.createContext()
     got = ctx.matchDocs(b"".join(docs), offs)
     c = ctx.batchCounters()
-    assert c["scan_units"] == sum(max(1, -(-len(d) // 65536)) for d in docs) and c["rescanned_docs"] == 0
+    assert c["scan_units"] == sum(max(1, -(-len(d) // 32768)) for d in docs) and c["rescanned_docs"] == 0
     for di, d in enumerate(docs):
         assert got.doc(di).tolist() == o.match(d).tolist(), (di, len(d))
     # every chunk boundary position: 64-byte chunks over short documents, including inside multi-byte characters and words
