@@ -23,7 +23,7 @@ def test_module_exports_reference_symbols():
     assert "createPatternLexer_std" in out and "createPatternMatcher_std" in out   # include/strus/lib/pattern.hpp:27-32
 
 
-def _write_fixtures(tmp):
+def _write_fixtures(tmp, regex_case=0):
     case = l2_cases.load("simple_token_pattern_match.json")
     simple = os.path.join(tmp, "simple.txt")
     with open(simple, "w") as f:
@@ -33,9 +33,9 @@ def _write_fixtures(tmp):
                 f.write("EXPECT\t%s\t%d\n" % (r["name"], p))
         for lx in l2_cases.simple_doc(case):
             f.write("DOC\t%d\t%d\t%d\n" % (lx[0], lx[1], lx[3]))
-    rc = l1_cases.load_char_regex_cases()[0]
+    rc = l1_cases.load_char_regex_cases()[regex_case]
     regex = os.path.join(tmp, "regex.txt")
-    with open(regex, "w") as f:
+    with open(regex, "w", encoding="utf8") as f:
         f.write("OPTION\tDOTALL\n")
         for pid, expr, residx, level, haspos in rc["patterns"]:
             f.write("LEXEM\t%d\t%s\t%d\t%d\t%d\n" % (pid, expr, residx, level, int(haspos)))
@@ -48,9 +48,10 @@ def _write_fixtures(tmp):
 
 
 @pytest.mark.gpu
-def test_reference_known_answer_tests_through_the_cpp_interfaces(tmp_path):
+@pytest.mark.parametrize("regex_case", [0, 1, 2])     # charRegexMatch case 1 (36 lexems), cases 2 and 3 (`abc ~1`, ASCII and UTF-8)
+def test_reference_known_answer_tests_through_the_cpp_interfaces(tmp_path, regex_case):
     lib, module, testbin = _built()
-    simple, regex = _write_fixtures(str(tmp_path))
+    simple, regex = _write_fixtures(str(tmp_path), regex_case)
     p = subprocess.run([testbin, simple, regex, module], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
     assert p.stdout.strip() == "OK"
