@@ -119,7 +119,7 @@ struct sp_matcher_ctx
 	std::vector<uint32_t> curOrigseg; bool curHasSeg;
 	sp_matcher_stats_t lastStats;
 
-	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),fast(false),fastWaves(0),fastBlocksPerCU(0),fastVariant(1),fastMaxRules(2048),fastMaxStaged(32768),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
+	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),fast(false),fastWaves(0),fastBlocksPerCU(0),fastVariant(4),fastMaxRules(2048),fastMaxStaged(32768),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
 		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
@@ -282,7 +282,7 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 				c->dKeyinst.upload( ki.data(), ki.size()*sizeof(FastKeyInst));
 				c->fastKeyinst.swap( ki);
 				// SPA_L2_FAST_SIZE=s|m|l picks the kernel instance (LDS capacities; t = the tiny one of the tests); the spill area takes what does not fit
-				if (const char* e = getenv( "SPA_L2_FAST_SIZE")) c->fastVariant = (e[0] == 's') ? 0u : (e[0] == 'l') ? 2u : (e[0] == 't') ? 3u : (e[0] == 'n') ? 4u : 1u;
+				if (const char* e = getenv( "SPA_L2_FAST_SIZE")) c->fastVariant = (e[0] == 's') ? 0u : (e[0] == 'm') ? 1u : (e[0] == 'l') ? 2u : (e[0] == 't') ? 3u : 4u;
 				if (const char* e = getenv( "SPA_L2_FAST_MAXRULES")) c->fastMaxRules = (uint32_t)atoi( e);
 				if (const char* e = getenv( "SPA_L2_FAST_MAXSTAGED")) c->fastMaxStaged = (uint32_t)atoi( e);
 				if (c->fastMaxRules > 4095) c->fastMaxRules = 4095;		// trigger ids are 14 bits (rule << 2 | slot)
