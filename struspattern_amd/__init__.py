@@ -206,6 +206,10 @@ class PatternMatcherContext:
     def lastKernelMs(self):
         return self._L.sp_matcher_ctx_last_kernel_ms(self._h)
 
+    def kernelKind(self):
+        """0 general automaton kernel, 1 LDS-resident kernel (flat rule sets), 2 join prototype (SPA_L2_JOIN=1)"""
+        return self._L.sp_matcher_ctx_kernel_kind(self._h)
+
 
 def _serialize(L, fn, handle, err):
     blob = ctypes.c_void_p()

@@ -4,6 +4,7 @@
 #include "l2_compile.hpp"
 #include "l2_device.h"
 #include "l2_fast.h"
+#include "l2_join.h"
 #include "hip_util.hpp"
 #include <hip/hip_runtime_api.h>
 #include <cstdlib>
@@ -21,6 +22,8 @@ hipError_t launchL2Fast( const FastParams& P, unsigned variant, unsigned nblocks
 int fastBlocksPerCU( unsigned variant);
 void fastCapacities( unsigned variant, uint32_t& R, uint32_t& T);
 std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out);
+std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab, std::vector<JoinRule>& rules, uint32_t& maxRange);
+hipError_t launchL2Join( const JoinParams& P, unsigned nwaves, hipStream_t stream);
 void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], uint32_t& expShift, const std::vector<FastKeyInst>& keyinst, uint32_t R, uint32_t T, uint32_t maxRules, uint32_t maxStaged);
 }
 
@@ -95,6 +98,8 @@ struct sp_matcher_ctx
 	bool fast;
 	std::string whyNotFast;
 	DeviceBuffer dKeyinst, dSpill, dFallbackList;
+	// join prototype (l2_join.h, opt-in by SPA_L2_JOIN=1): result sets without materialised rule instances
+	bool join; std::string whyNotJoin; uint32_t joinKeymask, joinMaxRange; DeviceBuffer dJoinKeytab, dJoinRules;
 	std::vector<FastKeyInst> fastKeyinst;
 	FastSpillLayout fastSpill; uint32_t fastBucketMeta[ 16]; uint32_t fastExpShift;
 	unsigned fastWaves, fastBlocksPerCU, fastVariant;	// variant: kernel instance = LDS capacities (l2_fast_kernel.hip)
@@ -119,7 +124,7 @@ struct sp_matcher_ctx
 	std::vector<uint32_t> curOrigseg; bool curHasSeg;
 	sp_matcher_stats_t lastStats;
 
-	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),fast(false),fastWaves(0),fastBlocksPerCU(0),fastVariant(4),fastMaxRules(2048),fastMaxStaged(32768),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
+	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),join(false),joinKeymask(0),joinMaxRange(0),fast(false),fastWaves(0),fastBlocksPerCU(0),fastVariant(4),fastMaxRules(2048),fastMaxStaged(32768),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
 		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
@@ -180,6 +185,9 @@ const char* sp_matcher_variable_name( const sp_matcher_t* m, uint32_t variable) 
 
 uint32_t sp_matcher_format_count( const sp_matcher_t* m) { return m->compiler.formatCount(); }
 const char* sp_matcher_format_string( const sp_matcher_t* m, uint32_t format_handle) { return m->compiler.formatString( format_handle); }
+
+// which kernel the context's batches run on: 0 = general, 1 = LDS-resident (flat rule sets), 2 = join prototype (SPA_L2_JOIN=1)
+int sp_matcher_ctx_kernel_kind( const sp_matcher_ctx_t* c) { return c->join ? 2 : c->fast ? 1 : 0; }
 
 // 1 when the compiled rule set is flat (l2_fast.h) and runs on the LDS-resident kernel, else 0 with the reason
 int sp_matcher_fast_tier( const sp_matcher_t* m, char* why, size_t whysize)
@@ -288,6 +296,21 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 				if (c->fastMaxRules > 4095) c->fastMaxRules = 4095;		// trigger ids are 14 bits (rule << 2 | slot)
 			}
 			if (getenv( "SPA_L2_VERBOSE")) fprintf( stderr, "[spa] fast tier: %s\n", c->fast ? "on" : c->whyNotFast.c_str());
+		}
+		if (const char* e = getenv( "SPA_L2_JOIN"))
+		{
+			if (e[0] == '1')
+			{
+				std::vector<JoinKey> jk; std::vector<JoinRule> jr;
+				c->whyNotJoin = buildJoinTables( ft, jk, jr, c->joinMaxRange);
+				c->join = c->whyNotJoin.empty();
+				if (c->join)
+				{
+					c->dJoinKeytab.upload( jk.data(), jk.size()*sizeof(JoinKey)); c->dJoinRules.upload( jr.data(), jr.size()*sizeof(JoinRule));
+					c->joinKeymask = (uint32_t)jk.size()-1;
+				}
+				if (getenv( "SPA_L2_VERBOSE")) fprintf( stderr, "[spa] join prototype: %s\n", c->join ? "on" : c->whyNotJoin.c_str());
+			}
 		}
 		c->dCursor.alloc( 256);		// u32: [0] fast cursor, [1] general cursor (list mode), [2] hand-over count, [16..31] hand-over reasons, [32..47] phase profile (u64 x 8)
 		c->dCounters.alloc( SPC_COUNT*sizeof(uint64_t));
@@ -641,6 +664,20 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		P.docList = (const uint32_t*)c->dFallbackList.ptr; P.docListCount = (const uint32_t*)c->dCursor.ptr + 2;
 		P.docCursor = (uint32_t*)c->dCursor.ptr + 1;
 		HIP_CHECK( launchL2Match( P, nblocks, stream));
+	}
+	else if (c->join)
+	{
+		// opt-in prototype: result sets by joining positions, nothing installed (l2_join.h)
+		JoinParams J;
+		std::memset( &J, 0, sizeof(J));
+		J.keytab = (const JoinKey*)c->dJoinKeytab.ptr; J.keymask = c->joinKeymask; J.rules = (const JoinRule*)c->dJoinRules.ptr; J.maxRange = c->joinMaxRange;
+		J.lexems = P.lexems; J.origseg = P.origseg; J.docOffsets = P.docOffsets; J.docRangesIn = P.docRangesIn; J.ndocs = P.ndocs;
+		J.docCursor = (uint32_t*)c->dCursor.ptr;
+		J.counters = P.counters; J.results = P.results; J.resultCapacity = P.resultCapacity;
+		J.docRange = P.docRange; J.docStats = P.docStats; J.docStatus = P.docStatus;
+		J.withFormats = P.withFormats; J.resultFormat = P.resultFormat;
+		const size_t jslots = (size_t)c->numCUs * 32;		// one wave per document, no LDS, few registers
+		HIP_CHECK( launchL2Join( J, (unsigned)(ndocs < jslots ? (ndocs ? ndocs : 1) : jslots), stream));
 	}
 	else if (c->fast)
 	{

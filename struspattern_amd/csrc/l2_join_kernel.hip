@@ -1,0 +1,148 @@
+// PROTOTYPE of the non-materialising rule automaton (l2_join.h): lane-parallel over the lexems of a document, no state.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "l2_join.h"
+#include "l2_tables.h"
+#include "l2_device.h"
+#include "wave_scan.h"
+
+using namespace spa;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+namespace {
+#define LANE ((u32)(threadIdx.x & 63u))
+__device__ __forceinline__ u32 uni( u32 v) { return __builtin_amdgcn_readfirstlane( v); }
+
+// the matches that end at lexem j (lane-private loop over the lexems of the last maxRange positions); WRITE: store them
+// from `out` on, else count
+template <bool WRITE>
+__device__ __forceinline__ u32 matchesEndingAt( const JoinParams& P, const uint4* lex, const u32* seg, u32 j, uint4 lj, u32* out, u32* fmtOut)
+{
+	u32 cnt = 0;
+	const u32 e = lj.x;
+	if (!e) return 0;
+	u32 takenPos = 0;		// position of the latest occurrence of e seen so far: it has taken every instance that began at an earlier position
+	for (u32 i=j; i-- > 0;)
+	{
+		const uint4 li = lex[ i];
+		if (lj.y - li.y > P.maxRange) break;		// every instance that old has expired
+		if (takenPos > li.y) break;			// this one and all earlier ones were completed by that occurrence
+		if (li.x && lj.y > li.y)
+		{
+			u32 slot = joinHash( li.x, e) & P.keymask;
+			for (u32 probes=0; probes<=P.keymask; ++probes)
+			{
+				const JoinKey k = P.keytab[ slot];
+				if (!k.first) break;
+				if (k.first == li.x && k.second == e)
+				{
+					for (u32 r=0; r<k.count; ++r)
+					{
+						const JoinRule rule = P.rules[ k.begin + r];
+						if (lj.y - li.y > rule.range) continue;
+						if (WRITE)
+						{
+							u32* o = out + 9*(u64)cnt;
+							o[0] = rule.resultHandle; o[1] = li.y; o[2] = lj.y + 1u; o[3] = seg ? seg[ i] : 0u; o[4] = li.z;
+							o[5] = seg ? seg[ j] : 0u; o[6] = lj.z + lj.w; o[7] = 0; o[8] = 0;
+							if (fmtOut) fmtOut[ cnt] = rule.formatHandle;
+						}
+						++cnt;
+					}
+					break;
+				}
+				slot = (slot+1) & P.keymask;
+			}
+		}
+		if (li.x == e && li.y > takenPos) takenPos = li.y;
+	}
+	return cnt;
+}
+
+__device__ void joinDocuments( const JoinParams& P)
+{
+	for (u32 round=0; round<=P.ndocs; ++round)
+	{
+		u32 doc = 0;
+		if (LANE == 0) doc = atomicAdd( P.docCursor, 1u);
+		doc = uni( doc);
+		if (doc >= P.ndocs) break;
+		u64 beg, n64;
+		if (P.docRangesIn) { beg = P.docRangesIn[ 2*(u64)doc]; n64 = P.docRangesIn[ 2*(u64)doc+1]; }
+		else { beg = P.docOffsets[ doc]; n64 = P.docOffsets[ doc+1] - beg; }
+		beg = ((u64)uni( (u32)(beg >> 32)) << 32) | uni( (u32)beg);
+		const u32 n = uni( (u32)n64);
+		const uint4* lex = (const uint4*)P.lexems + beg;
+		const u32* seg = P.origseg ? P.origseg + beg : 0;
+		u32 err = 0;
+		if (n64 >= (1ull << 32)) err = SPD_ERR_RANGE;
+		// checks of putInput (patternMatcher.cpp:131-162), the matches counted
+		u32 total = 0;
+		if (!err)
+		{
+			bool bad = false, order = false;
+			for (u32 base=0; base<n; base+=64)
+			{
+				const u32 j = base + LANE;
+				u32 c = 0;
+				if (j < n)
+				{
+					const uint4 lj = lex[ j];
+					if (lj.x >= (1u<<29) || lj.z >= 0x7FFFFFFFu || lj.w >= 0x7FFFFFFFu) bad = true;
+					if (j + 1 < n && lex[ j+1].y < lj.y) order = true;
+					c = matchesEndingAt<false>( P, lex, seg, j, lj, 0, 0);
+				}
+				const u32 incl = waveScanAdd( c);
+				total += uni( (u32)__shfl( (int)incl, 63));
+			}
+			if (__ballot( order)) err = SPD_ERR_ORDER; else if (__ballot( bad)) err = SPD_ERR_RANGE;
+		}
+		u64 resBase = 0;
+		if (!err && total)
+		{
+			u64 b = 0;
+			if (LANE == 0) b = atomicAdd( (unsigned long long*)&P.counters[ SPC_RESULTS], (unsigned long long)total);
+			resBase = ((u64)uni( (u32)(b >> 32)) << 32) | uni( (u32)b);
+			if (resBase + total > P.resultCapacity) { err = SPD_ERR_OUTPUT; total = 0; }
+		}
+		if (!err && total)
+		{
+			u32 at = 0;
+			for (u32 base=0; base<n; base+=64)
+			{
+				const u32 j = base + LANE;
+				uint4 lj = make_uint4( 0, 0, 0, 0);
+				u32 c = 0;
+				if (j < n) { lj = lex[ j]; c = matchesEndingAt<false>( P, lex, seg, j, lj, 0, 0); }
+				const u32 incl = waveScanAdd( c);
+				if (c)
+				{
+					const u64 mine = resBase + at + incl - c;
+					(void)matchesEndingAt<true>( P, lex, seg, j, lj, P.results + 9*mine, P.withFormats ? P.resultFormat + mine : 0);
+				}
+				at += uni( (u32)__shfl( (int)incl, 63));
+			}
+		}
+		if (LANE == 0)
+		{
+			P.docRange[ 2*(u64)doc] = resBase; P.docRange[ 2*(u64)doc+1] = err ? 0 : total;
+			u64* st = P.docStats + 4*(u64)doc;
+			st[0] = 0; st[1] = 0; st[2] = 0; st[3] = 0;
+			P.docStatus[ doc] = (int32_t)err;
+			atomicAdd( (unsigned long long*)&P.counters[ SPC_EVENTS], (unsigned long long)(err ? 0 : n));
+			if (err) atomicAdd( (unsigned long long*)&P.counters[ SPC_FAILED], 1ull);
+		}
+	}
+}
+} // anonymous namespace
+
+extern "C" __global__ __launch_bounds__(256) void spa_l2_join_kernel( JoinParams P) { joinDocuments( P); }
+
+namespace spa {
+hipError_t launchL2Join( const JoinParams& P, unsigned nwaves, hipStream_t stream)
+{
+	hipLaunchKernelGGL( spa_l2_join_kernel, dim3( (nwaves + 3) / 4), dim3( 256), 0, stream, P);
+	return hipGetLastError();
+}
+}

@@ -1,0 +1,67 @@
+"""The opt-in join prototype of the rule automaton (csrc/l2_join.h, SPA_L2_JOIN=1): two-term sequence rule sets
+evaluated without materialised rule instances.  It reproduces the reference's result SETS per document, not the order
+of the results inside a document and not the statistics -- so this test compares sorted result tuples with the
+oracle (unoptimized automaton), and checks that the default engine is untouched by the switch."""
+import numpy as np
+import pytest
+
+import oracle
+import struspattern_amd as spa
+from struspattern_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _docs(rng, ndocs, n, nfeat, shared_positions):
+    lex = np.zeros((ndocs * n, 4), np.uint32)
+    offs = np.arange(ndocs + 1, dtype=np.uint64) * n
+    for d in range(ndocs):
+        ids = rng.integers(1, nfeat + 1, size=n)
+        pos = np.arange(1, n + 1)
+        if shared_positions:
+            pos = np.cumsum(rng.random(n) < 0.7) + 1          # several lexems on one position
+        lex[d * n:(d + 1) * n, 0] = ids
+        lex[d * n:(d + 1) * n, 1] = pos
+        lex[d * n:(d + 1) * n, 2] = np.arange(n) * 3
+        lex[d * n:(d + 1) * n, 3] = 2
+    return lex, offs
+
+
+def _sorted_results(batch, d):
+    r = batch.doc(d)[:, :7] if hasattr(batch, "doc") else None
+    return sorted(map(tuple, r.tolist()))
+
+
+@pytest.mark.parametrize("seed,nrules,nfeat,n,shared", [(1, 50, 8, 300, False), (2, 400, 30, 500, True), (3, 3000, 200, 1000, True), (4, 20, 3, 200, True)])
+def test_join_prototype_result_sets(monkeypatch, seed, nrules, nfeat, n, shared):
+    rng = np.random.default_rng(100 + seed)
+    rules = synth.random_rules(nrules, nfeat, seed, op="sequence")
+    monkeypatch.setenv("SPA_L2_JOIN", "1")
+    m = spa.PatternMatcherInstance()
+    synth.apply_rules(m, rules, compile=False)        # (not optimized: no alternative keys)
+    ctx = m.createContext()
+    assert ctx.kernelKind() == 2
+    monkeypatch.delenv("SPA_L2_JOIN")
+    o = oracle.L2Matcher()
+    synth.apply_rules(o, rules, compile=False)
+    ndocs = 24
+    lex, offs = _docs(rng, ndocs, n, nfeat, shared)
+    got = ctx.matchDocs(lex, offs)
+    ref = o.run(synth.lexems5(lex), offs)
+    assert np.array_equal(got.doc_offsets, ref.doc_offsets)
+    total = 0
+    for d in range(ndocs):
+        a = sorted(map(tuple, got.results[got.doc_offsets[d]:got.doc_offsets[d + 1], :7].tolist()))
+        b = sorted(map(tuple, ref.results[ref.doc_offsets[d]:ref.doc_offsets[d + 1], :7].tolist()))
+        assert a == b, (d, len(a), len(b))
+        total += len(a)
+    assert total > 100
+    # the same instance without the switch runs the exact engine
+    assert m.createContext().kernelKind() == 1
+
+
+def test_join_prototype_takes_two_term_sequences_only(monkeypatch):
+    monkeypatch.setenv("SPA_L2_JOIN", "1")
+    m = spa.PatternMatcherInstance()
+    synth.apply_rules(m, synth.random_rules(20, 5, 1))          # 5-operator mix
+    assert m.createContext().kernelKind() != 2
