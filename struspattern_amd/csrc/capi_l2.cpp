@@ -22,7 +22,7 @@ hipError_t launchL2Fast( const FastParams& P, unsigned variant, unsigned nblocks
 int fastBlocksPerCU( unsigned variant);
 void fastCapacities( unsigned variant, uint32_t& R, uint32_t& T);
 std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out);
-std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab, std::vector<JoinRule>& rules, uint32_t& maxRange);
+std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab, std::vector<JoinRule>& rules, uint32_t& maxRange, uint32_t& delimiter);
 hipError_t launchL2Join( const JoinParams& P, unsigned nwaves, hipStream_t stream);
 void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], uint32_t& expShift, const std::vector<FastKeyInst>& keyinst, uint32_t R, uint32_t T, uint32_t maxRules, uint32_t maxStaged);
 }
@@ -99,7 +99,7 @@ struct sp_matcher_ctx
 	std::string whyNotFast;
 	DeviceBuffer dKeyinst, dSpill, dFallbackList;
 	// join prototype (l2_join.h, opt-in by SPA_L2_JOIN=1): result sets without materialised rule instances
-	bool join; std::string whyNotJoin; uint32_t joinKeymask, joinMaxRange; DeviceBuffer dJoinKeytab, dJoinRules;
+	bool join; std::string whyNotJoin; uint32_t joinKeymask, joinMaxRange, joinDelimiter; DeviceBuffer dJoinKeytab, dJoinRules;
 	std::vector<FastKeyInst> fastKeyinst;
 	FastSpillLayout fastSpill; uint32_t fastBucketMeta[ 16]; uint32_t fastExpShift;
 	unsigned fastWaves, fastBlocksPerCU, fastVariant;	// variant: kernel instance = LDS capacities (l2_fast_kernel.hip)
@@ -124,7 +124,7 @@ struct sp_matcher_ctx
 	std::vector<uint32_t> curOrigseg; bool curHasSeg;
 	sp_matcher_stats_t lastStats;
 
-	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),join(false),joinKeymask(0),joinMaxRange(0),fast(false),fastWaves(0),fastBlocksPerCU(0),fastVariant(4),fastMaxRules(2048),fastMaxStaged(32768),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
+	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),join(false),joinKeymask(0),joinMaxRange(0),joinDelimiter(0),fast(false),fastWaves(0),fastBlocksPerCU(0),fastVariant(4),fastMaxRules(2048),fastMaxStaged(32768),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
 		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
@@ -302,7 +302,7 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 			if (e[0] == '1')
 			{
 				std::vector<JoinKey> jk; std::vector<JoinRule> jr;
-				c->whyNotJoin = buildJoinTables( ft, jk, jr, c->joinMaxRange);
+				c->whyNotJoin = buildJoinTables( ft, jk, jr, c->joinMaxRange, c->joinDelimiter);
 				c->join = c->whyNotJoin.empty();
 				if (c->join)
 				{
@@ -670,7 +670,7 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		// opt-in prototype: result sets by joining positions, nothing installed (l2_join.h)
 		JoinParams J;
 		std::memset( &J, 0, sizeof(J));
-		J.keytab = (const JoinKey*)c->dJoinKeytab.ptr; J.keymask = c->joinKeymask; J.rules = (const JoinRule*)c->dJoinRules.ptr; J.maxRange = c->joinMaxRange;
+		J.keytab = (const JoinKey*)c->dJoinKeytab.ptr; J.keymask = c->joinKeymask; J.rules = (const JoinRule*)c->dJoinRules.ptr; J.maxRange = c->joinMaxRange; J.delimiter = c->joinDelimiter;
 		J.lexems = P.lexems; J.origseg = P.origseg; J.docOffsets = P.docOffsets; J.docRangesIn = P.docRangesIn; J.ndocs = P.ndocs;
 		J.docCursor = (uint32_t*)c->dCursor.ptr;
 		J.counters = P.counters; J.results = P.results; J.resultCapacity = P.resultCapacity;

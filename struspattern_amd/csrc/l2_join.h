@@ -24,12 +24,14 @@ struct JoinKey			// 16 B, open addressing by joinHash( first, second), first==0 
 	uint32_t begin;		// rules[begin .. begin+count), definition order
 	uint32_t count;
 };
+enum {JOIN_SELF=0xFFFFFFFFu};		// `first` of the entries for any( .. ): the lexem alone is the match
+enum {JOIN_STRUCT=1u};			// JoinRule::flags: no delimiter lexem may lie between the two terms (*_struct)
 struct JoinRule			// 16 B
 {
 	uint32_t range;
 	uint32_t resultHandle;
 	uint32_t formatHandle;
-	uint32_t _pad;
+	uint32_t flags;
 };
 static inline
 #if defined(__HIPCC__)
@@ -47,6 +49,7 @@ struct JoinParams
 	const JoinKey* keytab; uint32_t keymask;
 	const JoinRule* rules;
 	uint32_t maxRange;		// the largest position range of any program
+	uint32_t delimiter;		// the delimiter event of the *_struct programs (0 = none)
 	const uint32_t* lexems;		// sp_lexem_t[]: id, ordpos, origpos, origsize
 	const uint32_t* origseg;	// optional
 	const uint64_t* docOffsets;	// ndocs+1 lexem indices, or NULL when docRangesIn is given

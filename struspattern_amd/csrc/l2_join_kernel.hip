@@ -22,7 +22,34 @@ __device__ __forceinline__ u32 matchesEndingAt( const JoinParams& P, const uint4
 	u32 cnt = 0;
 	const u32 e = lj.x;
 	if (!e) return 0;
+	// any( .., e, .. ): the lexem alone
+	{
+		u32 slot = joinHash( JOIN_SELF, e) & P.keymask;
+		for (u32 probes=0; probes<=P.keymask; ++probes)
+		{
+			const JoinKey k = P.keytab[ slot];
+			if (!k.first) break;
+			if (k.first == (u32)JOIN_SELF && k.second == e)
+			{
+				for (u32 r=0; r<k.count; ++r)
+				{
+					if (WRITE)
+					{
+						const JoinRule rule = P.rules[ k.begin + r];
+						u32* o = out + 9*(u64)cnt;
+						o[0] = rule.resultHandle; o[1] = lj.y; o[2] = lj.y + 1u; o[3] = seg ? seg[ j] : 0u; o[4] = lj.z;
+						o[5] = o[3]; o[6] = lj.z + lj.w; o[7] = 0; o[8] = 0;
+						if (fmtOut) fmtOut[ cnt] = rule.formatHandle;
+					}
+					++cnt;
+				}
+				break;
+			}
+			slot = (slot+1) & P.keymask;
+		}
+	}
 	u32 takenPos = 0;		// position of the latest occurrence of e seen so far: it has taken every instance that began at an earlier position
+	bool delimited = false;		// a delimiter lexem lies between i and j
 	for (u32 i=j; i-- > 0;)
 	{
 		const uint4 li = lex[ i];
@@ -40,7 +67,7 @@ __device__ __forceinline__ u32 matchesEndingAt( const JoinParams& P, const uint4
 					for (u32 r=0; r<k.count; ++r)
 					{
 						const JoinRule rule = P.rules[ k.begin + r];
-						if (lj.y - li.y > rule.range) continue;
+						if (lj.y - li.y > rule.range || (delimited && (rule.flags & JOIN_STRUCT))) continue;
 						if (WRITE)
 						{
 							u32* o = out + 9*(u64)cnt;
@@ -56,6 +83,7 @@ __device__ __forceinline__ u32 matchesEndingAt( const JoinParams& P, const uint4
 			}
 		}
 		if (li.x == e && li.y > takenPos) takenPos = li.y;
+		if (P.delimiter && li.x == P.delimiter) delimited = true;
 	}
 	return cnt;
 }

@@ -9,11 +9,10 @@
 namespace spa {
 
 // returns the reason why the rule set cannot run in join mode (empty = it can)
-std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab, std::vector<JoinRule>& rules, uint32_t& maxRange)
+std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab, std::vector<JoinRule>& rules, uint32_t& maxRange, uint32_t& delimiter)
 {
 	std::map<std::pair<uint32_t,uint32_t>,std::vector<JoinRule> > byPair;
-	maxRange = 0;
-	for (size_t ki=0; ki<ft.keylist.size(); ++ki) if (ft.keylist[ ki].pastEvent) return "a program with an alternative key (compile without optimize)";
+	maxRange = 0; delimiter = 0;
 	std::set<uint32_t> listened;
 	for (size_t i=0; i<ft.trigdefs.size(); ++i) listened.insert( ft.trigdefs[ i].event);
 	for (size_t pi=0; pi<ft.programs.size(); ++pi)
@@ -21,19 +20,53 @@ std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab,
 		const DevProgram& p = ft.programs[ pi];
 		if (p.event && listened.count( p.event)) return "a program whose result another program listens to";
 		if (!p.resultHandle) return "a program without result";
-		if (p.trigCount != 2 || p.initsigval != 2 || p.initcount != 2) return "a program that is not a two-term sequence";
-		uint32_t first = 0, second = 0;
-		for (uint32_t t=0; t<2; ++t)
+	}
+	for (size_t pi=0; pi<ft.programs.size(); ++pi)
+	{
+		const DevProgram& p = ft.programs[ pi];
+		// the two terms and the delimiter of the program.  Which of the terms the optimizer made the key does not matter here:
+		// the entries follow the program's meaning -- sequence: first term -> second; within: either way round; any: each term
+		// alone -- which is what the key lists of the unoptimized automaton give (a program with two equal terms counts twice
+		// there, and twice here).
+		const DevTrigDef* term[ 2] = {0, 0}; const DevTrigDef* del = 0;
+		unsigned nterm = 0;
+		for (uint32_t t=0; t<p.trigCount; ++t)
 		{
 			const DevTrigDef& td = ft.trigdefs[ p.trigBegin + t];
-			if ((td.flags & 0xF) != SIG_SEQUENCE) return "a program that is not a plain two-term sequence";	// (variables are accepted, captured items are not produced)
-			if (td.sigval == 2 && (td.flags & 0x100)) first = td.event;
-			else if (td.sigval == 1 && !(td.flags & 0x100)) second = td.event;
+			if ((td.flags & 0xF) == SIG_DEL) { if (del) return "a program with two delimiters"; del = &td; }
+			else { if (nterm == 2) return "a program with more than two terms"; term[ nterm++] = &td; }
 		}
-		if (!first || !second) return "a program that is not a plain two-term sequence";
-		JoinRule r; r.range = p.positionRange; r.resultHandle = p.resultHandle; r.formatHandle = p.formatHandle; r._pad = 0;
+		if (nterm != 2) return "a program that has not two terms";
+		const uint32_t sigtype = term[ 0]->flags & 0xF;
+		if ((term[ 1]->flags & 0xF) != sigtype) return "a program with mixed signals";
+		JoinRule r; r.range = p.positionRange; r.resultHandle = p.resultHandle; r.formatHandle = p.formatHandle; r.flags = 0;
+		if (del)
+		{
+			if (delimiter && delimiter != del->event) return "more than one delimiter event";
+			delimiter = del->event; r.flags |= JOIN_STRUCT;
+			if (term[ 0]->event == delimiter || term[ 1]->event == delimiter) return "the delimiter as a term";
+		}
 		if (r.range > maxRange) maxRange = r.range;
-		byPair[ std::make_pair( first, second)].push_back( r);
+		if (sigtype == SIG_ANY)
+		{
+			if (p.initcount != 1 || del) return "an `any` program with a cardinality or a delimiter";
+			byPair[ std::make_pair( (uint32_t)JOIN_SELF, term[ 0]->event)].push_back( r);
+			byPair[ std::make_pair( (uint32_t)JOIN_SELF, term[ 1]->event)].push_back( r);
+		}
+		else if (sigtype == SIG_SEQUENCE)
+		{
+			if (p.initcount != 2 || p.initsigval != 2) return "a sequence with a cardinality";
+			const int first = term[ 0]->sigval == 2 ? 0 : 1;
+			if (term[ first]->sigval != 2 || term[ 1-first]->sigval != 1) return "a sequence with unexpected signal values";
+			byPair[ std::make_pair( term[ first]->event, term[ 1-first]->event)].push_back( r);
+		}
+		else if (sigtype == SIG_WITHIN)
+		{
+			if (p.initcount != 2) return "a within with a cardinality";
+			byPair[ std::make_pair( term[ 0]->event, term[ 1]->event)].push_back( r);
+			byPair[ std::make_pair( term[ 1]->event, term[ 0]->event)].push_back( r);
+		}
+		else return "a program that is neither sequence, within nor any";
 	}
 	if (byPair.empty()) return "no program";
 	size_t size = 1;

@@ -1,16 +1,18 @@
 # the join prototype (SPA_L2_JOIN=1, csrc/l2_join.h) beside the exact engine on the sequence-only automaton workload:
-# 10k two-term sequence rules (not optimized) x 1000-token documents; result counts must agree
+# 10k two-term rules (sequence only, or the 5-operator mix: `mix` as second argument) x 1000-token documents (exact engine:
+# optimized automaton as in bench.py; its result count may differ by the optimizer's alternative keys, ~0.02 %)
 import os, sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 import struspattern_amd as spa
 from struspattern_amd import synth
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 12288
-rules = synth.random_rules(10000, 10000, 2, "sequence")
+op = None if len(sys.argv) > 2 and sys.argv[2] == "mix" else "sequence"
+rules = synth.random_rules(10000, 10000, 2, op)
 lex, offs = synth.random_documents(nd, 1000, 10000, 1000)
 d_lex = torch.from_numpy(lex.view(np.int32)).cuda(); d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
 for join in ("0", "1"):
     os.environ["SPA_L2_JOIN"] = join
-    m = spa.PatternMatcherInstance(); synth.apply_rules(m, rules, compile=False)
+    m = spa.PatternMatcherInstance(); synth.apply_rules(m, rules)
     ctx = m.createContext()
     best = None
     for it in range(14):

@@ -32,5 +32,5 @@ for size in (sys.argv[2].split(",") if len(sys.argv) > 2 else [os.environ.get("S
         ms = mctx.lastKernelMs()
         best = ms if best is None or ms < best else best
         if it >= 12: break
-    print("pipeline L2 size %s: %.1f ms, %d docs, %d events (%.1f M ev/s), %d results, handed over %d" % (
+    print("kernel kind %d;" % mctx.kernelKind(), "pipeline L2 size %s: %.1f ms, %d docs, %d events (%.1f M ev/s), %d results, handed over %d" % (
         size, best, nd, c["events"], c["events"]/best/1e3, c["results"], c["handed_over"]), flush=True)

@@ -1,5 +1,6 @@
-"""The opt-in join prototype of the rule automaton (csrc/l2_join.h, SPA_L2_JOIN=1): two-term sequence rule sets
-evaluated without materialised rule instances.  It reproduces the reference's result SETS per document, not the order
+"""The opt-in join prototype of the rule automaton (csrc/l2_join.h, SPA_L2_JOIN=1): two-term rule sets (sequence, within,
+sequence_struct, within_struct, any: the operators of the reference's randomTokenPatternMatch) evaluated without
+materialised rule instances.  It reproduces the reference's result SETS per document, not the order
 of the results inside a document and not the statistics -- so this test compares sorted result tuples with the
 oracle (unoptimized automaton), and checks that the default engine is untouched by the switch."""
 import numpy as np
@@ -17,6 +18,7 @@ def _docs(rng, ndocs, n, nfeat, shared_positions):
     offs = np.arange(ndocs + 1, dtype=np.uint64) * n
     for d in range(ndocs):
         ids = rng.integers(1, nfeat + 1, size=n)
+        ids[rng.random(n) < 0.06] = synth.DELIM
         pos = np.arange(1, n + 1)
         if shared_positions:
             pos = np.cumsum(rng.random(n) < 0.7) + 1          # several lexems on one position
@@ -32,10 +34,11 @@ def _sorted_results(batch, d):
     return sorted(map(tuple, r.tolist()))
 
 
+@pytest.mark.parametrize("op", ["sequence", "within", "sequence_struct", "within_struct", "any", None])
 @pytest.mark.parametrize("seed,nrules,nfeat,n,shared", [(1, 50, 8, 300, False), (2, 400, 30, 500, True), (3, 3000, 200, 1000, True), (4, 20, 3, 200, True)])
-def test_join_prototype_result_sets(monkeypatch, seed, nrules, nfeat, n, shared):
+def test_join_prototype_result_sets(monkeypatch, seed, nrules, nfeat, n, shared, op):
     rng = np.random.default_rng(100 + seed)
-    rules = synth.random_rules(nrules, nfeat, seed, op="sequence")
+    rules = synth.random_rules(nrules, nfeat, seed, op=op)
     monkeypatch.setenv("SPA_L2_JOIN", "1")
     m = spa.PatternMatcherInstance()
     synth.apply_rules(m, rules, compile=False)        # (not optimized: no alternative keys)
@@ -60,8 +63,10 @@ def test_join_prototype_result_sets(monkeypatch, seed, nrules, nfeat, n, shared)
     assert m.createContext().kernelKind() == 1
 
 
-def test_join_prototype_takes_two_term_sequences_only(monkeypatch):
+def test_join_prototype_leaves_other_rule_sets_to_the_exact_engine(monkeypatch):
     monkeypatch.setenv("SPA_L2_JOIN", "1")
     m = spa.PatternMatcherInstance()
-    synth.apply_rules(m, synth.random_rules(20, 5, 1))          # 5-operator mix
+    m.pushTerm(1); m.pushTerm(2); m.pushTerm(3)
+    m.pushExpression("sequence", 3, 10, 0)                       # three terms
+    m.definePattern("x", "", True)
     assert m.createContext().kernelKind() != 2
