@@ -225,6 +225,8 @@ def main():
             base, parity = cpu_baseline(args, wl, pats, rules, text, head, lex, lctx, mctx)
             out["cpu_baseline"] = base
             out["parity_sample"] = parity
+        if world == 1 and mctx is not None and not args.no_cpu_baseline:
+            out["canonical_order_mode"] = canonical_order_mode(wl, rules, head, d_lex if wl == "l2" else None, local_rank, m, nbytes)
         print(json.dumps(out))
         if out.get("parity_sample") and not out["parity_sample"]["ok"]:
             if world > 1:
@@ -322,6 +324,45 @@ def pmc_traffic(kernel_prefix, wl, args, kernel_ms):
     except (OSError, KeyError, ValueError):
         pass
     return None, None
+
+
+def canonical_order_mode(wl, rules, head, d_lex, local_rank, m, nbytes):
+    """NOT part of `value`: the rule stage of the same step on the opt-in join prototype (csrc/l2_join.h, SPA_L2_JOIN=1), which
+    yields the same result SETS without materialising rule instances but not the reference's order of the results inside a
+    document (tests/test_l2_join_gpu.py checks the sets against the oracle).  Reported beside the exact engine's time."""
+    try:
+        import torch
+        import struspattern_amd as spa
+        from struspattern_amd import synth
+        os.environ["SPA_L2_JOIN"] = "1"
+        mi = spa.PatternMatcherInstance()
+        synth.apply_rules(mi, rules)
+        jctx = mi.createContext(local_rank)
+        os.environ.pop("SPA_L2_JOIN", None)
+        if jctx.kernelKind() != 2:
+            return {"available": False}
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def run():
+            if wl == "l2":
+                jctx.matchDocsDevice(d_lex.data_ptr(), head.d_offs.data_ptr(), head.ndocs, head.nlexems, stream)
+            else:
+                jctx.matchLexedDevice(head.lex_out.d_lexems, head.lex_out.d_doc_ranges, head.ndocs, head.nlexems, stream)
+        c = size_until_ok(run, jctx.batchCounters, jctx.batchStatus,
+                          lambda c: jctx.reserveOutput(int(c["results"] * 1.2) + 1024, 1024), jctx.growArena, head.ndocs, "join prototype")
+        ms = []
+        for _ in range(3):
+            run()
+            ms.append(jctx.lastKernelMs())
+        l2 = float(np.mean(ms))
+        out = {"available": True, "l2_ms": l2, "events_per_s": c["events"] / (l2 * 1e-3), "results": int(c["results"]),
+               "results_of_the_exact_engine": m["results"], "note": "result sets only, order inside a document not the reference's; never part of `value`"}
+        if wl == "pipeline":
+            out["pipeline_GBps_with_it"] = nbytes / ((m["l1_ms"] + l2) * 1e-3) / 1e9
+        return out
+    except (Exception, SystemExit) as e:          # the line must not depend on the prototype
+        os.environ.pop("SPA_L2_JOIN", None)
+        return {"available": False, "error": str(e)[:200]}
 
 
 def first_difference(gl, gr, rl, rr):

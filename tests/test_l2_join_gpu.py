@@ -70,3 +70,29 @@ def test_join_prototype_leaves_other_rule_sets_to_the_exact_engine(monkeypatch):
     m.pushExpression("sequence", 3, 10, 0)                       # three terms
     m.definePattern("x", "", True)
     assert m.createContext().kernelKind() != 2
+
+
+def test_join_prototype_on_the_headline_rule_set(monkeypatch):
+    """The 10k + 10k pipeline workload of bench.py: the join prototype's result sets against the exact engine's (same rule
+    set, not optimized -- the optimizer's alternative keys change ~0.02 % of the results of the exact engine itself)."""
+    vocab = synth.vocabulary(30000, 1)
+    pats, rules = synth.pipeline_workload(10000, 10000, vocab, seed=4)
+    text, offs = synth.text_documents(48, 16384, vocab, seed=1000, utf8=True)
+    lxi = spa.PatternLexerInstance()
+    synth.apply_lexer_patterns(lxi, pats)
+    lex = lxi.createContext().matchDocs(text, offs)
+    exact = spa.PatternMatcherInstance()
+    synth.apply_rules(exact, rules, compile=False)
+    monkeypatch.setenv("SPA_L2_JOIN", "1")
+    ctx = exact.createContext()
+    assert ctx.kernelKind() == 2
+    monkeypatch.delenv("SPA_L2_JOIN")
+    ectx = exact.createContext()
+    assert ectx.kernelKind() == 1
+    got = ctx.matchDocs(lex.lexems, lex.doc_offsets)
+    ref = ectx.matchDocs(lex.lexems, lex.doc_offsets)
+    assert np.array_equal(got.doc_offsets, ref.doc_offsets) and len(ref.results) > 100000
+    for d in range(len(offs) - 1):
+        a = sorted(map(tuple, got.results[got.doc_offsets[d]:got.doc_offsets[d + 1], :7].tolist()))
+        b = sorted(map(tuple, ref.results[ref.doc_offsets[d]:ref.doc_offsets[d + 1], :7].tolist()))
+        assert a == b, d
