@@ -22,7 +22,7 @@ hipError_t launchL2Fast( const FastParams& P, unsigned variant, unsigned nblocks
 int fastBlocksPerCU( unsigned variant);
 void fastCapacities( unsigned variant, uint32_t& R, uint32_t& T);
 std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out);
-std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab, std::vector<JoinRule>& rules, uint32_t& maxRange, uint32_t& delimiter);
+std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab, std::vector<JoinRule>& rules, std::vector<uint32_t>& filter, uint32_t& maxRange, uint32_t& delimiter);
 hipError_t launchL2Join( const JoinParams& P, unsigned nwaves, hipStream_t stream);
 void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], uint32_t& expShift, const std::vector<FastKeyInst>& keyinst, uint32_t R, uint32_t T, uint32_t maxRules, uint32_t maxStaged);
 }
@@ -99,7 +99,7 @@ struct sp_matcher_ctx
 	std::string whyNotFast;
 	DeviceBuffer dKeyinst, dSpill, dFallbackList;
 	// join prototype (l2_join.h, opt-in by SPA_L2_JOIN=1): result sets without materialised rule instances
-	bool join; std::string whyNotJoin; uint32_t joinKeymask, joinMaxRange, joinDelimiter; DeviceBuffer dJoinKeytab, dJoinRules;
+	bool join; std::string whyNotJoin; uint32_t joinKeymask, joinMaxRange, joinDelimiter; DeviceBuffer dJoinKeytab, dJoinRules, dJoinFilter, dJoinCounts;
 	std::vector<FastKeyInst> fastKeyinst;
 	FastSpillLayout fastSpill; uint32_t fastBucketMeta[ 16]; uint32_t fastExpShift;
 	unsigned fastWaves, fastBlocksPerCU, fastVariant;	// variant: kernel instance = LDS capacities (l2_fast_kernel.hip)
@@ -301,12 +301,12 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 		{
 			if (e[0] == '1')
 			{
-				std::vector<JoinKey> jk; std::vector<JoinRule> jr;
-				c->whyNotJoin = buildJoinTables( ft, jk, jr, c->joinMaxRange, c->joinDelimiter);
+				std::vector<JoinKey> jk; std::vector<JoinRule> jr; std::vector<uint32_t> jf;
+				c->whyNotJoin = buildJoinTables( ft, jk, jr, jf, c->joinMaxRange, c->joinDelimiter);
 				c->join = c->whyNotJoin.empty();
 				if (c->join)
 				{
-					c->dJoinKeytab.upload( jk.data(), jk.size()*sizeof(JoinKey)); c->dJoinRules.upload( jr.data(), jr.size()*sizeof(JoinRule));
+					c->dJoinKeytab.upload( jk.data(), jk.size()*sizeof(JoinKey)); c->dJoinRules.upload( jr.data(), jr.size()*sizeof(JoinRule)); c->dJoinFilter.upload( jf.data(), jf.size()*sizeof(uint32_t));
 					c->joinKeymask = (uint32_t)jk.size()-1;
 				}
 				if (getenv( "SPA_L2_VERBOSE")) fprintf( stderr, "[spa] join prototype: %s\n", c->join ? "on" : c->whyNotJoin.c_str());
@@ -670,6 +670,8 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		// opt-in prototype: result sets by joining positions, nothing installed (l2_join.h)
 		JoinParams J;
 		std::memset( &J, 0, sizeof(J));
+		c->dJoinCounts.reserve( (nlexems + 64) * sizeof(uint16_t));
+		J.filter = (const uint32_t*)c->dJoinFilter.ptr; J.counts = (uint16_t*)c->dJoinCounts.ptr; J.countsCapacity = nlexems;
 		J.keytab = (const JoinKey*)c->dJoinKeytab.ptr; J.keymask = c->joinKeymask; J.rules = (const JoinRule*)c->dJoinRules.ptr; J.maxRange = c->joinMaxRange; J.delimiter = c->joinDelimiter;
 		J.lexems = P.lexems; J.origseg = P.origseg; J.docOffsets = P.docOffsets; J.docRangesIn = P.docRangesIn; J.ndocs = P.ndocs;
 		J.docCursor = (uint32_t*)c->dCursor.ptr;

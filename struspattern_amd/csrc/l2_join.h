@@ -24,6 +24,7 @@ struct JoinKey			// 16 B, open addressing by joinHash( first, second), first==0 
 	uint32_t begin;		// rules[begin .. begin+count), definition order
 	uint32_t count;
 };
+enum {JOIN_FILTER_WORDS=4096};		// 16 KB = 131072 bits
 enum {JOIN_SELF=0xFFFFFFFFu};		// `first` of the entries for any( .. ): the lexem alone is the match
 enum {JOIN_STRUCT=1u};			// JoinRule::flags: no delimiter lexem may lie between the two terms (*_struct)
 struct JoinRule			// 16 B
@@ -48,6 +49,10 @@ struct JoinParams
 {
 	const JoinKey* keytab; uint32_t keymask;
 	const JoinRule* rules;
+	const uint32_t* filter;		// JOIN_FILTER_WORDS words: bit (joinHash( first, second) >> 8) % bits set for every table key -- copied to LDS,
+					// so that most pairs of nearby lexems (which complete nothing) are refused without a memory access
+	uint16_t* counts;		// per lexem of the batch: its number of matches (first pass -> second pass)
+	uint64_t countsCapacity;	// lexem indices below it have a slot (a document beyond it counts twice instead)
 	uint32_t maxRange;		// the largest position range of any program
 	uint32_t delimiter;		// the delimiter event of the *_struct programs (0 = none)
 	const uint32_t* lexems;		// sp_lexem_t[]: id, ordpos, origpos, origsize

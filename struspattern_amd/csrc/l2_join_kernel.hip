@@ -13,6 +13,12 @@ typedef uint64_t u64;
 namespace {
 #define LANE ((u32)(threadIdx.x & 63u))
 __device__ __forceinline__ u32 uni( u32 v) { return __builtin_amdgcn_readfirstlane( v); }
+__shared__ u32 pairFilter[ JOIN_FILTER_WORDS];
+__device__ __forceinline__ bool maybeKey( u32 first, u32 second)
+{
+	const u32 bit = (joinHash( first, second) >> 8) % (JOIN_FILTER_WORDS*32u);
+	return (pairFilter[ bit >> 5] >> (bit & 31u)) & 1u;
+}
 
 // the matches that end at lexem j (lane-private loop over the lexems of the last maxRange positions); WRITE: store them
 // from `out` on, else count
@@ -23,6 +29,7 @@ __device__ __forceinline__ u32 matchesEndingAt( const JoinParams& P, const uint4
 	const u32 e = lj.x;
 	if (!e) return 0;
 	// any( .., e, .. ): the lexem alone
+	if (maybeKey( JOIN_SELF, e))
 	{
 		u32 slot = joinHash( JOIN_SELF, e) & P.keymask;
 		for (u32 probes=0; probes<=P.keymask; ++probes)
@@ -55,7 +62,7 @@ __device__ __forceinline__ u32 matchesEndingAt( const JoinParams& P, const uint4
 		const uint4 li = lex[ i];
 		if (lj.y - li.y > P.maxRange) break;		// every instance that old has expired
 		if (takenPos > li.y) break;			// this one and all earlier ones were completed by that occurrence
-		if (li.x && lj.y > li.y)
+		if (li.x && lj.y > li.y && maybeKey( li.x, e))
 		{
 			u32 slot = joinHash( li.x, e) & P.keymask;
 			for (u32 probes=0; probes<=P.keymask; ++probes)
@@ -90,6 +97,8 @@ __device__ __forceinline__ u32 matchesEndingAt( const JoinParams& P, const uint4
 
 __device__ void joinDocuments( const JoinParams& P)
 {
+	for (u32 k=threadIdx.x; k<(u32)JOIN_FILTER_WORDS; k+=blockDim.x) pairFilter[ k] = P.filter[ k];
+	__syncthreads();
 	for (u32 round=0; round<=P.ndocs; ++round)
 	{
 		u32 doc = 0;
@@ -105,6 +114,7 @@ __device__ void joinDocuments( const JoinParams& P)
 		const u32* seg = P.origseg ? P.origseg + beg : 0;
 		u32 err = 0;
 		if (n64 >= (1ull << 32)) err = SPD_ERR_RANGE;
+		const bool stored = beg + n64 <= P.countsCapacity;
 		// checks of putInput (patternMatcher.cpp:131-162), the matches counted
 		u32 total = 0;
 		if (!err)
@@ -120,6 +130,8 @@ __device__ void joinDocuments( const JoinParams& P)
 					if (lj.x >= (1u<<29) || lj.z >= 0x7FFFFFFFu || lj.w >= 0x7FFFFFFFu) bad = true;
 					if (j + 1 < n && lex[ j+1].y < lj.y) order = true;
 					c = matchesEndingAt<false>( P, lex, seg, j, lj, 0, 0);
+					if (c > 0xFFFFu) bad = true;
+					if (stored) P.counts[ beg + j] = (uint16_t)c;
 				}
 				const u32 incl = waveScanAdd( c);
 				total += uni( (u32)__shfl( (int)incl, 63));
@@ -142,7 +154,11 @@ __device__ void joinDocuments( const JoinParams& P)
 				const u32 j = base + LANE;
 				uint4 lj = make_uint4( 0, 0, 0, 0);
 				u32 c = 0;
-				if (j < n) { lj = lex[ j]; c = matchesEndingAt<false>( P, lex, seg, j, lj, 0, 0); }
+				if (j < n)
+				{
+					if (stored) { c = P.counts[ beg + j]; if (c) lj = lex[ j]; }
+					else { lj = lex[ j]; c = matchesEndingAt<false>( P, lex, seg, j, lj, 0, 0); }
+				}
 				const u32 incl = waveScanAdd( c);
 				if (c)
 				{

@@ -9,7 +9,7 @@
 namespace spa {
 
 // returns the reason why the rule set cannot run in join mode (empty = it can)
-std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab, std::vector<JoinRule>& rules, uint32_t& maxRange, uint32_t& delimiter)
+std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab, std::vector<JoinRule>& rules, std::vector<uint32_t>& filter, uint32_t& maxRange, uint32_t& delimiter)
 {
 	std::map<std::pair<uint32_t,uint32_t>,std::vector<JoinRule> > byPair;
 	maxRange = 0; delimiter = 0;
@@ -73,6 +73,7 @@ std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab,
 	while (size < byPair.size()*2+1) size <<= 1;
 	JoinKey none; none.first = 0; none.second = 0; none.begin = 0; none.count = 0;
 	keytab.assign( size, none); rules.clear();
+	filter.assign( JOIN_FILTER_WORDS, 0);
 	for (std::map<std::pair<uint32_t,uint32_t>,std::vector<JoinRule> >::const_iterator it=byPair.begin(); it!=byPair.end(); ++it)
 	{
 		JoinKey k; k.first = it->first.first; k.second = it->first.second; k.begin = (uint32_t)rules.size(); k.count = (uint32_t)it->second.size();
@@ -80,6 +81,8 @@ std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab,
 		size_t slot = joinHash( k.first, k.second) & (size-1);
 		while (keytab[ slot].first) slot = (slot+1) & (size-1);
 		keytab[ slot] = k;
+		const uint32_t bit = (joinHash( k.first, k.second) >> 8) % (JOIN_FILTER_WORDS*32u);
+		filter[ bit >> 5] |= 1u << (bit & 31u);
 	}
 	return std::string();
 }
