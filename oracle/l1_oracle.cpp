@@ -611,6 +611,7 @@ Regex::Regex( const std::string& expr, unsigned options)
 	RegexParser parser( expr, options);
 	Ast ast = parser.parse();
 	m_ucp = (options & OptUcp) != 0;
+	m_allowEmpty = (options & OptAllowEmpty) != 0;
 	NfaBuilder b( m_nodes);
 	NfaBuilder::F f = b.build( ast);
 	int acc = b.node( Accept);
@@ -634,7 +635,8 @@ bool Regex::fixedContext( unsigned group, uint32_t& prefixLen, uint32_t& suffixL
 
 static inline bool isWordByte( int c) { return c >= 0 && c < 0x80 && (isalnum( c) || c == '_'); }
 
-// Semantics of SURVEY.md App. A.2: every end offset once, leftmost start, no empty matches.
+// Semantics of SURVEY.md App. A.2: every end offset once, leftmost start, no empty matches (with ALLOWEMPTY: also the empty
+// match at an offset where nothing longer ends -- a restatement of Hyperscan's documented flag that NO vector pins).
 void Regex::scan( const unsigned char* src, size_t len, std::vector<std::pair<uint32_t,uint32_t> >& out) const
 {
 	const uint32_t INF = 0xFFFFFFFFu;
@@ -706,7 +708,8 @@ void Regex::scan( const unsigned char* src, size_t len, std::vector<std::pair<ui
 		// report
 		for (size_t n=0; n<nn; ++n)
 		{
-			if (m_nodes[ n].type == Accept && cur[ n] != INF && cur[ n] < (uint32_t)i) out.push_back( std::make_pair( cur[ n], (uint32_t)i));
+			// (HS_FLAG_ALLOWEMPTY: also the empty match that starts and ends here, when nothing longer ends here)
+			if (m_nodes[ n].type == Accept && cur[ n] != INF && (cur[ n] < (uint32_t)i || m_allowEmpty)) out.push_back( std::make_pair( cur[ n], (uint32_t)i));
 		}
 		if (i == len) break;
 		// consume src[i]
@@ -1005,7 +1008,6 @@ static bool plainLiteral( const std::string& expr)
 // SURVEY.md 8(f) and are rejected here.
 void LexerInstance::compile()
 {
-	if (m_options & OptAllowEmpty) throw std::runtime_error( "option not supported by this oracle (ALLOWEMPTY)");
 	m_regex.clear(); m_literal.clear(); m_approx = false;
 	for (size_t i=0; i<m_defs.size(); ++i) if (m_defs[i].editdist) m_approx = true;
 	if (m_options & OptByteChar) m_approx = true;		// forceOneByteCharMap (patternLexer.cpp:1055-1058): the same route

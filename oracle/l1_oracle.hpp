@@ -59,7 +59,7 @@ private:
 	friend class RegexParser;
 	std::vector<Node> m_nodes;
 	int m_start;
-	bool m_ucp;
+	bool m_ucp, m_allowEmpty;
 	std::map<unsigned,std::pair<int,int> > m_groupFixed;	// group -> (prefix len, suffix len) or (-1,-1)
 };
 

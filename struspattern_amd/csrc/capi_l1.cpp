@@ -41,7 +41,7 @@ struct sp_lexer_ctx
 	int device;
 	std::string lasterror;
 	DeviceBuffer dByteClass, dClassCtx, dCharMask, dStartMask, dAcceptMask, dShiftDst, dSelfLoop, dExSrc, dExDst, dExCount,
-		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit, dApprox, dCharCp, dCharPos, dCpBlocks, dCpPages, dUnitStart, dDocSequential;
+		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit, dApprox, dCharCp, dCharPos, dCpBlocks, dCpPages, dUnitStart, dDocSequential, dNullable;
 	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst; unsigned blockThreads;
 	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus, dQueue, dReportCount;
 	uint32_t queueMul;		// report queue between the two kernels: queueMul/16 reports per text byte (+64 per document)
@@ -143,6 +143,9 @@ size_t sp_lexer_dump_tables( const sp_lexer_t* l, uint64_t** out)
 		for (uint32_t k=0; k<e.len; ++k) b.push_back( T.literalText[ e.textOffset+k]);
 		for (uint32_t k=0; k<e.patCount; ++k) b.push_back( T.litPats[ e.patBegin+k]);
 	}
+	// ALLOWEMPTY: {patterns entry, emptyOk bits} per expression that matches the empty string
+	b.push_back( T.nullable.size());
+	for (size_t i=0; i<T.nullable.size(); ++i) { b.push_back( T.nullable[ i].pattern); b.push_back( T.nullable[ i].emptyOk); }
 	// classes by code point: block table and pages (both may be empty)
 	b.push_back( T.cpBlocks.size());
 	for (size_t i=0; i<T.cpBlocks.size(); ++i) b.push_back( T.cpBlocks[ i]);
@@ -197,6 +200,7 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 		c->dLiteralText.upload( T.literalText.data(), T.literalText.size());
 		c->dLitPats.upload( T.litPats.data(), T.litPats.size()*4);
 		if (!T.cpBlocks.empty()) { c->dCpBlocks.upload( T.cpBlocks.data(), T.cpBlocks.size()*2); c->dCpPages.upload( T.cpPages.data(), T.cpPages.size()); }
+		if (!T.nullable.empty()) c->dNullable.upload( T.nullable.data(), T.nullable.size()*sizeof(DevNullable));
 		if (!T.approx.empty()) c->dApprox.upload( T.approx.data(), T.approx.size()*sizeof(DevApproxPattern));
 		{
 			// LDS image of the hot tables when it fits (one copy per workgroup; bigger workgroups when the copy is big)
@@ -354,6 +358,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.charCp = (uint32_t*)c->dCharCp.ptr; P.charPos = (uint32_t*)c->dCharPos.ptr;
 	P.cpBlocks = T.cpBlocks.empty() ? 0 : (const uint16_t*)c->dCpBlocks.ptr; P.cpPages = (const uint8_t*)c->dCpPages.ptr;
 	P.ucp = T.ucp ? 1u : 0u;
+	P.nullable = T.nullable.empty() ? 0 : (const DevNullable*)c->dNullable.ptr; P.nofNullable = (uint32_t)T.nullable.size();
 	P.unitStart = (uint32_t*)c->dUnitStart.ptr; P.chunkBytes = chunkBytes; P.docSequential = (uint32_t*)c->dDocSequential.ptr; P.sequentialPass = 0;
 	P.splitPatterns = (T.patterns.size() != c->inst->compiler.nofDefinitions()) ? 1u : 0u;
 	HIP_CHECK( hipEventRecord( c->evStart, stream));

@@ -710,6 +710,7 @@ struct Automaton
 	std::vector<uint64_t> follow;		// follow[i] = successors of position i
 	uint64_t start[ CTX_COUNT];		// positions a match may begin with, by context of the byte before
 	uint64_t accept[ CTX_COUNT];		// positions a match may end with, by context of the byte after
+	uint32_t emptyOk;			// bit (prev*CTX_COUNT + next): the expression matches the empty string between a byte of context prev and one of context next
 };
 
 struct TooWide {};		// more than 64 byte positions: the caller may cut the expression at an alternation
@@ -751,6 +752,11 @@ Automaton makeAutomaton( const Tree& tree, const std::string&, bool ucp)
 	}
 	if (a.pos.size() > 64) throw TooWide();
 	a.ctxDef = ctxOf;
+	a.emptyOk = 0;
+	for (size_t i=0; i<root.nullable.size(); ++i) for (int pv=0; pv<CTX_COUNT; ++pv) for (int nx=0; nx<CTX_COUNT; ++nx)
+	{
+		if (condHolds( root.nullable[ i], pv, nx)) a.emptyOk |= 1u << (pv*CTX_COUNT + nx);
+	}
 	a.follow.assign( a.pos.size(), 0);
 	for (int c=0; c<CTX_COUNT; ++c) { a.start[c] = 0; a.accept[c] = 0; }
 	for (size_t i=0; i<g.edges.size(); ++i)
@@ -937,7 +943,6 @@ void LexCompiler::defineOption( const std::string& name, double)
 // src/patternLexer.cpp:1068-1118 (+ PatternTable::complete :333-412)
 void LexCompiler::compile()
 {
-	if (m_options & LEX_ALLOWEMPTY) throw std::runtime_error( "option ALLOWEMPTY is not supported by this lexer");
 	LexTables& T = m_tables;
 	T = LexTables();
 
@@ -1032,6 +1037,13 @@ void LexCompiler::compile()
 		}
 		std::vector<Automaton> parts;
 		makeAutomata( tree, d.expression, ucp, parts);
+		if ((m_options & LEX_ALLOWEMPTY) && parts[ 0].emptyOk)
+		{
+			// HS_FLAG_ALLOWEMPTY: the expression also reports its empty matches (one report per offset where nothing longer ends)
+			if (parts.size() > 1) throw std::runtime_error( "failed to compile pattern \"" + d.expression + "\": an expression that matches the empty string must fit one automaton word with ALLOWEMPTY");
+			DevNullable nl; nl.pattern = (uint32_t)T.patterns.size(); nl.emptyOk = parts[ 0].emptyOk; nl._pad[0] = 0; nl._pad[1] = 0;
+			T.nullable.push_back( nl);
+		}
 		for (size_t k=0; k<parts.size(); ++k) { T.patterns.push_back( dp); autos.push_back( parts[ k]); }
 	}
 	if (T.patterns.size() >= (1u << 24)) throw std::runtime_error( "too many patterns");
@@ -1421,6 +1433,10 @@ void LexCompiler::compile()
 		}
 	}
 
+	// (the empty-match reports of ALLOWEMPTY are appended behind the automaton's reports of an offset: sort every offset's group)
+	if (T.nullable.size() > 64) throw std::runtime_error( "too many expressions that match the empty string (ALLOWEMPTY: at most 64)");
+	if (!T.nullable.empty()) T.reportsOrdered = false;
+
 	// 4b. whole-word literals: hash table keyed by the word
 	{
 		size_t size = 1;
@@ -1481,7 +1497,7 @@ void LexCompiler::compile()
 }
 
 // ---------------------------------------------------------------- compiled tables as a blob
-static const char L1_MAGIC[ 9] = "SPAL1v06";
+static const char L1_MAGIC[ 9] = "SPAL1v07";
 
 void LexCompiler::save( std::vector<uint8_t>& out) const
 {
@@ -1492,7 +1508,7 @@ void LexCompiler::save( std::vector<uint8_t>& out) const
 	w.u32( T.nofPasses); w.u32( T.nofClasses); w.u32( T.maxExceptions); w.u32( T.nofLiterals); w.u32( T.nofPositions); w.u32( T.reportsOrdered ? 1u : 0u); w.u32( T.ucp ? 1u : 0u);
 	w.vec( T.byteClass); w.vec( T.classCtx); w.vec( T.cpBlocks); w.vec( T.cpPages); w.vec( T.charMask); w.vec( T.startMask); w.vec( T.acceptMask); w.vec( T.shiftDst); w.vec( T.selfLoop);
 	w.vec( T.exCount); w.vec( T.exSrc); w.vec( T.exDst); w.vec( T.wordPatBegin); w.vec( T.wordPats); w.vec( T.patOfBit);
-	w.vec( T.patterns); w.vec( T.symbols); w.vec( T.symbolText); w.vec( T.literals); w.vec( T.literalText); w.vec( T.litPats); w.vec( T.approx);
+	w.vec( T.patterns); w.vec( T.symbols); w.vec( T.symbolText); w.vec( T.literals); w.vec( T.literalText); w.vec( T.litPats); w.vec( T.approx); w.vec( T.nullable);
 	w.u32( (uint32_t)m_defs.size());
 	for (size_t i=0; i<m_defs.size(); ++i)
 	{
@@ -1518,7 +1534,7 @@ void LexCompiler::load( const void* blob, size_t size)
 	T.nofPasses = r.u32(); T.nofClasses = r.u32(); T.maxExceptions = r.u32(); T.nofLiterals = r.u32(); T.nofPositions = r.u32(); T.reportsOrdered = r.u32() != 0; T.ucp = r.u32() != 0;
 	r.vec( T.byteClass); r.vec( T.classCtx); r.vec( T.cpBlocks); r.vec( T.cpPages); r.vec( T.charMask); r.vec( T.startMask); r.vec( T.acceptMask); r.vec( T.shiftDst); r.vec( T.selfLoop);
 	r.vec( T.exCount); r.vec( T.exSrc); r.vec( T.exDst); r.vec( T.wordPatBegin); r.vec( T.wordPats); r.vec( T.patOfBit);
-	r.vec( T.patterns); r.vec( T.symbols); r.vec( T.symbolText); r.vec( T.literals); r.vec( T.literalText); r.vec( T.litPats); r.vec( T.approx);
+	r.vec( T.patterns); r.vec( T.symbols); r.vec( T.symbolText); r.vec( T.literals); r.vec( T.literalText); r.vec( T.litPats); r.vec( T.approx); r.vec( T.nullable);
 	// the shapes the kernel indexes by must fit together (a blob of another build would fault on the device)
 	if (T.byteClass.size() != (T.ucp ? 320u : 256u) || (T.ucp && T.cpBlocks.empty()) || T.classCtx.size() != T.nofClasses
 	||  T.charMask.size() != (size_t)T.nofPasses*T.nofClasses*64 || T.startMask.size() != (size_t)T.nofPasses*CTX_COUNT*64 || T.acceptMask.size() != T.startMask.size()
@@ -1548,6 +1564,7 @@ void LexCompiler::load( const void* blob, size_t size)
 	{
 		if (T.patterns[ i].defIndex >= m_defs.size() || (i && T.patterns[ i].defIndex < T.patterns[ i-1].defIndex)) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
 	}
+	for (size_t i=0; i<T.nullable.size(); ++i) if (T.nullable[ i].pattern >= T.patterns.size() || T.nullable.size() > 64) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
 	for (size_t i=0; i<T.approx.size(); ++i)
 	{
 		if (T.approx[ i].len == 0 || T.approx[ i].len > L1_APPROX_MAXCHARS || T.approx[ i].editdist > L1_APPROX_MAXDIST || T.approx[ i].editdist >= T.approx[ i].len || T.approx.size() > L1_APPROX_MAXPATTERNS)

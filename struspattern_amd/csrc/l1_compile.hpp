@@ -43,6 +43,7 @@ struct LexTables
 	std::vector<DevLiteral> literals;	// power-of-two size (>=1)
 	std::vector<uint8_t> literalText;
 	std::vector<uint32_t> litPats;
+	std::vector<DevNullable> nullable;	// ALLOWEMPTY: the expressions that match the empty string (at most 64)
 	std::vector<DevApproxPattern> approx;	// non-empty: approximate literal table, the automaton tables are empty
 	uint32_t nofLiterals;
 	uint32_t nofPositions;

@@ -76,6 +76,8 @@ struct L1Params
 	uint32_t chunkBytes;		// multiple of 64
 	uint32_t* docSequential;	// [ndocs]: 1 = a chunk's start state could not be proven from its warm-up; the document is scanned again in one piece
 	uint32_t sequentialPass;	// this launch of the scan kernel is that re-scan
+	const DevNullable* nullable;	// ALLOWEMPTY: expressions that match the empty string (or null)
+	uint32_t nofNullable;
 	uint32_t ucp;			// option UCP: contexts by Unicode word characters, byteClass has the 64 twin entries [256..319]
 	uint32_t splitPatterns;		// some expression is cut into several patterns entries (same defIndex): their reports are merged
 };

@@ -698,7 +698,7 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 					state[ p] = nxt & cmRow[ p];
 				}
 			}
-			if (EMIT && __ballot( anyAcc != 0))
+			if (EMIT && (__ballot( anyAcc != 0) || (CP && P.nofNullable)))
 			{
 				
 #pragma unroll
@@ -751,6 +751,26 @@ __device__ void scanDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 						}
 					}
 					w.nQueue += total;
+				}
+				if (CP && P.nofNullable)
+				{
+					// ALLOWEMPTY: an expression that matches the empty string reports (i, i) when its empty path holds between the
+					// byte before and this one and nothing longer of it ends here (the leftmost start wins)
+					for (u32 k=0; k<P.nofNullable && !w.err; ++k)
+					{
+						const u32 pi = ldu( &P.nullable[ k].pattern), ok = ldu( &P.nullable[ k].emptyOk);
+						if (!((ok >> ((u32)prevctx*CTX_COUNT + (u32)ctx)) & 1u)) continue;
+						const DevLexPattern* pat = &P.patterns[ pi];
+						const u32 word = ldu( &pat->word);
+						const u64 mask = ((u64)ldu( &pat->maskHi) << 32) | ldu( &pat->maskLo);
+						u64 a = 0;
+#pragma unroll
+						for (int p=0; p<PASSES; ++p) if ((word >> 6) == (u32)p) a = acc[ p];
+						if (__ballot( (word & 63u) == LANE && (a & mask) != 0)) continue;
+						if (w.nQueue + 1u > w.queueCap) { w.err = L1D_ERR_ARENA; break; }
+						if (LANE == 0) *(uint4*)(w.queue + 4*(u64)w.nQueue) = make_uint4( i, pi, 0, 0);
+						++w.nQueue;
+					}
 				}
 				if (!P.reportsOrdered && !w.err)
 				{
@@ -1339,7 +1359,7 @@ __device__ void scanDocuments( const L1Params& P)
 {
 	// three sets of instances: plain (no classes by code point, no chunked document in the batch), chunks, classes by code point (+ chunks)
 	const u32 chunked = ldu( (const u32*)&P.counters[ L1C_CHUNKED]);
-	if (CP != (P.cpBlocks != 0) || (!CP && CH != (chunked != 0))) return;
+	if (CP != (P.cpBlocks != 0 || P.nofNullable != 0) || (!CP && CH != (chunked != 0))) return;
 	LexTab<LDS> T;
 	stageTables( P, T);
 	LexWave w;
@@ -1402,7 +1422,7 @@ __device__ void postDocuments( const L1Params& P)
 {
 	// (the same three sets of instances as the scan kernel's)
 	const u32 chunked = ldu( (const u32*)&P.counters[ L1C_CHUNKED]);
-	if (CP != (P.cpBlocks != 0) || (!CP && CH != (chunked != 0))) return;
+	if (CP != (P.cpBlocks != 0 || P.nofNullable != 0) || (!CP && CH != (chunked != 0))) return;
 	LexTab<LDS> T;
 	stageTables( P, T);
 	const u32 waveSlot = uni( blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -1519,7 +1539,7 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 	if (lds > 65536) { e = hipFuncSetAttribute( (const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
 	hipLaunchKernelGGL( KERNEL, dim3( nblocks), dim3( nthreads), lds, stream, ARGS); } while (0)
 #define SPA_L1_LAUNCH( N) do { \
-	if (P.cpBlocks) { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, P); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, S); } \
+	if (P.cpBlocks || P.nofNullable) { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, P); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, S); } \
 	else { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N, P); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, P); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, S); } } while (0)
 	switch (P.nofPasses)
 	{
@@ -1540,7 +1560,7 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 	if (e != hipSuccess) return e;
 	if (betweenKernels) { e = hipEventRecord( betweenKernels, stream); if (e != hipSuccess) return e; }
 	// its own number of waves (one event array each), in workgroups of POST_WAVES
-	if (P.cpBlocks) hipLaunchKernelGGL( spa_l1_post_kernel_cp, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
+	if (P.cpBlocks || P.nofNullable) hipLaunchKernelGGL( spa_l1_post_kernel_cp, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
 	else
 	{
 		hipLaunchKernelGGL( spa_l1_post_kernel, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);

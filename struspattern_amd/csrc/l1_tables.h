@@ -47,6 +47,15 @@ struct DevApproxPattern		// 128 B, index = definition index
 	uint32_t cp[ L1_APPROX_MAXCHARS];	// code points
 };
 
+// ALLOWEMPTY: an expression that matches the empty string reports (offset, offset) wherever its empty path holds and nothing
+// longer of it ends
+struct DevNullable		// 16 B
+{
+	uint32_t pattern;	// patterns[] entry (the expression fits one automaton word)
+	uint32_t emptyOk;	// bit (prev*CTX_COUNT + next)
+	uint32_t _pad[2];
+};
+
 struct DevSymbol		// 32 B, open addressing (linear probing), hash==0 = empty
 {
 	uint32_t hash;

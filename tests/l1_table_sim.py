@@ -44,6 +44,8 @@ class Tables:
             ln, pc = take(2)
             word = bytes(take(ln))
             self.literals[word] = take(pc)
+        nnull = take(1)[0]
+        self.nullable = [tuple(take(2)) for _ in range(nnull)]      # ALLOWEMPTY: (patterns entry, emptyOk bits)
         nblk = take(1)[0]
         self.cpBlocks = take(nblk)
         npg = take(1)[0]
@@ -134,6 +136,13 @@ class Tables:
                 i = j
             else:
                 i += 1
+        # ALLOWEMPTY: the empty match of an expression wherever its empty path holds and nothing longer of it ends
+        have = set((r[0], r[2]) for r in out)
+        for i in range(len(text) + 1):
+            pv, nx = self.ctx(text, i - 1), self.ctx(text, i)
+            for pi, ok in self.nullable:
+                if (ok >> (pv * 4 + nx)) & 1 and (pi + 1, i) not in have:
+                    out.append((pi + 1, i, i))
         out.sort(key=lambda r: (r[2], r[0]))
         # an expression cut into several entries reports once per entry: one report per (definition, end) with the
         # leftmost start, numbered by definition

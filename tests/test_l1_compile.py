@@ -115,6 +115,18 @@ def test_ucp_unicode_word_characters():
     assert _product_reports(["\\b\\w+\\b"], "\u00fcber".encode("utf8"), opts) == [(1, 0, 5)]
 
 
+def test_allowempty_reports_empty_matches():
+    """Option ALLOWEMPTY (HS_FLAG_ALLOWEMPTY): an expression that can match the empty string also reports (offset, offset)
+    wherever its empty path holds and nothing longer of it ends -- restated from Hyperscan's documentation, pinned by no
+    vector of the reference."""
+    pats = ["a*", "\\b", "x?\\b", "(?:ab)*c?", "\\B", "^", "$", "[0-9]+"]
+    opts = ("DOTALL", "ALLOWEMPTY")
+    for t in (b"baab aa", b"", b"a", b" x1 22y ", b"abab c"):
+        assert _product_reports(pats, t, opts) == _oracle_reports(pats, t, opts), t
+    got = _product_reports(["a*"], b"baab", opts)
+    assert got == [(1, 0, 0), (1, 1, 1), (1, 1, 2), (1, 1, 3), (1, 4, 4)]
+
+
 def test_caseless_folds_beyond_ascii():
     """CASELESS in UTF-8 mode uses Unicode case classes (tools/gen_unicode_tables.py): literals, classes, ranges."""
     pats = ["stra\u00dfe", "[a-z]+k", "\u00c4\u00d6[\u00fc]+", "\u03a3\u03af\u03c3\u03c5\u03c6\u03bf\u03c2", "[\u0430-\u044f]+", "x\u017f"]

@@ -231,6 +231,26 @@ def test_ucp_unicode_word_characters():
         assert got.doc(di).tolist() == o.match(d).tolist(), d[:80]
 
 
+def test_allowempty_option():
+    """ALLOWEMPTY: empty matches become zero-length events and go through the handler like any other (restated semantics,
+    pinned by no reference vector); documents of several tiles and chunks."""
+    def build(x):
+        x.defineOption("ALLOWEMPTY", 0) if isinstance(x, spa.PatternLexerInstance) else x.defineOption("ALLOWEMPTY")
+        x.defineLexem(1, "\\b\\w+\\b", 0, 2, "content")
+        x.defineLexem(2, "a*", 0, 1, "content")
+        x.defineLexem(3, "x?\\b", 0, 3, "predecessor")
+        x.defineLexem(4, "[0-9]+", 0, 2, "content")
+        x.compile()
+    lx, o = _both(build)
+    rng = random.Random(21)
+    docs = [b"", b"a", b"baab aa", b" x1 22y "] + ["".join(rng.choice("ab x1 .") for _ in range(n)).encode() for n in (70, 300, 2000)]
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in docs])
+    got = lx.createContext().matchDocs(b"".join(docs), offs)
+    for di, d in enumerate(docs):
+        assert got.doc(di).tolist() == o.match(d).tolist(), d[:60]
+
+
 def test_wide_alternations_cut_into_several_words():
     """Expressions beyond 64 byte positions (cut at an alternation into several automaton words): several words of
     one expression report at the same end offset with different starts (suffix-related alternatives sit in
