@@ -1031,6 +1031,14 @@ void LexerInstance::compile()
 	for (size_t i=0; i<m_defs.size(); ++i)
 	{
 		m_regex.push_back( Regex( m_defs[i].expression, m_options));
+		if (!(m_options & OptAllowEmpty))
+		{
+			// Hyperscan refuses an expression that matches the empty buffer unless HS_FLAG_ALLOWEMPTY is given
+			Regex probe( m_defs[i].expression, m_options | OptAllowEmpty);
+			std::vector<std::pair<uint32_t,uint32_t> > hit;
+			probe.scan( (const unsigned char*)"", 0, hit);
+			if (!hit.empty()) throw std::runtime_error( "Pattern matches empty buffer; use option ALLOWEMPTY to enable support: " + m_defs[i].expression);
+		}
 		if (m_defs[i].resultIndex)
 		{
 			// sub-expression selection (patternLexer.cpp:488-507 via libtre): supported when the text

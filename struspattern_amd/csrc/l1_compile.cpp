@@ -1037,6 +1037,11 @@ void LexCompiler::compile()
 		}
 		std::vector<Automaton> parts;
 		makeAutomata( tree, d.expression, ucp, parts);
+		if (!(m_options & LEX_ALLOWEMPTY) && (parts[ 0].emptyOk & (1u << (CTX_EDGE*CTX_COUNT + CTX_EDGE))))
+		{
+			// what Hyperscan answers hs_compile_ext_multi with (the reference hands the message on, patternLexer.cpp:1094-1104)
+			throw std::runtime_error( "failed to compile pattern \"" + d.expression + "\": Pattern matches empty buffer; use option ALLOWEMPTY to enable support");
+		}
 		if ((m_options & LEX_ALLOWEMPTY) && parts[ 0].emptyOk)
 		{
 			// HS_FLAG_ALLOWEMPTY: the expression also reports its empty matches (one report per offset where nothing longer ends)

@@ -57,7 +57,7 @@ def test_random_regex_tables_vs_oracle_and_python_re(seed):
                 one.defineLexem(1, p, 0, 1, "content")
                 one.compile()
             except spa.PatternError as e:
-                assert "too complex" in str(e), str(e)
+                assert "too complex" in str(e) or "matches empty buffer" in str(e), str(e)
                 continue
             pats.append(p)
         text = l1_cases.random_text(rng, rng.randint(0, 30)).encode()
