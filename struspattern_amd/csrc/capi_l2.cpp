@@ -124,7 +124,7 @@ struct sp_matcher_ctx
 	std::vector<uint32_t> curOrigseg; bool curHasSeg;
 	sp_matcher_stats_t lastStats;
 
-	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),fast(false),fastWaves(0),fastBlocksPerCU(0),fastVariant(4),fastMaxRules(2048),fastMaxStaged(32768),join(false),joinKeymask(0),joinMaxRange(0),joinDelimiter(0),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
+	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),fast(false),join(false),joinKeymask(0),joinMaxRange(0),joinDelimiter(0),fastWaves(0),fastBlocksPerCU(0),fastVariant(4),fastMaxRules(2048),fastMaxStaged(32768),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
 		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
