@@ -670,12 +670,13 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		// opt-in prototype: result sets by joining positions, nothing installed (l2_join.h)
 		JoinParams J;
 		std::memset( &J, 0, sizeof(J));
-		c->dJoinCounts.reserve( (nlexems + 64) * sizeof(uint16_t));
-		J.filter = (const uint32_t*)c->dJoinFilter.ptr; J.counts = (uint16_t*)c->dJoinCounts.ptr; J.countsCapacity = nlexems;
+		c->dJoinCounts.reserve( (nlexems + 64) * sizeof(uint32_t));
+		J.filter = (const uint32_t*)c->dJoinFilter.ptr; J.counts = (uint32_t*)c->dJoinCounts.ptr; J.countsCapacity = nlexems;
 		J.keytab = (const JoinKey*)c->dJoinKeytab.ptr; J.keymask = c->joinKeymask; J.rules = (const JoinRule*)c->dJoinRules.ptr; J.maxRange = c->joinMaxRange; J.delimiter = c->joinDelimiter;
 		J.lexems = P.lexems; J.origseg = P.origseg; J.docOffsets = P.docOffsets; J.docRangesIn = P.docRangesIn; J.ndocs = P.ndocs;
 		J.docCursor = (uint32_t*)c->dCursor.ptr;
 		J.counters = P.counters; J.results = P.results; J.resultCapacity = P.resultCapacity;
+		J.items = P.items; J.itemCapacity = P.itemCapacity; J.withItems = P.withItems; J.itemFormat = P.itemFormat;
 		J.docRange = P.docRange; J.docStats = P.docStats; J.docStatus = P.docStatus;
 		J.withFormats = P.withFormats; J.resultFormat = P.resultFormat;
 		const size_t jslots = (size_t)c->numCUs * 32;		// one wave per document, no LDS, few registers

@@ -1,5 +1,5 @@
 // PROTOTYPE, opt-in (SPA_L2_JOIN=1): the rule automaton WITHOUT materialised rule instances, for rule sets made of two-term
-// `sequence( A, B | range )` programs without variables that nobody listens to ("The ceiling").
+// `sequence( A, B | range )` programs that nobody listens to ("The ceiling").
 // The reference installs an instance at every A and retires it at the first later B or when it expires
 // (src/ruleMatcherAutomaton.cpp:589-1334); the result SET of a document follows from the positions alone:
 //   (A at lexem i, B at lexem j) matches  iff  ordpos(i) < ordpos(j) <= ordpos(i) + range  and no B lies between them at a
@@ -26,7 +26,8 @@ struct JoinKey			// 16 B, open addressing by joinHash( first, second), first==0 
 };
 enum {JOIN_FILTER_WORDS=4096};		// 16 KB = 131072 bits
 enum {JOIN_SELF=0xFFFFFFFFu};		// `first` of the entries for any( .. ): the lexem alone is the match
-enum {JOIN_STRUCT=1u};			// JoinRule::flags: no delimiter lexem may lie between the two terms (*_struct)
+enum {JOIN_STRUCT=1u};			// JoinRule::flags: no delimiter lexem may lie between the two terms (*_struct);
+					// bits 8..15 / 16..23: the variable attached to the first / the completing term (0 = none)
 struct JoinRule			// 16 B
 {
 	uint32_t range;
@@ -51,7 +52,7 @@ struct JoinParams
 	const JoinRule* rules;
 	const uint32_t* filter;		// JOIN_FILTER_WORDS words: bit (joinHash( first, second) >> 8) % bits set for every table key -- copied to LDS,
 					// so that most pairs of nearby lexems (which complete nothing) are refused without a memory access
-	uint16_t* counts;		// per lexem of the batch: its number of matches (first pass -> second pass)
+	uint32_t* counts;		// per lexem of the batch: its number of matches | items << 16 (first pass -> second pass)
 	uint64_t countsCapacity;	// lexem indices below it have a slot (a document beyond it counts twice instead)
 	uint32_t maxRange;		// the largest position range of any program
 	uint32_t delimiter;		// the delimiter event of the *_struct programs (0 = none)
@@ -63,6 +64,7 @@ struct JoinParams
 	uint32_t* docCursor;
 	uint64_t* counters;		// SPC_*
 	uint32_t* results; uint64_t resultCapacity;
+	uint32_t* items; uint64_t itemCapacity; uint32_t withItems; uint32_t* itemFormat;	// sp_result_item_t[] (7 words each)
 	uint64_t* docRange; uint64_t* docStats; int32_t* docStatus;
 	uint32_t withFormats; uint32_t* resultFormat;
 };

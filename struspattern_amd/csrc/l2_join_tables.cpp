@@ -37,6 +37,7 @@ std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab,
 			else { if (nterm == 2) return "a program with more than two terms"; term[ nterm++] = &td; }
 		}
 		if (nterm != 2) return "a program that has not two terms";
+		if (term[ 0]->variable > 255 || term[ 1]->variable > 255) return "a variable id beyond 255";
 		const uint32_t sigtype = term[ 0]->flags & 0xF;
 		if ((term[ 1]->flags & 0xF) != sigtype) return "a program with mixed signals";
 		JoinRule r; r.range = p.positionRange; r.resultHandle = p.resultHandle; r.formatHandle = p.formatHandle; r.flags = 0;
@@ -50,21 +51,33 @@ std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab,
 		if (sigtype == SIG_ANY)
 		{
 			if (p.initcount != 1 || del) return "an `any` program with a cardinality or a delimiter";
-			byPair[ std::make_pair( (uint32_t)JOIN_SELF, term[ 0]->event)].push_back( r);
-			byPair[ std::make_pair( (uint32_t)JOIN_SELF, term[ 1]->event)].push_back( r);
+			// (two equal terms: both triggers of both instances take the lexem, term[0] in table order first -- listed last)
+			const bool same = term[ 0]->event == term[ 1]->event;
+			for (int t=0; t<2; ++t)
+			{
+				JoinRule rt = r; rt.flags |= same ? ((term[ 1]->variable << 16) | (term[ 0]->variable << 8)) : (term[ t]->variable << 16);
+				byPair[ std::make_pair( (uint32_t)JOIN_SELF, term[ t]->event)].push_back( rt);
+			}
 		}
 		else if (sigtype == SIG_SEQUENCE)
 		{
 			if (p.initcount != 2 || p.initsigval != 2) return "a sequence with a cardinality";
 			const int first = term[ 0]->sigval == 2 ? 0 : 1;
 			if (term[ first]->sigval != 2 || term[ 1-first]->sigval != 1) return "a sequence with unexpected signal values";
+			r.flags |= (term[ first]->variable << 8) | (term[ 1-first]->variable << 16);
 			byPair[ std::make_pair( term[ first]->event, term[ 1-first]->event)].push_back( r);
 		}
 		else if (sigtype == SIG_WITHIN)
 		{
 			if (p.initcount != 2) return "a within with a cardinality";
-			byPair[ std::make_pair( term[ 0]->event, term[ 1]->event)].push_back( r);
-			byPair[ std::make_pair( term[ 1]->event, term[ 0]->event)].push_back( r);
+			// (two equal terms: the key lexem is taken by the trigger installed first, term[0] in table order, in both instances)
+			const bool same = term[ 0]->event == term[ 1]->event;
+			for (int t=0; t<2; ++t)
+			{
+				const int a = same ? 0 : t;
+				JoinRule rt = r; rt.flags |= (term[ a]->variable << 8) | (term[ 1-a]->variable << 16);
+				byPair[ std::make_pair( term[ t]->event, term[ 1-t]->event)].push_back( rt);
+			}
 		}
 		else return "a program that is neither sequence, within nor any";
 	}

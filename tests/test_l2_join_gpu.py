@@ -30,8 +30,12 @@ def _docs(rng, ndocs, n, nfeat, shared_positions):
 
 
 def _sorted_results(batch, d):
-    r = batch.doc(d)[:, :7] if hasattr(batch, "doc") else None
-    return sorted(map(tuple, r.tolist()))
+    """the results of document d with their captured items (variable, positions; in the result's list order), sorted"""
+    out = []
+    for r in batch.results[batch.doc_offsets[d]:batch.doc_offsets[d + 1]].tolist():
+        it = batch.items[r[7]:r[7] + r[8]]
+        out.append(tuple(r[:7]) + (r[8],) + tuple(it.reshape(-1).tolist()))
+    return sorted(out)
 
 
 @pytest.mark.parametrize("op", ["sequence", "within", "sequence_struct", "within_struct", "any", None])
@@ -54,11 +58,12 @@ def test_join_prototype_result_sets(monkeypatch, seed, nrules, nfeat, n, shared,
     assert np.array_equal(got.doc_offsets, ref.doc_offsets)
     total = 0
     for d in range(ndocs):
-        a = sorted(map(tuple, got.results[got.doc_offsets[d]:got.doc_offsets[d + 1], :7].tolist()))
-        b = sorted(map(tuple, ref.results[ref.doc_offsets[d]:ref.doc_offsets[d + 1], :7].tolist()))
-        assert a == b, (d, len(a), len(b))
+        a = _sorted_results(got, d)
+        b = _sorted_results(ref, d)
+        assert a == b, (d, len(a), len(b), [x for x in a if x not in b][:2], [x for x in b if x not in a][:2])
         total += len(a)
     assert total > 100
+    assert len(got.items) == len(ref.items) > 0
     # the same instance without the switch runs the exact engine
     assert m.createContext().kernelKind() == 1
 
@@ -92,7 +97,6 @@ def test_join_prototype_on_the_headline_rule_set(monkeypatch):
     got = ctx.matchDocs(lex.lexems, lex.doc_offsets)
     ref = ectx.matchDocs(lex.lexems, lex.doc_offsets)
     assert np.array_equal(got.doc_offsets, ref.doc_offsets) and len(ref.results) > 100000
+    assert len(got.items) == len(ref.items) > 100000
     for d in range(len(offs) - 1):
-        a = sorted(map(tuple, got.results[got.doc_offsets[d]:got.doc_offsets[d + 1], :7].tolist()))
-        b = sorted(map(tuple, ref.results[ref.doc_offsets[d]:ref.doc_offsets[d + 1], :7].tolist()))
-        assert a == b, d
+        assert _sorted_results(got, d) == _sorted_results(ref, d), d
