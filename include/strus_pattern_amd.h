@@ -230,7 +230,7 @@ int sp_matcher_ctx_batch_counters(sp_matcher_ctx_t* c, uint64_t counters[8]);
 /* duration of the last rule-automaton kernel in milliseconds (HIP events on the launch stream) */
 double sp_matcher_ctx_last_kernel_ms(sp_matcher_ctx_t* c);
 /* which kernel the context runs its batches on: 0 general automaton, 1 LDS-resident automaton (flat rule sets),
- * 2 the opt-in join prototype (environment SPA_L2_JOIN=1 at context creation; result SETS only) */
+ * 2 the opt-in join prototype (environment SPA_L2_JOIN=1 at context creation; result SETS with their items, no statistics) */
 int sp_matcher_ctx_kernel_kind(const sp_matcher_ctx_t* c);
 /* copies the per-document status words of the last batch to the host (waits for the stream) */
 int sp_matcher_ctx_batch_status(sp_matcher_ctx_t* c, int32_t* status, size_t ndocs);
