@@ -326,7 +326,7 @@ class PatternMatcher:
     """PatternMatcherInterface (src/patternMatcher.hpp:31-35)."""
 
     def getCompileOptionNames(self):
-        return ["stopwordOccurrenceFactor", "weightFactor", "maxRange", "exclusive"]  # src/patternMatcher.cpp:707-716
+        return ["stopwordOccurrenceFactor", "weightFactor", "maxRange", "exclusive", "maxResultSize"]  # src/patternMatcher.cpp:707-716
 
     def createInstance(self):
         return PatternMatcherInstance()

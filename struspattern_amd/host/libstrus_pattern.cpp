@@ -304,7 +304,7 @@ public:
 	explicit Matcher( ErrorBufferInterface* e) :m_errorhnd(e){}
 	virtual std::vector<std::string> getCompileOptionNames() const
 	{
-		static const char* ar[] = {"stopwordOccurrenceFactor", "weightFactor", "maxRange", "exclusive", 0};	// src/patternMatcher.cpp:707-716
+		static const char* ar[] = {"stopwordOccurrenceFactor", "weightFactor", "maxRange", "exclusive", "maxResultSize", 0};	// src/patternMatcher.cpp:707-716
 		std::vector<std::string> rt;
 		for (int i=0; ar[i]; ++i) rt.push_back( ar[i]);
 		return rt;

@@ -212,8 +212,20 @@ int main( int argc, const char** argv)
 {
 	try
 	{
-		if (argc < 4) { std::cerr << "usage: testStrusInterface <simple fixture> <regex fixture> <module .so>" << std::endl; return 2; }
 		ErrorBuffer err;
+		if (argc == 2 && !strcmp( argv[1], "--options"))
+		{
+			// the option name lists of both interfaces, one per line (no GPU needed): tests/test_host_shim.py compares them
+			// with the reference's (src/patternLexer.cpp:1154-1163, src/patternMatcher.cpp:707-716)
+			std::unique_ptr<strus::PatternMatcherInterface> pt( strus::createPatternMatcher_std( &err));
+			std::unique_ptr<strus::PatternLexerInterface> pl( strus::createPatternLexer_std( &err));
+			if (!pt.get() || !pl.get()) throw std::runtime_error( "failed to create the interfaces");
+			std::vector<std::string> lo = pl->getCompileOptionNames(), mo = pt->getCompileOptionNames();
+			for (size_t i=0; i<lo.size(); ++i) std::cout << "lexer\t" << lo[i] << std::endl;
+			for (size_t i=0; i<mo.size(); ++i) std::cout << "matcher\t" << mo[i] << std::endl;
+			return 0;
+		}
+		if (argc < 4) { std::cerr << "usage: testStrusInterface <simple fixture> <regex fixture> <module .so> | --options" << std::endl; return 2; }
 		// 1. through the exported factory functions (libstrus_pattern)
 		std::unique_ptr<strus::PatternMatcherInterface> pt( strus::createPatternMatcher_std( &err));
 		std::unique_ptr<strus::PatternLexerInterface> pl( strus::createPatternLexer_std( &err));

@@ -23,6 +23,24 @@ def test_module_exports_reference_symbols():
     assert "createPatternLexer_std" in out and "createPatternMatcher_std" in out   # include/strus/lib/pattern.hpp:27-32
 
 
+def test_compile_option_names_equal_the_references():
+    """getCompileOptionNames of both interfaces, C++ shim and Python mirror, against the reference's lists
+    (tests/golden/option_names.json <- src/patternLexer.cpp:1154-1163, src/patternMatcher.cpp:707-716)."""
+    import json
+    import struspattern_amd as spa
+    with open(os.path.join(os.path.dirname(__file__), "golden", "option_names.json")) as f:
+        want = json.load(f)
+    assert spa.PatternLexer().getCompileOptionNames() == want["lexer"]
+    assert spa.PatternMatcher().getCompileOptionNames() == want["matcher"]
+    lib, module, testbin = _built()
+    out = subprocess.check_output([testbin, "--options"], text=True)
+    got = {"lexer": [], "matcher": []}
+    for ln in out.splitlines():
+        k, v = ln.split("\t")
+        got[k].append(v)
+    assert got["lexer"] == want["lexer"] and got["matcher"] == want["matcher"]
+
+
 def _write_fixtures(tmp, regex_case=0):
     case = l2_cases.load("simple_token_pattern_match.json")
     simple = os.path.join(tmp, "simple.txt")
