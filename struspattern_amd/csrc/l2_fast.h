@@ -8,8 +8,9 @@
 // the document's lexem array, nothing is reference counted, nothing is joined.  For such rule sets
 // (the reference's own benchmark shape, tests/randomTokenPatternMatch, and the token-rule stage of the
 // pipeline) the whole hot state of a document -- rule words, trigger buckets, expiry lists, stop-word
-// log -- fits a few KB and lives in LDS; HBM sees the lexems once, a 16-byte write-once record per rule
-// instance and the results.
+// log -- fits a few KB and lives in LDS; HBM sees the lexems once, the install lines (one cache-resident 64-byte
+// line per installed program) and the results.  A rule instance has a record in HBM only when it captured
+// something the key lexem and its install line do not tell (round 3; a 32-byte record per instance before).
 #ifndef SPA_L2_FAST_H
 #define SPA_L2_FAST_H
 #include <stdint.h>
@@ -29,15 +30,101 @@ struct FastKeyInst			// 64 B
 	uint32_t meta;			// initvalue(4) | initcount(5)<<4 | range(6)<<9 | ntrig(2)<<15 | pastStopIdx(8)<<17
 	struct { uint32_t event; uint32_t info; } trig[ 3];	// installation order (= last expression argument first)
 					// info: sigval(4) | sigtype(3)<<4 | install(1)<<7 | key(1)<<8 | bucket(4)<<9 | hasVar(1)<<13 | delStopIdx(8)<<14 | variable(8)<<24
-	uint32_t program;		// index into DevProgram[] (diagnostics)
-	uint32_t _pad[ 5];
+	// ---- STATIC INSTALL (round 3).  For a program that is not alternative-keyed, everything installProgram does
+	// except the absolute positions is decided by the (key event, program) pair alone: the slot after the key trigger(s)
+	// have fired, whether a result / a dispose entry is due at once, and -- because the 64 programs of a batch are
+	// the key list entries [kiBegin + 64 b, ..) whatever the document -- the RANK of every record the batch appends
+	// (bucket entries per bucket, expiry row entries per range, results, dispose entries).  The host simulates the key
+	// fires (fireLocal below, the very function the kernel runs for the dynamic cases) and counts the ranks, so a
+	// static batch needs no simulation, no prefix sum and no ballot on the device.
+	uint32_t hw0;			// rule word after the key fires: value | count | done | active | trigger mask | nItems | hasStart (end bits excluded)
+	uint32_t ranksA;		// expRank(8) | expClose(8): members of my expiry group if I am its last lane, else 0 | resRank(8) | dispRank(8)
+	uint32_t ranksB;		// bRank0(8) | bRank1(8) | bRank2(8): rank of my template j among the batch's entries of its bucket | bLast(3)<<24: template j is its bucket's last
+	uint32_t totals;		// of the batch: installed triggers(8) | key fires(8) | results(8) | dispose entries(8)
+	uint32_t items;			// var0 | var1<<8 | var2<<16 (capture order) | items of the batch's immediate results (8)<<24
+	uint32_t flags;			// FKF_*
 };
 enum {
 	FKI_VALUE_MASK=0xFu, FKI_COUNT_SHIFT=4, FKI_COUNT_MASK=0x1Fu, FKI_RANGE_SHIFT=9, FKI_RANGE_MASK=0x3Fu,
 	FKI_NTRIG_SHIFT=15, FKI_NTRIG_MASK=0x3u, FKI_PASTSTOP_SHIFT=17, FKI_PASTSTOP_MASK=0xFFu,
 	FTI_SIGVAL_MASK=0xFu, FTI_SIGTYPE_SHIFT=4, FTI_SIGTYPE_MASK=0x7u, FTI_INSTALL=1u<<7, FTI_KEY=1u<<8,
-	FTI_BUCKET_SHIFT=9, FTI_HASVAR=1u<<13, FTI_DELSTOP_SHIFT=14, FTI_DELSTOP_MASK=0xFFu, FTI_VAR_SHIFT=24
+	FTI_BUCKET_SHIFT=9, FTI_HASVAR=1u<<13, FTI_DELSTOP_SHIFT=14, FTI_DELSTOP_MASK=0xFFu, FTI_VAR_SHIFT=24,
+	FKF_BATCH_STATIC=1u,		// every line of my 64-lane batch is static: the batch takes the static path
+	FKF_END_SET=2u,			// a key fire took the event: end_ordpos = position + 1
+	FKF_START_SET=4u,		// ... and set the start of the match to the key lexem
+	FKF_RESULT_NOW=8u,		// the key fire completes the rule and the pattern is visible: a result at once
+	FKF_DISPOSE_NOW=16u		// finished or deleted by its own key event
 };
+// rule word of the fast tier (LDS, u32 per rule instance)
+enum {
+	H_VALUE_MASK=0xFu, H_COUNT_SHIFT=4, H_COUNT_MASK=0x1Fu, H_END_SHIFT=9, H_END_MASK=0xFFu, H_ENDZERO=1u<<17,
+	H_DONE=1u<<18, H_ACTIVE=1u<<19, H_TMASK_SHIFT=20, H_TMASK_MASK=0x7u, H_NITEMS_SHIFT=23, H_NITEMS_MASK=0x3u, H_HASSTART=1u<<25,
+	H_COLD=1u<<26,			// start of the match and captured items are in the rule's record in HBM (else: the key lexem + the static line)
+	H_LISTED=1u<<27			// already in the dispose list of the current transition
+};
+
+// ---- a fresh slot while its program is being installed: the alternative-key replay and the key triggers fire before
+// anything is stored.  Shared by the kernel (dynamic batches) and the host (static lines).
+enum {S_HASSTART=1u, S_DONE=2u, S_FIN=4u, S_DEL=8u, S_ODD=16u, S_RESULT=32u, S_HASLIST=64u, S_TOOK=128u};
+struct Sim
+{
+	uint32_t value, count, end, startLex, nItems, it0, it1, it2, nFires, flags;
+	// S_HASLIST: the result shares the rule's item list only if the list existed when the rule matched (cpp:941-953):
+	// items captured later join that list (and show in the result), or start a list the result never sees
+};
+SPA_HD static inline void fireLocal( Sim& s, uint32_t info, uint32_t esord, uint32_t elex, uint32_t withItems)
+{
+	const uint32_t sigtype = (info >> FTI_SIGTYPE_SHIFT) & FTI_SIGTYPE_MASK, sigval = info & FTI_SIGVAL_MASK;
+	uint32_t m = 0, f = 0, took = 0;
+	s.nFires += 1;
+	if (sigtype == SIG_ANY)
+	{
+		took = 1;
+		if (s.count > 0) { m = 1; s.count -= 1; f = (s.count == 0); if (s.end < esord+1) s.end = esord+1; }
+	}
+	else if (sigtype == SIG_SEQUENCE || sigtype == SIG_SEQUENCE_IMM)
+	{
+		if (sigval == s.value && (sigtype == SIG_SEQUENCE ? (s.end <= esord) : (s.end == esord)))
+		{
+			s.end = esord+1; s.value = sigval-1;
+			if (s.count > 0) { s.count -= 1; m = (s.count == 0); } else m = 1;
+			f = (s.value == 0); took = 1;
+		}
+	}
+	else if (sigtype == SIG_WITHIN)
+	{
+		if ((sigval & s.value) != 0 && s.end <= esord)
+		{
+			s.end = esord+1; s.value &= ~sigval;
+			if (s.count > 0) { s.count -= 1; m = (s.count == 0); } else m = 1;
+			took = 1;
+		}
+	}
+	else	// SIG_DEL: the rule goes to the dispose list, nothing else happens (cpp:868-876)
+	{
+		s.count = 0; s.value = 0; s.flags |= S_DEL;
+		return;
+	}
+	if (took)
+	{
+		if ((info & FTI_HASVAR) && withItems)
+		{
+			const uint32_t item = elex | ((info >> FTI_VAR_SHIFT) << 24);
+			if ((s.flags & S_DONE) && !(s.flags & S_HASLIST)) {}
+			else if (s.nItems == 0) { s.it0 = item; s.nItems = 1; }
+			else if (s.nItems == 1) { s.it1 = item; s.nItems = 2; }
+			else if (s.nItems == 2) { s.it2 = item; s.nItems = 3; }
+			else s.flags |= S_ODD;
+		}
+		if (!(s.flags & S_HASSTART)) { s.startLex = elex; s.flags |= S_TOOK; if (esord) s.flags |= S_HASSTART; }
+	}
+	if (m)
+	{
+		if (!(s.flags & S_DONE)) { s.flags |= S_DONE | S_RESULT; if (s.nItems) s.flags |= S_HASLIST; }
+		if (f) s.flags |= S_FIN;
+	}
+}
+
 // hash table over key events and stop words (open addressing, keyHash of l2_tables.h)
 struct FastKeyEntry			// 16 B
 {
@@ -51,7 +138,7 @@ struct FastKeyEntry			// 16 B
 // instance per capacity pair.  R = rule instances whose hot state is in LDS, T = trigger-bucket entries in LDS.
 // Rule ids >= R and bucket positions beyond a bucket's LDS region live in the wave's spill area in HBM, so a
 // burst (a frequent word that keys hundreds of programs) slows a document down instead of failing it.
-enum {FAST_LISTCAP=128, FAST_EXPCAP=1024, FAST_MAXSTOP=64, FAST_SPILL_BUCKET=1024, FAST_VARIANTS=5};
+enum {FAST_LISTCAP=128, FAST_EXPCAP=1024, FAST_MAXSTOP=64, FAST_SPILL_BUCKET=1024, FAST_VARIANTS=5, FAST_RQCAP=192};
 
 struct FastSpillLayout			// per-wave spill + cold area in HBM, offsets in u32 words
 {
@@ -59,6 +146,7 @@ struct FastSpillLayout			// per-wave spill + cold area in HBM, offsets in u32 wo
 	uint32_t oCold;			// u32[8*maxRules]  {resultHandle, formatHandle, first taken lexem, item0, item1, item2, -, -}, item = lexem | variable<<24:
 					// written when the rule is installed / takes an event, read when it matches after its installation
 	uint32_t oHot, oLink;	// spill rules (ids R..maxRules): same shapes as in LDS (u32 per element here)
+	uint32_t oKi, oLex0;		// ... their install line and key lexem
 	uint32_t oFree;			// u32[maxRules]  stack of free spill ids
 	uint32_t oEnt;			// {event, ts} per spill bucket entry: 16 rows of FAST_SPILL_BUCKET
 	uint32_t oStaged;		// staged results, 8 words each

@@ -18,10 +18,13 @@
 //         expiry list heads; the stop-word log {lexem index, ordpos, timestamp}; the dispose list.
 //         The layout is static (one kernel instance per capacity pair): every access is a ds instruction with an
 //         immediate offset.
-//   HBM   per rule instance ONE write-once 32-byte record {result handle, format, first taken lexem, <= 3 captured
-//         items as lexem index | variable}, read only if the rule matches after its installation; staged results
-//         (32 B) expanded to sp_result_t / sp_result_item_t records at the document's end; a spill area for rule
-//         ids and bucket positions beyond the LDS capacities.
+//         Since round 3 also the rule's install line (index into FastKeyInst[]) and its key lexem: what a rule has
+//         captured when it is installed -- result handle, format, start of the match, the key trigger's item -- follows
+//         from those two, so nothing is written to HBM for a rule that expires untouched (85 % of them).
+//   HBM   a 32-byte record {result handle, format, first taken lexem, <= 3 captured items as lexem index | variable}
+//         ONLY for a rule that takes an event without completing (H_COLD) or was installed by a dynamic batch; staged
+//         results (32 B) expanded to sp_result_t / sp_result_item_t records at the document's end; a spill area for
+//         rule ids and bucket positions beyond the LDS capacities.
 // Two instances of every step: the normal one touches LDS only; while a burst (a frequent word that keys
 // hundreds of programs) has rule ids or bucket entries in the spill area the document runs the instance whose
 // accessors look at both places (wave-uniform switch, checked when the position advances).
@@ -57,11 +60,6 @@ __device__ __forceinline__ KP kernelParams() { return *(const __attribute__((add
 // wave execute in order; the fence keeps the compiler from moving or reusing accesses across the point
 #define WAVE_FENCE() __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront")
 
-// rule word
-enum {
-	H_VALUE_MASK=0xFu, H_COUNT_SHIFT=4, H_COUNT_MASK=0x1Fu, H_END_SHIFT=9, H_END_MASK=0xFFu, H_ENDZERO=1u<<17,
-	H_DONE=1u<<18, H_ACTIVE=1u<<19, H_TMASK_SHIFT=20, H_TMASK_MASK=0x7u, H_NITEMS_SHIFT=23, H_NITEMS_MASK=0x3u, H_HASSTART=1u<<25
-};
 enum {NIL16=0xFFFFu};
 
 // Phase profile (make PROF=1): wave-cycles per phase summed into P.prof[0..7]
@@ -130,82 +128,23 @@ __device__ __forceinline__ bool endLE( u32 hw, u32 pos) { return (hw & H_ENDZERO
 __device__ __forceinline__ bool endEQ( u32 hw, u32 pos) { return (hw & H_ENDZERO) ? (pos == 0) : (((hw >> H_END_SHIFT) & H_END_MASK) == (pos & 0xFFu)); }
 __device__ __forceinline__ u32 withEnd( u32 hw, u32 end) { return (hw & ~((H_END_MASK << H_END_SHIFT) | H_ENDZERO)) | ((end & 0xFFu) << H_END_SHIFT); }
 
-// ---------------------------------------------------------------- a fresh slot while its program is being installed
-// (registers only: the alternative-key replay and the key triggers fire before anything is stored)
-enum {S_HASSTART=1u, S_DONE=2u, S_FIN=4u, S_DEL=8u, S_ODD=16u, S_RESULT=32u, S_HASLIST=64u};
-struct Sim
-{
-	u32 value, count, end, startLex, nItems, it0, it1, it2, nFires, flags;
-	// S_HASLIST: the result shares the rule's item list only if the list existed when the rule matched (cpp:941-953):
-	// items captured later join that list (and show in the result), or start a list the result never sees
-};
-__device__ __forceinline__ void fireLocal( Sim& s, u32 info, u32 esord, u32 elex, u32 withItems)
-{
-	const u32 sigtype = (info >> FTI_SIGTYPE_SHIFT) & FTI_SIGTYPE_MASK, sigval = info & FTI_SIGVAL_MASK;
-	u32 m = 0, f = 0, took = 0;
-	s.nFires += 1;
-	if (sigtype == SIG_ANY)
-	{
-		took = 1;
-		if (s.count > 0) { m = 1; s.count -= 1; f = (s.count == 0); if (s.end < esord+1) s.end = esord+1; }
-	}
-	else if (sigtype == SIG_SEQUENCE || sigtype == SIG_SEQUENCE_IMM)
-	{
-		if (sigval == s.value && (sigtype == SIG_SEQUENCE ? (s.end <= esord) : (s.end == esord)))
-		{
-			s.end = esord+1; s.value = sigval-1;
-			if (s.count > 0) { s.count -= 1; m = (s.count == 0); } else m = 1;
-			f = (s.value == 0); took = 1;
-		}
-	}
-	else if (sigtype == SIG_WITHIN)
-	{
-		if ((sigval & s.value) != 0 && s.end <= esord)
-		{
-			s.end = esord+1; s.value &= ~sigval;
-			if (s.count > 0) { s.count -= 1; m = (s.count == 0); } else m = 1;
-			took = 1;
-		}
-	}
-	else	// SIG_DEL: the rule goes to the dispose list, nothing else happens (cpp:868-876)
-	{
-		s.count = 0; s.value = 0; s.flags |= S_DEL;
-		return;
-	}
-	if (took)
-	{
-		if ((info & FTI_HASVAR) && withItems)
-		{
-			const u32 item = elex | ((info >> FTI_VAR_SHIFT) << 24);
-			if ((s.flags & S_DONE) && !(s.flags & S_HASLIST)) {}
-			else if (s.nItems == 0) { s.it0 = item; s.nItems = 1; }
-			else if (s.nItems == 1) { s.it1 = item; s.nItems = 2; }
-			else if (s.nItems == 2) { s.it2 = item; s.nItems = 3; }
-			else s.flags |= S_ODD;
-		}
-		if (!(s.flags & S_HASSTART)) { s.startLex = elex; if (esord) s.flags |= S_HASSTART; }
-	}
-	if (m)
-	{
-		if (!(s.flags & S_DONE)) { s.flags |= S_DONE | S_RESULT; if (s.nItems) s.flags |= S_HASLIST; }
-		if (f) s.flags |= S_FIN;
-	}
-}
-
 // ---------------------------------------------------------------- LDS image of a document (static layout)
 template <int R, int T>
 struct LdsDoc
 {
 	u32 hot[ R];			// rule word
+	u32 ki[ R];			// install line of the rule (FastKeyInst index)
+	u32 lex0[ R];			// its key lexem (index inside the document)
 	u64 ent[ T];			// bucket entries: event id | (trigger id (rule<<2 | slot) | signal byte << 16 | variable << 24) << 32; bucket h owns [base_h, base_h + cap_h)
 	u32 bsize[ 16];			// bucket sizes
 	u32 bmeta[ 16];			// base_h | cap_h << 16
 	u32 stop[ 3*FAST_MAXSTOP];	// stop-word log {lexem index, ordpos, timestamp}
-	u16 link[ 3*R];			// bucket << 12 | position of trigger slot j of rule r at [3r+j]
+	u16 link[ 4*R];			// bucket << 12 | position of trigger slot j of rule r at [4r+j] (one 8-byte read per rule)
 	u16 freeS[ R];			// stack of free rule ids < R
 	u16 exp[ FAST_EXPCAP];		// expiry lists: row (position & (W-1)) holds the rules that expire at that position, in definition order
 	u16 expCnt[ 64];		// their lengths
 	u16 list[ FAST_LISTCAP];	// dispose list of the current transition
+	u16 rq[ FAST_RQCAP];		// removal queue: the triggers (rule << 2 | slot) of a deactivation batch grouped by bucket, in removal order
 };
 
 // per-document scalars (wave-uniform registers)
@@ -232,8 +171,17 @@ typedef __attribute__((address_space(3))) Lds& LR;
 // ---- rule fields: ids < R in LDS, others in the spill area (same shapes).  SP=false: LDS only.
 template <bool SP> static __device__ __forceinline__ u32 ldHot( LR L, const Wave& w, KP P, u32 r) { if (!SP || r < (u32)R) return L.hot[ r]; return w.sp[ P.spill.oHot + (r - R)]; }
 template <bool SP> static __device__ __forceinline__ void stHot( LR L, const Wave& w, KP P, u32 r, u32 v) { if (!SP || r < (u32)R) L.hot[ r] = v; else w.sp[ P.spill.oHot + (r - R)] = v; }
-template <bool SP> static __device__ __forceinline__ u32 ldLink( LR L, const Wave& w, KP P, u32 r, u32 j) { if (!SP || r < (u32)R) return (u32)L.link[ 3*r + j]; return w.sp[ P.spill.oLink + 3*(r - R) + j]; }
-template <bool SP> static __device__ __forceinline__ void stLink( LR L, const Wave& w, KP P, u32 r, u32 j, u32 v) { if (!SP || r < (u32)R) L.link[ 3*r + j] = (u16)v; else w.sp[ P.spill.oLink + 3*(r - R) + j] = v; }
+template <bool SP> static __device__ __forceinline__ u32 ldLink( LR L, const Wave& w, KP P, u32 r, u32 j) { if (!SP || r < (u32)R) return (u32)L.link[ 4*r + j]; return w.sp[ P.spill.oLink + 3*(r - R) + j]; }
+template <bool SP> static __device__ __forceinline__ void stLink( LR L, const Wave& w, KP P, u32 r, u32 j, u32 v) { if (!SP || r < (u32)R) L.link[ 4*r + j] = (u16)v; else w.sp[ P.spill.oLink + 3*(r - R) + j] = v; }
+template <bool SP> static __device__ __forceinline__ void ldLinks( LR L, const Wave& w, KP P, u32 r, u32& l0, u32& l1, u32& l2)
+{
+	if (!SP || r < (u32)R) { const u64 v = *(const __attribute__((address_space(3))) u64*)&L.link[ 4*r]; l0 = (u32)v & 0xFFFFu; l1 = ((u32)v >> 16); l2 = (u32)(v >> 32) & 0xFFFFu; }
+	else { const u32* q = &w.sp[ P.spill.oLink + 3*(r - R)]; l0 = q[0]; l1 = q[1]; l2 = q[2]; }
+}
+template <bool SP> static __device__ __forceinline__ u32 ldKi( LR L, const Wave& w, KP P, u32 r) { if (!SP || r < (u32)R) return L.ki[ r]; return w.sp[ P.spill.oKi + (r - R)]; }
+template <bool SP> static __device__ __forceinline__ u32 ldLex0( LR L, const Wave& w, KP P, u32 r) { if (!SP || r < (u32)R) return L.lex0[ r]; return w.sp[ P.spill.oLex0 + (r - R)]; }
+template <bool SP> static __device__ __forceinline__ void stKiLex( LR L, const Wave& w, KP P, u32 r, u32 ki, u32 lx)
+{ if (!SP || r < (u32)R) { L.ki[ r] = ki; L.lex0[ r] = lx; } else { w.sp[ P.spill.oKi + (r - R)] = ki; w.sp[ P.spill.oLex0 + (r - R)] = lx; } }
 // ---- expiry rows: entry i of row `row` sits in LDS while i < C = FAST_EXPCAP >> expShift, else in the row's spill part
 template <bool SP> static __device__ __forceinline__ u32 ldExp( LR L, const Wave& w, KP P, u32 row, u32 i)
 { const u32 C = (u32)FAST_EXPCAP >> P.expShift; if (!SP || i < C) return (u32)L.exp[ row*C + i]; return w.sp[ P.spill.oExp + row*P.spill.maxRules + (i - C)]; }
@@ -268,7 +216,11 @@ static __device__ __forceinline__ void stageResult( Wave& w, KP P, u32 at, u32 h
 }
 
 // ---------------------------------------------------------------- fireSignal (cpp:772-979) on an installed trigger
-// uniform: every lane computes the same; stores by lane 0
+// uniform: every lane computes the same; stores by lane 0.
+// What the rule has captured so far (start of the match, items) is not stored anywhere while it is what the install
+// line says for the key lexem (!H_COLD): it is rebuilt here when the rule completes -- one read of the line, which the
+// result needs anyway for its handle -- and written to the rule's record in HBM only if the rule takes this event and
+// goes on waiting (programs of three triggers, cardinalities).
 template <bool SP>
 static __device__ __forceinline__ void fireSignal( LR L, Wave& w, KP P, u32 tsv, u32 sord)
 {
@@ -303,13 +255,17 @@ static __device__ __forceinline__ void fireSignal( LR L, Wave& w, KP P, u32 tsv,
 			break;
 		default: // SIG_DEL
 			hw &= ~(H_VALUE_MASK | (H_COUNT_MASK << H_COUNT_SHIFT));
+			if (!(hw & H_LISTED))
+			{
+				// (a rule is listed once per transition: of two entries only the first would act, cpp:679-702)
+				if (w.nDispose < P.spill.maxRules) { pushList( L, w, P, w.nDispose, r); w.nDispose += 1; hw |= H_LISTED; } else FALLBACK( FB_DISPOSE);
+			}
 			if (LANE == 0) stHot<SP>( L, w, P, r, hw);
-			if (w.nDispose < P.spill.maxRules) { pushList( L, w, P, w.nDispose, r); w.nDispose += 1; } else FALLBACK( FB_DISPOSE);
 			return;
 	}
 	const bool done = (hw & H_DONE) != 0;
 	u32 nItems = (hw >> H_NITEMS_SHIFT) & H_NITEMS_MASK;
-	u32* cold = &w.sp[ P.spill.oCold + 8*r];		// {resultHandle, formatHandle, first taken lexem, item0, item1, item2, -, -}; item = lexem | variable<<24
+	bool newItem = false, newStart = false;
 	if (take)
 	{
 		if (hasVar && P.withItems)
@@ -320,61 +276,86 @@ static __device__ __forceinline__ void fireSignal( LR L, Wave& w, KP P, u32 tsv,
 				// existed when the result was made (cpp:941-953 share the reference) -- not expressible here
 				if (nItems) { FALLBACK( FB_ITEM_AFTER_RESULT); return; }
 			}
-			else if (nItems < 3u)
-			{
-				if (LANE == 0) cold[ 3+nItems] = w.lbase | (variable << 24);
-				++nItems;
-			}
+			else if (nItems < 3u) newItem = true;
 			else { FALLBACK( FB_ITEMS); return; }
 		}
-		if (!(hw & H_HASSTART))
-		{
-			if (LANE == 0) cold[ 2] = w.lbase;
-			if (sord) hw |= H_HASSTART;		// (a start at ordinal position 0 counts as unset, cpp:919)
-		}
+		newStart = !(hw & H_HASSTART);
 	}
-	hw = (hw & ~(H_VALUE_MASK | (H_COUNT_MASK << H_COUNT_SHIFT) | (H_NITEMS_MASK << H_NITEMS_SHIFT))) | value | (count << H_COUNT_SHIFT) | (nItems << H_NITEMS_SHIFT);
-	if (match && !done) hw |= H_DONE;
-	if (LANE == 0) stHot<SP>( L, w, P, r, hw);
-	if (match)
+	if (!done && (match || newItem || newStart))
 	{
-		if (!done)
+		// ---- what the rule has captured: its record, or the key lexem + the install line
+		u32* cold = &w.sp[ P.spill.oCold + 8*r];		// {resultHandle, formatHandle, first taken lexem, item0, item1, item2, -, -}; item = lexem | variable<<24
+		u32 handle, fmt, startLex, it0, it1, it2;
+		if (hw & H_COLD)
 		{
-			// the rule's write-once record: one round trip, nothing else is read from HBM on a match
-			WAVE_FENCE();
 			const uint4 c0 = ldu4( cold), c1 = ldu4( cold + 4);		// written by this wave (same-wave store -> load)
-			if (c0.x)
+			handle = c0.x; fmt = c0.y; startLex = c0.z; it0 = c0.w; it1 = c1.x; it2 = c1.y;
+		}
+		else
+		{
+			const u32 ki = bcast0( ldKi<SP>( L, w, P, r)), lx = bcast0( ldLex0<SP>( L, w, P, r));
+			const u32* K = (const u32*)&P.keyinst[ ki];
+			handle = ldu( K); fmt = ldu( K+1);
+			const u32 vars = ldu( K+14);
+			startLex = lx;		// (a static line is installed at a position != 0: a key fire that took set the start)
+			it0 = lx | ((vars & 0xFFu) << 24); it1 = lx | (((vars >> 8) & 0xFFu) << 24); it2 = lx | (((vars >> 16) & 0xFFu) << 24);
+		}
+		if (newItem)
+		{
+			const u32 item = w.lbase | (variable << 24);
+			if (nItems == 0) it0 = item; else if (nItems == 1) it1 = item; else it2 = item;
+			++nItems;
+		}
+		if (newStart) startLex = w.lbase;
+		if (match)
+		{
+			if (handle)
 			{
 				if (w.nStaged < P.spill.maxStaged)
 				{
 					// items latest first
-					const u32 ia = nItems == 3 ? c1.y : nItems == 2 ? c1.x : c0.w;
-					const u32 ib = nItems == 3 ? c1.x : c0.w;
-					const u32 ic = c0.w;
+					const u32 ia = nItems == 3 ? it2 : nItems == 2 ? it1 : it0;
+					const u32 ib = nItems == 3 ? it1 : it0;
+					const u32 ic = it0;
 					const u32 vars = nItems == 0 ? 0u : nItems == 1 ? (ia >> 24) : nItems == 2 ? ((ia >> 24) | ((ib >> 24) << 8)) : ((ia >> 24) | ((ib >> 24) << 8) | ((ic >> 24) << 16));
-					if (LANE == 0) stageResult( w, P, w.nStaged, c0.x, c0.y, c0.z, w.lbase, nItems, vars, ia & 0xFFFFFFu, ib & 0xFFFFFFu, ic & 0xFFFFFFu);
+					if (LANE == 0) stageResult( w, P, w.nStaged, handle, fmt, startLex, w.lbase, nItems, vars, ia & 0xFFFFFFu, ib & 0xFFFFFFu, ic & 0xFFFFFFu);
 					w.nStaged += 1; w.nStagedItems += nItems;
 				}
 				else FALLBACK( FB_STAGED);
 			}
 		}
-		if (fin)
+		else
 		{
-			if (w.nDispose < P.spill.maxRules) { pushList( L, w, P, w.nDispose, r); w.nDispose += 1; } else FALLBACK( FB_DISPOSE);
+			// the rule goes on waiting with more than its install line tells: its record takes over
+			if (LANE == 0) { st4( cold, handle, fmt, startLex, it0); *(uint2*)(cold + 4) = make_uint2( it1, it2); }
+			hw |= H_COLD;
+			WAVE_FENCE();
 		}
 	}
+	if (newStart && sord) hw |= H_HASSTART;		// (a start at ordinal position 0 counts as unset, cpp:919)
+	hw = (hw & ~(H_VALUE_MASK | (H_COUNT_MASK << H_COUNT_SHIFT) | (H_NITEMS_MASK << H_NITEMS_SHIFT))) | value | (count << H_COUNT_SHIFT) | (nItems << H_NITEMS_SHIFT);
+	if (match && !done) hw |= H_DONE;
+	if (match && fin && !(hw & H_LISTED))
+	{
+		if (w.nDispose < P.spill.maxRules) { pushList( L, w, P, w.nDispose, r); w.nDispose += 1; hw |= H_LISTED; } else FALLBACK( FB_DISPOSE);
+	}
+	if (LANE == 0) stHot<SP>( L, w, P, r, hw);
 }
 
 // ---------------------------------------------------------------- deactivation of a list of rules
 // deactivateRule (cpp:679-702) for n rules in list order; freeIds: disposeRule (cpp:704-708).  The list is the
-// dispose list of the transition (EXPROW = false) or, last defined first, the expiry row of a position.
-// The only order-dependent part is the swap-with-last removal of the rules' triggers from the 16 buckets:
-// removals in different buckets do not interact, inside a bucket they must run in list order (rule by rule, a
-// rule's triggers last installed first).  Every lane takes a rule.  A prefix count per bucket gives every trigger
-// its rank among the batch's removals from its bucket; a bucket shrinks by one per removal, so a trigger's turn
-// has come exactly when its bucket has reached (size at the start - rank): no lane waits on anything but that.
+// dispose list of the transition (EXPROW = false; a rule is listed once, H_LISTED) or, last defined first, the
+// expiry row of a position.
+// The only order-dependent part is the swap-with-last removal of the rules' triggers from the 16 buckets
+// (cpp:133-152): removals in different buckets do not interact, inside a bucket they must run in list order (rule
+// by rule, a rule's triggers last installed first).  So: every lane takes a rule; a prefix count per bucket gives
+// every trigger its rank among the batch's removals from its bucket, which is its place in the bucket's part of a
+// removal queue in LDS; then LANE b REPLAYS BUCKET b's removals one after the other -- 16 buckets side by side, a
+// step is two dependent LDS reads and two stores by one lane.  (Round 2 let every rule's lane wait for its
+// trigger's turn: as many rounds of the whole wave as the fullest bucket has removals, 5 per event on the
+// pipeline workload -- the sentence delimiter's bucket holds a trigger of every *_struct instance.)
 template <bool SP, bool EXPROW>
-static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 n, u32 row, bool freeIds, bool mayRepeat)
+static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 n, u32 row, bool freeIds)
 {
 	for (u32 base=0; base<n && !w.err; base+=64)
 	{
@@ -386,84 +367,66 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 			r = EXPROW ? ldExp<SP>( L, w, P, row, n - 1u - (base + LANE)) : ldList<SP>( L, w, P, base + LANE);
 			hw = ldHot<SP>( L, w, P, r);
 		}
-		bool act = have && (hw & H_ACTIVE);
-		if (mayRepeat && nb > 1)
-		{
-			// the same rule may be listed twice (deleted and finished in one transition): only its first entry acts
-			for (u32 k=0; k+1<nb; ++k)
-			{
-				const u32 rk = (u32)__builtin_amdgcn_readlane( r, k);
-				if (LANE > k && r == rk) act = false;
-			}
-		}
-		u32 mask = act ? ((hw >> H_TMASK_SHIFT) & H_TMASK_MASK) : 0u;
+		const bool act = have && (hw & H_ACTIVE);
+		const u32 mask = act ? ((hw >> H_TMASK_SHIFT) & H_TMASK_MASK) : 0u;
 		if (act) stHot<SP>( L, w, P, r, hw & ~(H_ACTIVE | (H_TMASK_MASK << H_TMASK_SHIFT)));
 		if (__ballot( mask != 0))
 		{
-			// my triggers in removal order (slot 2, 1, 0): bucket, and the bucket size at which each one's turn comes
-			u32 hj[ 3], turn[ 3], metaj[ 3];
+			// my triggers' buckets; their number per bucket as packed byte counters (16 buckets x 8 bits in four words)
+			u32 lk[ 3] = {0,0,0};
+			if (mask) ldLinks<SP>( L, w, P, r, lk[ 0], lk[ 1], lk[ 2]);
 			u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
-			for (int j=2; j>=0; --j)
-			{
-				hj[ j] = 16u; metaj[ j] = 0;
-				if ((mask >> j) & 1u) { hj[ j] = ldLink<SP>( L, w, P, r, (u32)j) >> 12; byteInc( c0, c1, c2, c3, hj[ j]); metaj[ j] = L.bmeta[ hj[ j]]; }
-			}
-			const u32 e0 = waveScanAdd( c0) - c0, e1 = waveScanAdd( c1) - c1, e2 = waveScanAdd( c2) - c2, e3 = waveScanAdd( c3) - c3;	// (fields < 256: 64 x 3)
+			for (int j=0; j<3; ++j) if ((mask >> j) & 1u) byteInc( c0, c1, c2, c3, lk[ j] >> 12);
+			const u32 i0 = waveScanAdd( c0), i1 = waveScanAdd( c1), i2 = waveScanAdd( c2), i3 = waveScanAdd( c3);	// (fields < 256: 64 x 3)
+			const u32 e0 = i0 - c0, e1 = i1 - c1, e2 = i2 - c2, e3 = i3 - c3;
+			const u32 t0 = (u32)__builtin_amdgcn_readlane( i0, 63), t1 = (u32)__builtin_amdgcn_readlane( i1, 63);
+			const u32 t2 = (u32)__builtin_amdgcn_readlane( i2, 63), t3 = (u32)__builtin_amdgcn_readlane( i3, 63);
+			// the queue part of bucket b begins behind the parts of the buckets below it
+			const u32 tot = LANE < 16u ? byteField( t0, t1, t2, t3, LANE) : 0u;
+			const u32 qoff = waveScanAdd( tot) - tot;
+			const u32 total = (u32)__builtin_amdgcn_readlane( qoff + tot, 15);
+			// a rule's triggers go last installed first (slot 2, 1, 0)
 #pragma unroll
 			for (int j=2; j>=0; --j)
 			{
-				turn[ j] = 0;
+				const u32 h = lk[ j] >> 12;
+				const u32 qo = (u32)__builtin_amdgcn_ds_bpermute( (int)(h << 2), (int)qoff);	// (all lanes: the lanes that hold the offsets must take part)
 				if ((mask >> j) & 1u)
 				{
 					u32 mineBefore = 0;
 #pragma unroll
-					for (int jj=2; jj>j; --jj) if (((mask >> jj) & 1u) && hj[ jj] == hj[ j]) ++mineBefore;
-					turn[ j] = L.bsize[ hj[ j]] - (byteField( e0, e1, e2, e3, hj[ j]) + mineBefore);
+					for (int jj=2; jj>j; --jj) if (((mask >> jj) & 1u) && (lk[ jj] >> 12) == h) ++mineBefore;
+					L.rq[ qo + byteField( e0, e1, e2, e3, h) + mineBefore] = (u16)(4u*r + (u32)j);
 				}
 			}
-			u32 removed = 0;
-#ifdef SPA_PROF
-			const u64 prof_r0 = __builtin_amdgcn_s_memtime(); u32 prof_rounds = 0;
-#endif
-			for (u32 guard=0; guard<=3u*64u && __ballot( mask != 0); ++guard)
+			WAVE_FENCE();
+			if (LANE < 16u && tot)
 			{
-#ifdef SPA_PROF
-				++prof_rounds;
-#endif
-				// my next trigger: the highest remaining slot
-				const u32 j = mask ? (31u - (u32)__builtin_clz( mask)) : 0u;
-				const u32 h = j == 2 ? hj[ 2] : j == 1 ? hj[ 1] : hj[ 0];
-				const u32 myTurn = j == 2 ? turn[ 2] : j == 1 ? turn[ 1] : turn[ 0];
-				const u32 meta = j == 2 ? metaj[ 2] : j == 1 ? metaj[ 1] : metaj[ 0];
-				if (mask)
+				const u32 h = LANE, meta = L.bmeta[ h];
+				u32 size = L.bsize[ h];
+				for (u32 q=0; q<tot; ++q)
 				{
-					const u32 size = L.bsize[ h];
-					const u32 pos = ldLink<SP>( L, w, P, r, j) & 0xFFFu;	// (read beside the size: an earlier removal of this batch may have moved my trigger)
-					if (size == myTurn)
+					const u32 tid = (u32)L.rq[ qoff + q];
+					const u32 pos = ldLink<SP>( L, w, P, tid >> 2, tid & 3u) & 0xFFFu;	// (an earlier removal of this replay may have moved it)
+					const u32 last = size - 1u;
+					const uint2 m = ldEnt<SP>( L, w, P, h, meta, last);
+					if (pos != last)
 					{
 						// cpp:133-152: the bucket's last entry moves into the hole
-						const u32 last = size - 1u;
-						if (pos != last)
-						{
-							const uint2 m = ldEnt<SP>( L, w, P, h, meta, last);
-							stEnt<SP>( L, w, P, h, meta, pos, m.x, m.y);
-							stLink<SP>( L, w, P, (m.y & 0xFFFFu) >> 2, m.y & 3u, (h << 12) | pos);
-						}
-						L.bsize[ h] = last;
-						mask &= ~(1u << j);
-						++removed;
+						stEnt<SP>( L, w, P, h, meta, pos, m.x, m.y);
+						stLink<SP>( L, w, P, (m.y & 0xFFFFu) >> 2, m.y & 3u, (h << 12) | pos);
 					}
+					size = last;
+					if (SP) WAVE_FENCE();
 				}
-				WAVE_FENCE();
+				L.bsize[ h] = size;
 			}
+			WAVE_FENCE();
+			w.nTrig -= total;
 #ifdef SPA_PROF
-			w.prof[ 7] += __builtin_amdgcn_s_memtime() - prof_r0;
-			w.prof[ 8] += prof_rounds; w.prof[ 9] += 1; w.prof[ 10] += nb;
+			w.prof[ 8] += (u32)__builtin_amdgcn_readlane( waveScanMax( tot), 63); w.prof[ 9] += 1; w.prof[ 10] += nb;
 #endif
-			if (__ballot( mask != 0)) { w.err = SPD_ERR_INTERNAL; return; }
-			const u32 incl = waveScanAdd( removed);
-			w.nTrig -= (u32)__builtin_amdgcn_readlane( incl, 63);
 		}
 		if (freeIds)
 		{
@@ -494,7 +457,7 @@ static __device__ __forceinline__ void setCurrentPos( LR L, Wave& w, KP P, u32 p
 		if (n)
 		{
 			// the rules of this position, last defined first (the reference's list is LIFO)
-			if (w.spill) deactivateList<true,true>( L, w, P, n, row, true, false); else deactivateList<false,true>( L, w, P, n, row, true, false);
+			if (w.spill) deactivateList<true,true>( L, w, P, n, row, true); else deactivateList<false,true>( L, w, P, n, row, true);
 			if (LANE == 0) L.expCnt[ row] = 0;
 			WAVE_FENCE();
 		}
@@ -593,7 +556,7 @@ static __device__ __forceinline__ void installBatchT( LR L, Wave& w, KP P, u32 k
 	// ---- the rule itself
 	if (mat)
 	{
-		u32 hw = value | (count << H_COUNT_SHIFT) | H_ACTIVE | (tmask << H_TMASK_SHIFT) | (nItems << H_NITEMS_SHIFT);
+		u32 hw = value | (count << H_COUNT_SHIFT) | H_ACTIVE | H_COLD | (tmask << H_TMASK_SHIFT) | (nItems << H_NITEMS_SHIFT);	// (dynamic batch: start and items in the rule's record)
 		hw |= end ? ((end & 0xFFu) << H_END_SHIFT) : (u32)H_ENDZERO;
 		if (done) hw |= H_DONE;
 		if (hasStart) hw |= H_HASSTART;
@@ -643,6 +606,91 @@ static __device__ __forceinline__ void installBatchT( LR L, Wave& w, KP P, u32 k
 	WAVE_FENCE();
 }
 
+// The same for a STATIC batch (l2_fast.h): no program of it is alternative-keyed, so the host has fired the key
+// triggers and counted every rank; the lanes place their records and the wave adds the batch's totals.
+template <bool SP>
+static __device__ __forceinline__ void installStaticT( LR L, Wave& w, KP P, u32 ki0, u32 nb, u32 sord, u32 r,
+	const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3)
+{
+	const bool have = LANE < nb;
+	const u32 handle = q0.x, fmt = q0.y, meta = q0.w;
+	const u32 tEv[ 3] = {q1.x, q1.z, q2.x};
+	const u32 tInfo[ 3] = {q1.y, q1.w, q2.y};
+	const u32 hw0 = q2.z, ranksA = q2.w, ranksB = q3.x, fl = q3.w;
+	const u32 totals = bcast0( q3.y), itemsTotal = bcast0( q3.z) >> 24;		// (the same in every line of the batch)
+	const u32 range = (meta >> FKI_RANGE_SHIFT) & FKI_RANGE_MASK;
+	const u32 row = (sord + range) & ((1u << P.expShift) - 1u);
+	// ---- expiry row of position sord+range (cpp:1066-1082) and the triggers (cpp:1204-1250 -> EventTriggerTable::add :114-131)
+	u32 cnt = 0, oldB[ 3] = {0,0,0};
+	if (have)
+	{
+		cnt = (u32)L.expCnt[ row];
+		stExp<SP>( L, w, P, row, cnt + (ranksA & 0xFFu), r);
+#pragma unroll
+		for (int j=0; j<3; ++j)
+		{
+			if (tInfo[ j] & FTI_INSTALL)
+			{
+				const u32 h = (tInfo[ j] >> FTI_BUCKET_SHIFT) & 15u;
+				oldB[ j] = L.bsize[ h];
+				const u32 pos = oldB[ j] + ((ranksB >> (8*j)) & 0xFFu);
+				const u32 sv = (tInfo[ j] & FTI_SIGVAL_MASK) | (((tInfo[ j] >> FTI_SIGTYPE_SHIFT) & FTI_SIGTYPE_MASK) << 4) | ((tInfo[ j] & FTI_HASVAR) ? 0x80u : 0u);
+				stEnt<SP>( L, w, P, h, L.bmeta[ h], pos, tEv[ j], (4*r + (u32)j) | (sv << 16) | ((tInfo[ j] >> FTI_VAR_SHIFT) << 24));
+				stLink<SP>( L, w, P, r, (u32)j, (h << 12) | pos);
+			}
+		}
+	}
+	WAVE_FENCE();
+	const u32 nItems = P.withItems ? ((hw0 >> H_NITEMS_SHIFT) & H_NITEMS_MASK) : 0u;
+	if (have)
+	{
+		// the last lane of an expiry group / of a bucket's entries closes it (every lane has read the old counts above)
+		const u32 close = (ranksA >> 8) & 0xFFu;
+		if (close) L.expCnt[ row] = (u16)(cnt + close);
+#pragma unroll
+		for (int j=0; j<3; ++j)
+		{
+			if ((tInfo[ j] & FTI_INSTALL) && ((ranksB >> (24+j)) & 1u)) L.bsize[ (tInfo[ j] >> FTI_BUCKET_SHIFT) & 15u] = oldB[ j] + ((ranksB >> (8*j)) & 0xFFu) + 1u;
+		}
+		// ---- the rule itself: its word, its install line, its key lexem
+		u32 hw = (hw0 & ~(H_NITEMS_MASK << H_NITEMS_SHIFT)) | (nItems << H_NITEMS_SHIFT);
+		hw |= (fl & FKF_END_SET) ? (((sord + 1u) & 0xFFu) << H_END_SHIFT) : (u32)H_ENDZERO;
+		stHot<SP>( L, w, P, r, hw);
+		stKiLex<SP>( L, w, P, r, ki0 + LANE, w.lbase);
+	}
+	// ---- results (cpp:954-965), in lane order; the items are the key lexem under the key triggers' variables, latest first
+	const u32 nres = (totals >> 16) & 0xFFu;
+	if (nres)
+	{
+		if (w.nStaged + nres > P.spill.maxStaged) { FALLBACK( FB_STAGED); return; }
+		if (have && (fl & FKF_RESULT_NOW))
+		{
+			const u32 v0 = q3.z & 0xFFu, v1 = (q3.z >> 8) & 0xFFu, v2 = (q3.z >> 16) & 0xFFu;
+			const u32 va = nItems == 3 ? v2 : nItems == 2 ? v1 : v0;
+			const u32 vb = nItems == 3 ? v1 : v0;
+			const u32 vars = nItems == 0 ? 0u : nItems == 1 ? va : nItems == 2 ? (va | (vb << 8)) : (va | (vb << 8) | (v0 << 16));
+			stageResult( w, P, w.nStaged + ((ranksA >> 16) & 0xFFu), handle, fmt, (fl & FKF_START_SET) ? w.lbase : 0u, w.lbase, nItems, vars, w.lbase, w.lbase, w.lbase);
+		}
+		w.nStaged += nres;
+		if (P.withItems) w.nStagedItems += itemsTotal;
+	}
+	// ---- rules that finished or were deleted by their own key event: deactivated after the installs (cpp:1030-1034)
+	const u32 nd = totals >> 24;
+	if (nd)
+	{
+		if (w.nDispose + nd > P.spill.maxRules) { FALLBACK( FB_DISPOSE); return; }
+		if (w.nDispose + nd > (u32)FAST_LISTCAP) w.spill = 1;
+		if (have && (fl & FKF_DISPOSE_NOW))
+		{
+			const u32 at = w.nDispose + (ranksA >> 24);
+			if (at < (u32)FAST_LISTCAP) L.list[ at] = (u16)r; else w.sp[ P.spill.oList + at] = r;
+		}
+		w.nDispose += nd;
+	}
+	w.nTrig += totals & 0xFFu;
+	WAVE_FENCE();
+}
+
 static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb, u32 kc, u32 sord)
 {
 	// (requesting an event's install records one event ahead was measured: no gain -- the kernel is bound by the
@@ -651,12 +699,14 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 	{
 		const u32 nb = (kc - base) < 64u ? (kc - base) : 64u;
 		const bool have = LANE < nb;
-		uint4 q0 = make_uint4( 0,0,0,0), q1 = q0, q2 = q0;
+		uint4 q0 = make_uint4( 0,0,0,0), q1 = q0, q2 = q0, q3 = q0;
 		if (have)
 		{
 			const FastKeyInst* K = &P.keyinst[ kb + base + LANE];
-			q0 = ld4( K); q1 = ld4( (const u32*)K + 4); q2 = ld4( (const u32*)K + 8);
+			q0 = ld4( K); q1 = ld4( (const u32*)K + 4); q2 = ld4( (const u32*)K + 8); q3 = ld4( (const u32*)K + 12);
 		}
+		// a static batch at a position other than 0: the key fires and all ranks are in the lines (l2_fast.h)
+		const bool isStatic = (bcast0( q3.w) & FKF_BATCH_STATIC) != 0 && sord != 0;
 		const u32 pastEvent = q0.z, meta = q0.w;
 		const u32 tEv[ 3] = {q1.x, q1.z, q2.x};
 		const u32 tInfo[ 3] = {q1.y, q1.w, q2.y};		// (templates beyond the program's count are all zero)
@@ -667,7 +717,7 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 		sim.value = meta & FKI_VALUE_MASK; sim.count = (meta >> FKI_COUNT_SHIFT) & FKI_COUNT_MASK; sim.end = 0;
 		sim.startLex = 0; sim.nItems = 0; sim.it0 = 0; sim.it1 = 0; sim.it2 = 0; sim.nFires = 0; sim.flags = 0;
 		bool dropped = false;		// deactivated by the replay: the rule never becomes visible to anything else
-		if (__ballot( have && pastEvent != 0))
+		if (!isStatic && __ballot( have && pastEvent != 0))
 		{
 			const u32 psi = (meta >> FKI_PASTSTOP_SHIFT) & FKI_PASTSTOP_MASK;
 			if (have && pastEvent && psi)
@@ -696,18 +746,23 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 			}
 			w.nAlt += (u32)__popcll( __ballot( have && pastEvent != 0));
 		}
-		if (have && !dropped)
+		if (!isStatic)
 		{
+			if (have && !dropped)
+			{
 #pragma unroll
-			for (int j=0; j<3; ++j) if (tInfo[ j] & FTI_KEY) fireLocal( sim, tInfo[ j], sord, w.lbase, P.withItems);
+				for (int j=0; j<3; ++j) if (tInfo[ j] & FTI_KEY) fireLocal( sim, tInfo[ j], sord, w.lbase, P.withItems);
+			}
+			if (__ballot( (sim.flags & S_ODD) != 0)) { FALLBACK( FB_ITEMS); return; }
 		}
-		if (__ballot( (sim.flags & S_ODD) != 0)) { FALLBACK( FB_ITEMS); return; }
 		const bool mat = have && !dropped;
 		const u64 matMask = __ballot( mat);
 		const u32 nmat = (u32)__popcll( matMask);
 		const u32 rank = (u32)__popcll( matMask & lanesBelow());
 		// ---- statistics (cpp:1251, :780)
 		w.nInstalled += nb;
+		if (isStatic) w.nSignals += (bcast0( q3.y) >> 8) & 0xFFu;
+		else
 		{
 			u32 incl = waveScanAdd( have ? sim.nFires : 0u);
 			w.nSignals += (u32)__builtin_amdgcn_readlane( incl, 63);
@@ -751,13 +806,14 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 			u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
 			for (int j=0; j<3; ++j) if (mat && (tInfo[ j] & FTI_INSTALL)) byteInc( c0, c1, c2, c3, (tInfo[ j] >> FTI_BUCKET_SHIFT) & 15u);
-			// upper bound without the scan: the batch adds at most nmat x 3 entries to a bucket
+			// upper bound without the scan: the batch adds at most nmat x 3 entries to a bucket (a static batch: its total)
+			const u32 bound = isStatic ? (bcast0( q3.y) & 0xFFu) : 3*nmat;
 			bool over = false, fail = false;
 			if (LANE < 16u)
 			{
 				const u32 sz = L.bsize[ LANE], cap = L.bmeta[ LANE] >> 16;
-				over = sz + 3*nmat > cap;
-				fail = sz + 3*nmat > cap + (u32)FAST_SPILL_BUCKET || sz + 3*nmat > 0xFFFu;
+				over = sz + bound > cap;
+				fail = sz + bound > cap + (u32)FAST_SPILL_BUCKET || sz + bound > 0xFFFu;
 			}
 			if (__ballot( over))
 			{
@@ -776,7 +832,12 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 				if (__ballot( over)) w.spill = 1;
 			}
 		}
-		if (w.spill) installBatchT<true>( L, w, P, kb, nb, sord, matMask, r, q0, q1, q2, sim);
+		if (isStatic)
+		{
+			if (w.spill) installStaticT<true>( L, w, P, kb + base, nb, sord, r, q0, q1, q2, q3);
+			else installStaticT<false>( L, w, P, kb + base, nb, sord, r, q0, q1, q2, q3);
+		}
+		else if (w.spill) installBatchT<true>( L, w, P, kb, nb, sord, matMask, r, q0, q1, q2, sim);
 		else installBatchT<false>( L, w, P, kb, nb, sord, matMask, r, q0, q1, q2, sim);
 	}
 }
@@ -914,7 +975,7 @@ static __device__ __forceinline__ void runKernel()
 				if (w.nDispose)
 				{
 					WAVE_FENCE();
-					if (w.spill) deactivateList<true,false>( L, w, P, w.nDispose, 0, false, true); else deactivateList<false,false>( L, w, P, w.nDispose, 0, false, true);
+					if (w.spill) deactivateList<true,false>( L, w, P, w.nDispose, 0, false); else deactivateList<false,false>( L, w, P, w.nDispose, 0, false);
 				}
 				if (stopIdx)
 				{

@@ -63,7 +63,7 @@ std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out
 			const DevProgram& p = ft.programs[ ref.program];
 			FastKeyInst& ki = out[ e.listBegin + k];
 			ki.resultHandle = p.resultHandle; ki.formatHandle = p.formatHandle;
-			ki.pastEvent = ref.pastEvent; ki.program = ref.program;
+			ki.pastEvent = ref.pastEvent;
 			bool within = false;
 			for (uint32_t j=0; j<p.trigCount; ++j) if ((ft.trigdefs[ p.trigBegin + j].flags & 15u) == SIG_WITHIN) within = true;
 			const uint32_t count = p.initcount & 0xFFFFu;		// ActionSlot::count is 16 bit (src/ruleMatcherAutomaton.hpp:98)
@@ -99,6 +99,63 @@ std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out
 				ki.trig[ j].event = t.event;
 				ki.trig[ j].info = (t.sigval & FTI_SIGVAL_MASK) | (sigtype << FTI_SIGTYPE_SHIFT) | (doInstall ? (uint32_t)FTI_INSTALL : 0u) | (key ? (uint32_t)FTI_KEY : 0u)
 					| ((a & 15u) << FTI_BUCKET_SHIFT) | (t.variable ? (uint32_t)FTI_HASVAR : 0u) | (delStop << FTI_DELSTOP_SHIFT) | (t.variable << FTI_VAR_SHIFT);
+			}
+		}
+		// ---- static install (l2_fast.h): the key fires of every line simulated here, the ranks of what a 64-lane batch
+		// appends counted here.  A batch with an alternative-keyed program (its replay depends on the document) or with a
+		// program whose key fires capture a fourth item stays dynamic.
+		for (uint32_t b0=0; b0<e.listCount; b0+=64)
+		{
+			const uint32_t nb = (e.listCount - b0) < 64u ? (e.listCount - b0) : 64u;
+			FastKeyInst* B = &out[ e.listBegin + b0];
+			bool isStatic = true;
+			uint32_t bucketCnt[ 16], rangeCnt[ 64], rangeLast[ 64];
+			std::memset( bucketCnt, 0, sizeof(bucketCnt)); std::memset( rangeCnt, 0, sizeof(rangeCnt)); std::memset( rangeLast, 0xFF, sizeof(rangeLast));
+			int bucketLastLane[ 16], bucketLastSlot[ 16];
+			for (int h=0; h<16; ++h) { bucketLastLane[ h] = -1; bucketLastSlot[ h] = -1; }
+			uint32_t trigTotal = 0, firesTotal = 0, resTotal = 0, dispTotal = 0, itemsTotal = 0;
+			for (uint32_t l=0; l<nb; ++l)
+			{
+				FastKeyInst& ki = B[ l];
+				ki.hw0 = 0; ki.ranksA = 0; ki.ranksB = 0; ki.totals = 0; ki.items = 0; ki.flags = 0;
+				if (ki.pastEvent) { isStatic = false; continue; }
+				Sim sim;
+				std::memset( &sim, 0, sizeof(sim));
+				sim.value = ki.meta & FKI_VALUE_MASK; sim.count = (ki.meta >> FKI_COUNT_SHIFT) & FKI_COUNT_MASK;
+				const uint32_t S = 1000;	// any position but 0 (position 0 takes the dynamic path: a start at position 0 counts as unset, cpp:919)
+				for (int j=0; j<3; ++j) if (ki.trig[ j].info & FTI_KEY) fireLocal( sim, ki.trig[ j].info, S, 0/*key lexem*/, 1);
+				if (sim.flags & S_ODD) { isStatic = false; continue; }
+				uint32_t tmask = 0;
+				for (int j=0; j<3; ++j)
+				{
+					if (!(ki.trig[ j].info & FTI_INSTALL)) continue;
+					const uint32_t h = (ki.trig[ j].info >> FTI_BUCKET_SHIFT) & 15u;
+					ki.ranksB |= (bucketCnt[ h] & 0xFFu) << (8*j);
+					bucketCnt[ h] += 1; bucketLastLane[ h] = (int)l; bucketLastSlot[ h] = j;
+					tmask |= 1u << j; trigTotal += 1;
+				}
+				ki.hw0 = sim.value | (sim.count << H_COUNT_SHIFT) | (uint32_t)H_ACTIVE | (tmask << H_TMASK_SHIFT) | (sim.nItems << H_NITEMS_SHIFT)
+					| ((sim.flags & S_DONE) ? (uint32_t)H_DONE : 0u) | ((sim.flags & S_HASSTART) ? (uint32_t)H_HASSTART : 0u);
+				if (sim.end) ki.flags |= FKF_END_SET;
+				if (sim.flags & S_TOOK) ki.flags |= FKF_START_SET;
+				const bool resultNow = (sim.flags & S_RESULT) && ki.resultHandle != 0;
+				const bool disposeNow = (sim.flags & (S_DEL | S_FIN)) != 0;
+				const uint32_t range = (ki.meta >> FKI_RANGE_SHIFT) & FKI_RANGE_MASK;
+				ki.ranksA = (rangeCnt[ range] & 0xFFu) | ((resTotal & 0xFFu) << 16) | ((dispTotal & 0xFFu) << 24);
+				rangeCnt[ range] += 1; rangeLast[ range] = l;
+				if (resultNow) { ki.flags |= FKF_RESULT_NOW; resTotal += 1; itemsTotal += sim.nItems; }
+				if (disposeNow) { ki.flags |= FKF_DISPOSE_NOW; dispTotal += 1; }
+				ki.items = (sim.it0 >> 24) | ((sim.it1 >> 24) << 8) | ((sim.it2 >> 24) << 16);
+				firesTotal += sim.nFires;
+			}
+			if (!isStatic || trigTotal > 255u || firesTotal > 255u || itemsTotal > 255u) continue;
+			for (int h=0; h<16; ++h) if (bucketLastLane[ h] >= 0) B[ bucketLastLane[ h]].ranksB |= 1u << (24 + bucketLastSlot[ h]);
+			for (uint32_t rg=0; rg<64; ++rg) if (rangeCnt[ rg]) B[ rangeLast[ rg]].ranksA |= (rangeCnt[ rg] & 0xFFu) << 8;
+			for (uint32_t l=0; l<nb; ++l)
+			{
+				B[ l].flags |= FKF_BATCH_STATIC;
+				B[ l].totals = trigTotal | (firesTotal << 8) | (resTotal << 16) | (dispTotal << 24);
+				B[ l].items |= itemsTotal << 24;
 			}
 		}
 	}
@@ -142,6 +199,7 @@ void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], uint32_t& expShift
 	S.maxRules = maxRules;
 	S.oCold = takeW( 8*maxRules);
 	S.oHot = takeW( spillRules); S.oLink = takeW( 3*spillRules);
+	S.oKi = takeW( spillRules); S.oLex0 = takeW( spillRules);
 	S.oFree = takeW( spillRules);
 	S.oEnt = takeW( 2*16*FAST_SPILL_BUCKET);
 	S.maxStaged = maxStaged;
