@@ -138,7 +138,7 @@ struct FastKeyEntry			// 16 B
 // instance per capacity pair.  R = rule instances whose hot state is in LDS, T = trigger-bucket entries in LDS.
 // Rule ids >= R and bucket positions beyond a bucket's LDS region live in the wave's spill area in HBM, so a
 // burst (a frequent word that keys hundreds of programs) slows a document down instead of failing it.
-enum {FAST_LISTCAP=128, FAST_EXPCAP=1024, FAST_MAXSTOP=64, FAST_SPILL_BUCKET=1024, FAST_VARIANTS=5, FAST_RQCAP=192};
+enum {FAST_LISTCAP=64, FAST_EXPCAP=1024, FAST_MAXSTOP=64, FAST_SPILL_BUCKET=1024, FAST_VARIANTS=5, FAST_RQCAP=192};
 
 struct FastSpillLayout			// per-wave spill + cold area in HBM, offsets in u32 words
 {

@@ -120,7 +120,7 @@ __device__ __forceinline__ void byteInc( u32& c0, u32& c1, u32& c2, u32& c3, u32
 
 // the document leaves the fast tier (a capacity of the spill area, or a case the compact state cannot express)
 #define FALLBACK( WHY) do { w.err = SPD_FAST_FALLBACK; w.why = (WHY); } while (0)
-enum {FB_LEXEMS=1, FB_DISPOSE=2, FB_ITEM_AFTER_RESULT=3, FB_ITEMS=4, FB_STAGED=5, FB_RULES=8, FB_BUCKET_SIZE=9};
+enum {FB_LEXEMS=1, FB_DISPOSE=2, FB_ITEM_AFTER_RESULT=3, FB_ITEMS=4, FB_STAGED=5, FB_RULES=8, FB_BUCKET_SIZE=9, FB_POSLEXEMS=10};
 
 // end_ordpos <= pos (sequence / within guard) and == pos (sequence_imm), from the 8 low bits kept in the word;
 // the true value lies in [pos-63, pos+1]
@@ -129,18 +129,20 @@ __device__ __forceinline__ bool endEQ( u32 hw, u32 pos) { return (hw & H_ENDZERO
 __device__ __forceinline__ u32 withEnd( u32 hw, u32 end) { return (hw & ~((H_END_MASK << H_END_SHIFT) | H_ENDZERO)) | ((end & 0xFFu) << H_END_SHIFT); }
 
 // ---------------------------------------------------------------- LDS image of a document (static layout)
+// (LDS is what bounds the number of documents in flight per CU, and the kernel is latency bound: every byte counts.
+//  The stop-word log lives in three vector registers, lane = stop word.)
+template <bool SMALL> struct FreeId { typedef u8 type; };
+template <> struct FreeId<false> { typedef u16 type; };
 template <int R, int T>
 struct LdsDoc
 {
 	u32 hot[ R];			// rule word
-	u32 ki[ R];			// install line of the rule (FastKeyInst index)
-	u32 lex0[ R];			// its key lexem (index inside the document)
+	u32 kl[ R];			// install line of the rule (FastKeyInst index, 20 bits) | its key lexem (index inside the document, low 12 bits) << 20
 	u64 ent[ T];			// bucket entries: event id | (trigger id (rule<<2 | slot) | signal byte << 16 | variable << 24) << 32; bucket h owns [base_h, base_h + cap_h)
 	u32 bsize[ 16];			// bucket sizes
 	u32 bmeta[ 16];			// base_h | cap_h << 16
-	u32 stop[ 3*FAST_MAXSTOP];	// stop-word log {lexem index, ordpos, timestamp}
-	u16 link[ 4*R];			// bucket << 12 | position of trigger slot j of rule r at [4r+j] (one 8-byte read per rule)
-	u16 freeS[ R];			// stack of free rule ids < R
+	u16 link[ 3*R];			// bucket << 12 | position of trigger slot j of rule r at [3r+j]
+	typename FreeId<(R <= 256)>::type freeS[ R];	// stack of free rule ids < R
 	u16 exp[ FAST_EXPCAP];		// expiry lists: row (position & (W-1)) holds the rules that expire at that position, in definition order
 	u16 expCnt[ 64];		// their lengths
 	u16 list[ FAST_LISTCAP];	// dispose list of the current transition
@@ -157,6 +159,11 @@ struct Wave
 	u32 lbase;				// lexem index of the event being processed, relative to the document
 	u32 spill;				// something of this document lives in the spill area: the two-place accessors run
 	u32 why;				// reason of a hand-over (diagnostics)
+	u32 posLexems;				// lexems at the current position (the key lexem of a rule is kept modulo 4096)
+	// per-lane values (not uniform)
+	u32 stopLex, stopOrd, stopTs;		// stop-word log {lexem index, ordpos, timestamp}: lane = stop word index - 1
+	u32 bsizeV, bmetaV;			// lane b < 16: size and region of bucket b (mirrors of L.bsize / L.bmeta for uniform reads without an LDS round trip)
+	u32 expCntV;				// lane = expiry row: its length (mirror of L.expCnt)
 #ifdef SPA_PROF
 	u64 prof[ 12];
 #endif
@@ -171,17 +178,20 @@ typedef __attribute__((address_space(3))) Lds& LR;
 // ---- rule fields: ids < R in LDS, others in the spill area (same shapes).  SP=false: LDS only.
 template <bool SP> static __device__ __forceinline__ u32 ldHot( LR L, const Wave& w, KP P, u32 r) { if (!SP || r < (u32)R) return L.hot[ r]; return w.sp[ P.spill.oHot + (r - R)]; }
 template <bool SP> static __device__ __forceinline__ void stHot( LR L, const Wave& w, KP P, u32 r, u32 v) { if (!SP || r < (u32)R) L.hot[ r] = v; else w.sp[ P.spill.oHot + (r - R)] = v; }
-template <bool SP> static __device__ __forceinline__ u32 ldLink( LR L, const Wave& w, KP P, u32 r, u32 j) { if (!SP || r < (u32)R) return (u32)L.link[ 4*r + j]; return w.sp[ P.spill.oLink + 3*(r - R) + j]; }
-template <bool SP> static __device__ __forceinline__ void stLink( LR L, const Wave& w, KP P, u32 r, u32 j, u32 v) { if (!SP || r < (u32)R) L.link[ 4*r + j] = (u16)v; else w.sp[ P.spill.oLink + 3*(r - R) + j] = v; }
+template <bool SP> static __device__ __forceinline__ u32 ldLink( LR L, const Wave& w, KP P, u32 r, u32 j) { if (!SP || r < (u32)R) return (u32)L.link[ 3*r + j]; return w.sp[ P.spill.oLink + 3*(r - R) + j]; }
+template <bool SP> static __device__ __forceinline__ void stLink( LR L, const Wave& w, KP P, u32 r, u32 j, u32 v) { if (!SP || r < (u32)R) L.link[ 3*r + j] = (u16)v; else w.sp[ P.spill.oLink + 3*(r - R) + j] = v; }
 template <bool SP> static __device__ __forceinline__ void ldLinks( LR L, const Wave& w, KP P, u32 r, u32& l0, u32& l1, u32& l2)
 {
-	if (!SP || r < (u32)R) { const u64 v = *(const __attribute__((address_space(3))) u64*)&L.link[ 4*r]; l0 = (u32)v & 0xFFFFu; l1 = ((u32)v >> 16); l2 = (u32)(v >> 32) & 0xFFFFu; }
+	if (!SP || r < (u32)R) { l0 = (u32)L.link[ 3*r]; l1 = (u32)L.link[ 3*r+1]; l2 = (u32)L.link[ 3*r+2]; }
 	else { const u32* q = &w.sp[ P.spill.oLink + 3*(r - R)]; l0 = q[0]; l1 = q[1]; l2 = q[2]; }
 }
-template <bool SP> static __device__ __forceinline__ u32 ldKi( LR L, const Wave& w, KP P, u32 r) { if (!SP || r < (u32)R) return L.ki[ r]; return w.sp[ P.spill.oKi + (r - R)]; }
-template <bool SP> static __device__ __forceinline__ u32 ldLex0( LR L, const Wave& w, KP P, u32 r) { if (!SP || r < (u32)R) return L.lex0[ r]; return w.sp[ P.spill.oLex0 + (r - R)]; }
-template <bool SP> static __device__ __forceinline__ void stKiLex( LR L, const Wave& w, KP P, u32 r, u32 ki, u32 lx)
-{ if (!SP || r < (u32)R) { L.ki[ r] = ki; L.lex0[ r] = lx; } else { w.sp[ P.spill.oKi + (r - R)] = ki; w.sp[ P.spill.oLex0 + (r - R)] = lx; } }
+// install line and key lexem of a rule in one word: line index (< 2^20, checked by the host) | lexem index modulo 4096 << 20.
+// A rule lives at most 63 positions and a position with more than 60 lexems hands the document over (FB_POSLEXEMS),
+// so the key lexem lies less than 4096 lexems behind the current one.
+template <bool SP> static __device__ __forceinline__ u32 ldKl( LR L, const Wave& w, KP P, u32 r) { if (!SP || r < (u32)R) return L.kl[ r]; return w.sp[ P.spill.oKi + (r - R)]; }
+template <bool SP> static __device__ __forceinline__ void stKl( LR L, const Wave& w, KP P, u32 r, u32 ki, u32 lx)
+{ const u32 v = ki | (lx << 20); if (!SP || r < (u32)R) L.kl[ r] = v; else w.sp[ P.spill.oKi + (r - R)] = v; }
+static __device__ __forceinline__ u32 keyLexemOf( u32 kl, u32 lbase) { return lbase - ((lbase - (kl >> 20)) & 0xFFFu); }
 // ---- expiry rows: entry i of row `row` sits in LDS while i < C = FAST_EXPCAP >> expShift, else in the row's spill part
 template <bool SP> static __device__ __forceinline__ u32 ldExp( LR L, const Wave& w, KP P, u32 row, u32 i)
 { const u32 C = (u32)FAST_EXPCAP >> P.expShift; if (!SP || i < C) return (u32)L.exp[ row*C + i]; return w.sp[ P.spill.oExp + row*P.spill.maxRules + (i - C)]; }
@@ -293,8 +303,8 @@ static __device__ __forceinline__ void fireSignal( LR L, Wave& w, KP P, u32 tsv,
 		}
 		else
 		{
-			const u32 ki = bcast0( ldKi<SP>( L, w, P, r)), lx = bcast0( ldLex0<SP>( L, w, P, r));
-			const u32* K = (const u32*)&P.keyinst[ ki];
+			const u32 kl = bcast0( ldKl<SP>( L, w, P, r)), lx = keyLexemOf( kl, w.lbase);
+			const u32* K = (const u32*)&P.keyinst[ kl & 0xFFFFFu];
 			handle = ldu( K); fmt = ldu( K+1);
 			const u32 vars = ldu( K+14);
 			startLex = lx;		// (a static line is installed at a position != 0: a key fire that took set the start)
@@ -403,11 +413,13 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 			WAVE_FENCE();
 			if (LANE < 16u && tot)
 			{
-				const u32 h = LANE, meta = L.bmeta[ h];
-				u32 size = L.bsize[ h];
+				const u32 h = LANE, meta = w.bmetaV;
+				u32 size = w.bsizeV;
+				u32 tidNext = (u32)L.rq[ qoff];
 				for (u32 q=0; q<tot; ++q)
 				{
-					const u32 tid = (u32)L.rq[ qoff + q];
+					const u32 tid = tidNext;
+					if (q+1 < tot) tidNext = (u32)L.rq[ qoff + q + 1];		// (requested beside this step's reads)
 					const u32 pos = ldLink<SP>( L, w, P, tid >> 2, tid & 3u) & 0xFFFu;	// (an earlier removal of this replay may have moved it)
 					const u32 last = size - 1u;
 					const uint2 m = ldEnt<SP>( L, w, P, h, meta, last);
@@ -421,6 +433,7 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 					if (SP) WAVE_FENCE();
 				}
 				L.bsize[ h] = size;
+				w.bsizeV = size;
 			}
 			WAVE_FENCE();
 			w.nTrig -= total;
@@ -431,7 +444,7 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 		if (freeIds)
 		{
 			const u64 mL = __ballot( have && r < (u32)R);
-			if (have && r < (u32)R) L.freeS[ w.freeN + (u32)__popcll( mL & lanesBelow())] = (u16)r;
+			if (have && r < (u32)R) L.freeS[ w.freeN + (u32)__popcll( mL & lanesBelow())] = (typename FreeId<(R <= 256)>::type)r;
 			w.freeN += (u32)__popcll( mL);
 			if (SP)
 			{
@@ -453,12 +466,13 @@ static __device__ __forceinline__ void setCurrentPos( LR L, Wave& w, KP P, u32 p
 	for (; wcnt < W && w.curpos < pos && !w.err; ++wcnt, ++w.curpos)
 	{
 		const u32 row = w.curpos & (W-1u);
-		const u32 n = bcast0( (u32)L.expCnt[ row]);
+		const u32 n = (u32)__builtin_amdgcn_readlane( w.expCntV, row);
 		if (n)
 		{
 			// the rules of this position, last defined first (the reference's list is LIFO)
 			if (w.spill) deactivateList<true,true>( L, w, P, n, row, true); else deactivateList<false,true>( L, w, P, n, row, true);
 			if (LANE == 0) L.expCnt[ row] = 0;
+			if (LANE == row) w.expCntV = 0;
 			WAVE_FENCE();
 		}
 	}
@@ -467,8 +481,8 @@ static __device__ __forceinline__ void setCurrentPos( LR L, Wave& w, KP P, u32 p
 	{
 		// back to the LDS-only instance once nothing of the document is in the spill area any more
 		bool over = false;
-		if (LANE < 16u) over = L.bsize[ LANE] > (L.bmeta[ LANE] >> 16);
-		if ((u32)L.expCnt[ LANE] > ((u32)FAST_EXPCAP >> P.expShift)) over = true;
+		if (LANE < 16u) over = w.bsizeV > (w.bmetaV >> 16);
+		if (w.expCntV > ((u32)FAST_EXPCAP >> P.expShift)) over = true;
 		if (!__ballot( over) && w.sFreeN == w.usedS) { w.spill = 0; w.sFreeN = 0; w.usedS = 0; }
 	}
 }
@@ -656,7 +670,7 @@ static __device__ __forceinline__ void installStaticT( LR L, Wave& w, KP P, u32 
 		u32 hw = (hw0 & ~(H_NITEMS_MASK << H_NITEMS_SHIFT)) | (nItems << H_NITEMS_SHIFT);
 		hw |= (fl & FKF_END_SET) ? (((sord + 1u) & 0xFFu) << H_END_SHIFT) : (u32)H_ENDZERO;
 		stHot<SP>( L, w, P, r, hw);
-		stKiLex<SP>( L, w, P, r, ki0 + LANE, w.lbase);
+		stKl<SP>( L, w, P, r, ki0 + LANE, w.lbase);
 	}
 	// ---- results (cpp:954-965), in lane order; the items are the key lexem under the key triggers' variables, latest first
 	const u32 nres = (totals >> 16) & 0xFFu;
@@ -719,10 +733,21 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 		bool dropped = false;		// deactivated by the replay: the rule never becomes visible to anything else
 		if (!isStatic && __ballot( have && pastEvent != 0))
 		{
-			const u32 psi = (meta >> FKI_PASTSTOP_SHIFT) & FKI_PASTSTOP_MASK;
-			if (have && pastEvent && psi)
+			const u32 psi = (have && pastEvent) ? ((meta >> FKI_PASTSTOP_SHIFT) & FKI_PASTSTOP_MASK) : 0u;
+			// the stop-word log is in registers, lane = stop word: every lane fetches (all lanes take part in a bpermute)
+			const u32 plex = (u32)__builtin_amdgcn_ds_bpermute( (int)((psi-1u) << 2), (int)w.stopLex);
+			const u32 psord = (u32)__builtin_amdgcn_ds_bpermute( (int)((psi-1u) << 2), (int)w.stopOrd);
+			const u32 pts = (u32)__builtin_amdgcn_ds_bpermute( (int)((psi-1u) << 2), (int)w.stopTs);
+			u32 delTs[ 3];
+#pragma unroll
+			for (int j=0; j<3; ++j)
 			{
-				const u32 plex = L.stop[ 3*(psi-1)], psord = L.stop[ 3*(psi-1)+1], pts = L.stop[ 3*(psi-1)+2];
+				const u32 esi = (tInfo[ j] >> FTI_DELSTOP_SHIFT) & FTI_DELSTOP_MASK;
+				delTs[ j] = (u32)__builtin_amdgcn_ds_bpermute( (int)((esi-1u) << 2), (int)w.stopTs);
+				if (!esi) delTs[ j] = 0;
+			}
+			if (psi)
+			{
 				if (pts && psord + range >= w.curpos)
 				{
 #pragma unroll
@@ -737,8 +762,8 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 					{
 						if ((tInfo[ j] & FTI_INSTALL) && ((tInfo[ j] >> FTI_SIGTYPE_SHIFT) & FTI_SIGTYPE_MASK) == SIG_DEL)
 						{
-							const u32 esi = (tInfo[ j] >> FTI_DELSTOP_SHIFT) & FTI_DELSTOP_MASK;
-							if (esi) { const u32 ts = L.stop[ 3*(esi-1)+2]; if (ts && ts > pts) cancelled = true; }
+							const u32 ts = delTs[ j];
+							if (ts && ts > pts) cancelled = true;
 						}
 					}
 					if (cancelled || (sim.flags & (S_DEL | S_FIN))) dropped = true;	// (replayPastEvent deactivates what its signals disposed, cpp:1322-1330)
@@ -840,6 +865,9 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 		else if (w.spill) installBatchT<true>( L, w, P, kb, nb, sord, matMask, r, q0, q1, q2, sim);
 		else installBatchT<false>( L, w, P, kb, nb, sord, matMask, r, q0, q1, q2, sim);
 	}
+	// the register mirrors of the bucket sizes and the expiry row lengths (requested now, needed at the next event at the earliest)
+	w.bsizeV = L.bsize[ LANE & 15u];
+	w.expCntV = (u32)L.expCnt[ LANE];
 }
 
 // ---------------------------------------------------------------- doTransition (cpp:981-1064) for an input term
@@ -848,8 +876,8 @@ static __device__ __forceinline__ void scanAndFire( LR L, Wave& w, KP P, u32 id,
 {
 	// fire the triggers waiting for this event: 64 bucket entries per step, one ballot
 	const u32 h = evhash( id) & 15u;
-	const u32 n = bcast0( L.bsize[ h]);
-	const u32 meta = bcast0( L.bmeta[ h]);
+	const u32 n = (u32)__builtin_amdgcn_readlane( w.bsizeV, h);
+	const u32 meta = (u32)__builtin_amdgcn_readlane( w.bmetaV, h);
 	for (u32 base=0; base<n && !w.err; base+=64)
 	{
 		const u32 i = base + LANE;
@@ -887,9 +915,10 @@ static __device__ __forceinline__ void runKernel()
 		}
 		if (doc >= ndocs) break;
 		// per-document reset
-		if (LANE < 16u) { L.bsize[ LANE] = 0; L.bmeta[ LANE] = P.bucketMeta[ LANE]; }
+		w.bmetaV = P.bucketMeta[ LANE & 15u]; w.bsizeV = 0; w.expCntV = 0;
+		if (LANE < 16u) { L.bsize[ LANE] = 0; L.bmeta[ LANE] = w.bmetaV; }
 		L.expCnt[ LANE] = 0;
-		for (u32 s=LANE; s<P.nofStopWords; s+=64) L.stop[ 3*s+2] = 0;
+		w.stopLex = 0; w.stopOrd = 0; w.stopTs = 0; w.posLexems = 0;
 		w.curpos = 0; w.timestamp = 0; w.nInstalled = 0; w.nAlt = 0; w.nSignals = 0; w.nTrig = 0; w.openLo = 0; w.openHi = 0;
 		w.freeN = 0; w.usedL = 0; w.sFreeN = 0; w.usedS = 0;
 		w.nDispose = 0; w.nStaged = 0; w.nStagedItems = 0; w.err = 0; w.lbase = 0; w.why = 0; w.spill = 0;
@@ -948,10 +977,11 @@ static __device__ __forceinline__ void runKernel()
 				const u32 origseg = __builtin_amdgcn_readlane( seg, k);
 				// PatternMatcherContext::putInput (patternMatcher.cpp:131-162)
 				if (curPosition > ordpos) { w.err = SPD_ERR_ORDER; break; }
-				else if (curPosition < ordpos) { curPosition = ordpos; setCurrentPos( L, w, P, ordpos); PROF_ADD( 3); if (w.err) break; }
+				else if (curPosition < ordpos) { curPosition = ordpos; w.posLexems = 0; setCurrentPos( L, w, P, ordpos); PROF_ADD( 3); if (w.err) break; }
 				else if (origsize >= 0x7FFFFFFFu || origseg >= 0x7FFFFFFFu || origpos >= 0x7FFFFFFFu) { w.err = SPD_ERR_RANGE; break; }
 				if (id >= (1u<<29)) { w.err = SPD_ERR_RANGE; break; }
 				w.lbase = (u32)(tile - lbeg) + k;
+				if (++w.posLexems > 60u) { FALLBACK( FB_POSLEXEMS); break; }	// (key lexems are kept modulo 4096: ldKl)
 				// ---- doTransition (cpp:981-1064) for an input term: no follow events in a flat rule set
 				{
 					const u32 lo = w.openLo + w.nTrig;
@@ -979,7 +1009,7 @@ static __device__ __forceinline__ void runKernel()
 				}
 				if (stopIdx)
 				{
-					if (LANE == 0) { L.stop[ 3*(stopIdx-1)] = w.lbase; L.stop[ 3*(stopIdx-1)+1] = ordpos; L.stop[ 3*(stopIdx-1)+2] = w.timestamp + 1u; }
+					if (LANE == stopIdx-1u) { w.stopLex = w.lbase; w.stopOrd = ordpos; w.stopTs = w.timestamp + 1u; }
 					w.timestamp += 1;
 					WAVE_FENCE();
 				}
@@ -1084,10 +1114,10 @@ static __device__ __forceinline__ void runKernel()
 #endif
 #define SPA_FAST_INSTANCE( NAME, RR, TT) \
 	extern "C" __global__ __launch_bounds__(64) SPA_L2_FAST_OCC void NAME( FastParams kernelArgs) { Engine<RR,TT>::runKernel(); }
-SPA_FAST_INSTANCE( spa_l2_fast_kernel_s, 192, 320)
+SPA_FAST_INSTANCE( spa_l2_fast_kernel_s, 192, 312)
 SPA_FAST_INSTANCE( spa_l2_fast_kernel_m, 320, 512)
 SPA_FAST_INSTANCE( spa_l2_fast_kernel_l, 512, 1024)
-SPA_FAST_INSTANCE( spa_l2_fast_kernel_n, 256, 480)		// 10 KB of LDS: 16 waves per CU
+SPA_FAST_INSTANCE( spa_l2_fast_kernel_n, 256, 448)		// 10 KB of LDS: 16 waves per CU
 SPA_FAST_INSTANCE( spa_l2_fast_kernel_t, 8, 128)		// tests: everything beyond a handful of rules runs through the spill area
 
 namespace spa {
@@ -1097,7 +1127,7 @@ static const void* fastInstance( unsigned variant)
 }
 void fastCapacities( unsigned variant, uint32_t& R, uint32_t& T)
 {
-	if (variant == 0) { R = 192; T = 320; } else if (variant == 1) { R = 320; T = 512; } else if (variant == 2) { R = 512; T = 1024; } else if (variant == 4) { R = 256; T = 480; } else { R = 8; T = 128; }
+	if (variant == 0) { R = 192; T = 312; } else if (variant == 1) { R = 320; T = 512; } else if (variant == 2) { R = 512; T = 1024; } else if (variant == 4) { R = 256; T = 448; } else { R = 8; T = 128; }
 }
 // resident single-wave workgroups per CU of a kernel instance (registers and LDS both limit it)
 int fastBlocksPerCU( unsigned variant)

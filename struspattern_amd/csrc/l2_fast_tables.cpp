@@ -16,7 +16,7 @@ std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out
 {
 	out.clear();
 	if (ft.nofStopWords > FAST_MAXSTOP) return "more than 64 stop words";
-	if (ft.keylist.size() >= (1u<<24)) return "more than 2^24 key list entries";
+	if (ft.keylist.size() >= (1u<<20)) return "more than 2^20 key list entries";	// (a rule keeps its install line in 20 bits)
 	// events somebody waits for or is keyed by
 	std::set<uint32_t> listened;
 	std::map<uint32_t,uint32_t> stopIdxOf;
