@@ -21,7 +21,7 @@ hipError_t launchL2Match( const L2Params& P, unsigned nblocks, hipStream_t strea
 hipError_t launchL2Fast( const FastParams& P, unsigned variant, unsigned nblocks, hipStream_t stream);
 int fastBlocksPerCU( unsigned variant);
 void fastCapacities( unsigned variant, uint32_t& R, uint32_t& T);
-std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out);
+std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out, std::vector<FastStatic>* statics);
 std::string buildJoinTables( const FlatTables& ft, std::vector<JoinKey>& keytab, std::vector<JoinRule>& rules, std::vector<uint32_t>& filter, uint32_t& maxRange, uint32_t& delimiter);
 hipError_t launchL2Join( const JoinParams& P, unsigned nwaves, hipStream_t stream);
 void layoutFast( FastSpillLayout& S, uint32_t bucketMeta[16], uint32_t& expShift, const std::vector<FastKeyInst>& keyinst, uint32_t R, uint32_t T, uint32_t maxRules, uint32_t maxStaged);
@@ -97,7 +97,7 @@ struct sp_matcher_ctx
 	// fast tier (l2_fast.h): flat rule sets run with their hot state in LDS; the general kernel takes what it hands over
 	bool fast;
 	std::string whyNotFast;
-	DeviceBuffer dKeyinst, dSpill, dFallbackList;
+	DeviceBuffer dKeyinst, dStatics, dSpill, dFallbackList;
 	// join prototype (l2_join.h, opt-in by SPA_L2_JOIN=1): result sets without materialised rule instances
 	bool join; std::string whyNotJoin; uint32_t joinKeymask, joinMaxRange, joinDelimiter; DeviceBuffer dJoinKeytab, dJoinRules, dJoinFilter, dJoinCounts;
 	std::vector<FastKeyInst> fastKeyinst;
@@ -197,7 +197,7 @@ int sp_matcher_fast_tier( const sp_matcher_t* m, char* why, size_t whysize)
 		FlatTables ft;
 		m->compiler.flatten( ft);
 		std::vector<FastKeyInst> ki;
-		const std::string reason = buildFastTables( ft, ki);
+		const std::string reason = buildFastTables( ft, ki, 0);
 		if (why && whysize) { std::strncpy( why, reason.c_str(), whysize-1); why[ whysize-1] = 0; }
 		return reason.empty() ? 1 : 0;
 	}
@@ -280,7 +280,8 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 		{
 			// fast tier: eligible rule sets get the one-line-per-install table (SPA_L2_FAST=0 keeps everything on the general kernel)
 			std::vector<FastKeyInst> ki;
-			c->whyNotFast = buildFastTables( ft, ki);
+			std::vector<FastStatic> ks;
+			c->whyNotFast = buildFastTables( ft, ki, &ks);
 			const char* sw = getenv( "SPA_L2_FAST");
 			if (sw && sw[0] == '0') c->whyNotFast = "disabled by SPA_L2_FAST=0";
 			c->fast = c->whyNotFast.empty();
@@ -288,6 +289,7 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 			{
 				if (ki.empty()) ki.resize( 1);
 				c->dKeyinst.upload( ki.data(), ki.size()*sizeof(FastKeyInst));
+				c->dStatics.upload( ks.data(), ks.size()*sizeof(FastStatic));
 				c->fastKeyinst.swap( ki);
 				// SPA_L2_FAST_SIZE=s|m|l picks the kernel instance (LDS capacities; t = the tiny one of the tests); the spill area takes what does not fit
 				if (const char* e = getenv( "SPA_L2_FAST_SIZE")) c->fastVariant = (e[0] == 's') ? 0u : (e[0] == 'm') ? 1u : (e[0] == 'l') ? 2u : (e[0] == 't') ? 3u : 4u;
@@ -703,7 +705,7 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		c->dFallbackList.reserve( (ndocs+1)*sizeof(uint32_t));
 		FastParams F;
 		std::memset( &F, 0, sizeof(F));
-		F.keyinst = (const FastKeyInst*)c->dKeyinst.ptr; F.keytab = (const FastKeyEntry*)c->dKeytab.ptr;
+		F.keyinst = (const FastKeyInst*)c->dKeyinst.ptr; F.statics = (const FastStatic*)c->dStatics.ptr; F.keytab = (const FastKeyEntry*)c->dKeytab.ptr;
 		F.keymask = c->keymask; F.nofStopWords = c->nofStopWords;
 		F.lexems = P.lexems; F.origseg = P.origseg; F.docOffsets = P.docOffsets; F.docRangesIn = P.docRangesIn;
 		F.ndocs = P.ndocs; F.withItems = P.withItems;
@@ -800,10 +802,12 @@ int sp_matcher_ctx_batch_counters( sp_matcher_ctx_t* c, uint64_t counters[8])
 #ifdef SPA_PROF
 			uint64_t prof[ 12];
 			HIP_CHECK( hipMemcpy( prof, (const uint32_t*)c->dCursor.ptr + 32, sizeof(prof), hipMemcpyDeviceToHost));
-			double tot = 0; for (int i=0; i<8; ++i) tot += (double)prof[ i];
-			tot -= (double)prof[ 6] + (double)prof[ 7];
-			fprintf( stderr, "[spa] fast tier phases (share of wave cycles): scan+fire %.1f%% install %.1f%% deactivate %.1f%% expiry %.1f%% results %.1f%% fetch %.1f%% | inside: list walk %.1f%% removal rounds %.1f%% (%u rounds, %u batches, %u rules); %.0f cycles per event\n",
-				100*prof[0]/tot, 100*prof[1]/tot, 100*prof[2]/tot, 100*prof[3]/tot, 100*prof[4]/tot, 100*prof[5]/tot, 100*prof[6]/tot, 100*prof[7]/tot, (unsigned)prof[ 8], (unsigned)prof[ 9], (unsigned)prof[ 10], tot / (double)(counters[ SPC_EVENTS] ? counters[ SPC_EVENTS] : 1));
+			double tot = 0; for (int i=0; i<6; ++i) tot += (double)prof[ i];
+			
+			fprintf( stderr, "[spa] fast tier phases (share of wave cycles): scan+fire %.1f%% install %.1f%% deactivate %.1f%% expiry %.1f%% results %.1f%% fetch %.1f%% | inside deactivation: loads %.1f%% ranks+queue %.1f%% replay %.1f%% (%.2f replay steps, %.2f batches, %.2f rules per event); %.0f cycles per event\n",
+				100*prof[0]/tot, 100*prof[1]/tot, 100*prof[2]/tot, 100*prof[3]/tot, 100*prof[4]/tot, 100*prof[5]/tot, 100*prof[6]/tot, 100*prof[7]/tot, 100*prof[11]/tot,
+				(double)prof[ 8] / (double)(counters[ SPC_EVENTS] ? counters[ SPC_EVENTS] : 1), (double)prof[ 9] / (double)(counters[ SPC_EVENTS] ? counters[ SPC_EVENTS] : 1), (double)prof[ 10] / (double)(counters[ SPC_EVENTS] ? counters[ SPC_EVENTS] : 1),
+				tot / (double)(counters[ SPC_EVENTS] ? counters[ SPC_EVENTS] : 1));
 #endif
 			if (diag[ 0])
 			{

@@ -55,6 +55,25 @@ enum {
 	FKF_RESULT_NOW=8u,		// the key fire completes the rule and the pattern is visible: a result at once
 	FKF_DISPOSE_NOW=16u		// finished or deleted by its own key event
 };
+// COMPACT form of a static line (32 B, same index as FastKeyInst[]): all a static batch needs when none of its programs
+// installs more than two triggers -- the shape of every two-term rule -- so that an install batch reads 2 KB instead
+// of 4 KB and two 16-byte loads per lane instead of four.  Result handle, format and variables of a program that
+// completes at once (FSM_RESULT_NOW) are read from its FastKeyInst line.
+struct FastStatic			// 32 B
+{
+	uint32_t ev0, info0;		// first installed trigger; info: signal byte as in a bucket entry (8) | variable (8) << 8 | bucket (4) << 16 | rank in the
+	uint32_t ev1, info1;		// batch's entries of that bucket (8) << 20 | FSI_LAST | FSI_PRESENT | template slot (2) << 30
+	uint32_t hw0;			// as FastKeyInst::hw0
+	uint32_t misc;			// range (6) | expRank (8) << 6 | expClose (8) << 14 | FSM_* flags
+	uint32_t ranks;			// resRank (8) | dispRank (8) << 8 | items of the batch's immediate results (8) << 16
+	uint32_t totals;		// as FastKeyInst::totals
+};
+enum {
+	FSI_BUCKET_SHIFT=16, FSI_RANK_SHIFT=20, FSI_LAST=1u<<28, FSI_PRESENT=1u<<29, FSI_SLOT_SHIFT=30,
+	FSM_RANGE_MASK=0x3Fu, FSM_EXPRANK_SHIFT=6, FSM_EXPCLOSE_SHIFT=14,
+	FSM_END_SET=1u<<22, FSM_START_SET=1u<<23, FSM_RESULT_NOW=1u<<24, FSM_DISPOSE_NOW=1u<<25, FSM_BATCH_COMPACT=1u<<26
+};
+
 // rule word of the fast tier (LDS, u32 per rule instance)
 enum {
 	H_VALUE_MASK=0xFu, H_COUNT_SHIFT=4, H_COUNT_MASK=0x1Fu, H_END_SHIFT=9, H_END_MASK=0xFFu, H_ENDZERO=1u<<17,
@@ -162,6 +181,7 @@ enum {SPD_FAST_FALLBACK=100};
 struct FastParams
 {
 	const FastKeyInst* keyinst;
+	const FastStatic* statics;	// compact static lines, same index
 	const FastKeyEntry* keytab;
 	uint32_t keymask;
 	uint32_t nofStopWords;

@@ -372,6 +372,12 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 		const u32 nb = (n - base) < 64u ? (n - base) : 64u;
 		const bool have = LANE < nb;
 		u32 r = 0, hw = 0;
+#if defined(SPA_PROF) && !defined(SPA_PROF_INSTALL)
+		u64 pd0 = __builtin_amdgcn_s_memtime();
+#define PROF_D( SLOT) do { if (__ballot( hw == 0xFFFFFFFFu)) w.err = SPD_ERR_INTERNAL; const u64 pd1 = __builtin_amdgcn_s_memtime(); w.prof[ SLOT] += pd1 - pd0; pd0 = pd1; } while (0)
+#else
+#define PROF_D( SLOT) do {} while (0)
+#endif
 		if (have)
 		{
 			r = EXPROW ? ldExp<SP>( L, w, P, row, n - 1u - (base + LANE)) : ldList<SP>( L, w, P, base + LANE);
@@ -385,6 +391,10 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 			// my triggers' buckets; their number per bucket as packed byte counters (16 buckets x 8 bits in four words)
 			u32 lk[ 3] = {0,0,0};
 			if (mask) ldLinks<SP>( L, w, P, r, lk[ 0], lk[ 1], lk[ 2]);
+#if defined(SPA_PROF) && !defined(SPA_PROF_INSTALL)
+			if (__ballot( lk[ 0] == 0xFFFFFFFFu)) w.err = SPD_ERR_INTERNAL;
+#endif
+			PROF_D( 6);
 			u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
 			for (int j=0; j<3; ++j) if ((mask >> j) & 1u) byteInc( c0, c1, c2, c3, lk[ j] >> 12);
@@ -411,8 +421,12 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 				}
 			}
 			WAVE_FENCE();
+			PROF_D( 7);
 			if (LANE < 16u && tot)
 			{
+				// (a register replay of four removals per step -- trigger ids, positions and the bucket's last four entries in
+				// two rounds of loads -- was measured: slower, 184.6 vs 172 ms; its 120 instructions per step cost more than the
+				// round trips it saves while most buckets of a batch lose one or two entries)
 				const u32 h = LANE, meta = w.bmetaV;
 				u32 size = w.bsizeV;
 				u32 tidNext = (u32)L.rq[ qoff];
@@ -436,6 +450,7 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 				w.bsizeV = size;
 			}
 			WAVE_FENCE();
+			PROF_D( 11);
 			w.nTrig -= total;
 #ifdef SPA_PROF
 			w.prof[ 8] += (u32)__builtin_amdgcn_readlane( waveScanMax( tot), 63); w.prof[ 9] += 1; w.prof[ 10] += nb;
@@ -705,14 +720,201 @@ static __device__ __forceinline__ void installStaticT( LR L, Wave& w, KP P, u32 
 	WAVE_FENCE();
 }
 
-static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb, u32 kc, u32 sord)
+// ---- rule ids for the lanes of matMask: LDS free stack, LDS bump, spill free stack, spill bump.  false: the document is handed over
+static __device__ __forceinline__ bool allocRuleIds( LR L, Wave& w, KP P, u64 matMask, u32& r)
 {
-	// (requesting an event's install records one event ahead was measured: no gain -- the kernel is bound by the
-	// instructions it issues, not by this load)
+	const bool mat = (matMask >> LANE) & 1ull;
+	const u32 nmat = (u32)__popcll( matMask);
+	const u32 rank = (u32)__popcll( matMask & lanesBelow());
+	r = 0;
+	if (nmat)
+	{
+		const u32 a = w.freeN < nmat ? w.freeN : nmat;
+		const u32 roomL = (u32)R - w.usedL;
+		const u32 b = (nmat - a) < roomL ? (nmat - a) : roomL;
+		const u32 rest = nmat - a - b;
+		if (rest)
+		{
+			const u32 c = w.sFreeN < rest ? w.sFreeN : rest;
+			const u32 d = rest - c;
+			if ((u32)R + w.usedS + d > P.spill.maxRules) { FALLBACK( FB_RULES); return false; }
+			w.spill = 1;
+			if (mat && rank >= a+b)
+			{
+				if (rank < a+b+c) r = (u32)R + w.sp[ P.spill.oFree + w.sFreeN - 1 - (rank - a - b)];
+				else r = (u32)R + w.usedS + (rank - a - b - c);
+			}
+			w.sFreeN -= c; w.usedS += d;
+		}
+		if (mat)
+		{
+			if (rank < a) r = (u32)L.freeS[ w.freeN - 1 - rank];
+			else if (rank < a+b) r = w.usedL + (rank - a);
+		}
+		w.freeN -= a; w.usedL += b;
+	}
+	return true;
+}
+// ---- a bucket that outgrows its LDS region switches the document to the two-place accessors; one that outgrows its spill row
+// hands the document over (false).  `bound`: entries the batch adds to one bucket at most; exact counts only when that is too many.
+static __device__ __forceinline__ bool checkBuckets( LR L, Wave& w, KP P, u32 bound, const bool inst[ 3], const u32 hB[ 3])
+{
+	bool over = false, fail = false;
+	if (LANE < 16u)
+	{
+		const u32 sz = w.bsizeV, cap = w.bmetaV >> 16;		// (register mirrors: no LDS round trip on the way)
+		over = sz + bound > cap;
+		fail = sz + bound > cap + (u32)FAST_SPILL_BUCKET || sz + bound > 0xFFFu;
+	}
+	if (__ballot( over))
+	{
+		u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+		for (int j=0; j<3; ++j) if (inst[ j]) byteInc( c0, c1, c2, c3, hB[ j]);
+		const u32 i0 = waveScanAdd( c0), i1 = waveScanAdd( c1), i2 = waveScanAdd( c2), i3 = waveScanAdd( c3);
+		const u32 t0 = (u32)__builtin_amdgcn_readlane( i0, 63), t1 = (u32)__builtin_amdgcn_readlane( i1, 63);
+		const u32 t2 = (u32)__builtin_amdgcn_readlane( i2, 63), t3 = (u32)__builtin_amdgcn_readlane( i3, 63);
+		over = false; fail = false;
+		if (LANE < 16u)
+		{
+			const u32 sz = w.bsizeV + byteField( t0, t1, t2, t3, LANE), cap = w.bmetaV >> 16;
+			over = sz > cap;
+			fail = sz > cap + (u32)FAST_SPILL_BUCKET || sz > 0xFFFu;
+		}
+		if (__ballot( fail)) { FALLBACK( FB_BUCKET_SIZE); return false; }
+		if (__ballot( over)) w.spill = 1;
+	}
+	return true;
+}
+
+// ---- a COMPACT static batch (l2_fast.h): two 16-byte loads per lane (c0, c1: FastStatic), one round of LDS reads, stores.
+template <bool SP>
+static __device__ __forceinline__ void installCompactT( LR L, Wave& w, KP P, u32 ki0, u32 nb, u32 sord, u32 r,
+	const uint4 c0, const uint4 c1, u32 row, u32 cnt, const u32 oldB[ 2], const u32 metaB[ 2])
+{
+	const bool have = LANE < nb;
+	const u32 ev[ 2] = {c0.x, c0.z}, info[ 2] = {c0.y, c0.w};
+	const u32 hw0 = c1.x, misc = c1.y, ranks = c1.z;
+	const u32 totals = bcast0( c1.w), itemsTotal = (bcast0( c1.z) >> 16) & 0xFFu;		// (the same in every line of the batch)
+	if (have)
+	{
+		// ---- expiry row of position sord+range (cpp:1066-1082), triggers (cpp:1204-1250 -> EventTriggerTable::add :114-131)
+		stExp<SP>( L, w, P, row, cnt + ((misc >> FSM_EXPRANK_SHIFT) & 0xFFu), r);
+#pragma unroll
+		for (int t=0; t<2; ++t)
+		{
+			if (info[ t] & FSI_PRESENT)
+			{
+				const u32 h = (info[ t] >> FSI_BUCKET_SHIFT) & 15u, j = info[ t] >> FSI_SLOT_SHIFT;
+				const u32 pos = oldB[ t] + ((info[ t] >> FSI_RANK_SHIFT) & 0xFFu);
+				stEnt<SP>( L, w, P, h, metaB[ t], pos, ev[ t], (4*r + j) | ((info[ t] & 0xFFu) << 16) | (((info[ t] >> 8) & 0xFFu) << 24));
+				stLink<SP>( L, w, P, r, j, (h << 12) | pos);
+			}
+		}
+	}
+	WAVE_FENCE();
+	const u32 nItems = P.withItems ? ((hw0 >> H_NITEMS_SHIFT) & H_NITEMS_MASK) : 0u;
+	if (have)
+	{
+		// the last lane of an expiry group / of a bucket's entries closes it (every lane has read the old counts before)
+		const u32 close = (misc >> FSM_EXPCLOSE_SHIFT) & 0xFFu;
+		if (close) L.expCnt[ row] = (u16)(cnt + close);
+#pragma unroll
+		for (int t=0; t<2; ++t) if (info[ t] & FSI_LAST) L.bsize[ (info[ t] >> FSI_BUCKET_SHIFT) & 15u] = oldB[ t] + ((info[ t] >> FSI_RANK_SHIFT) & 0xFFu) + 1u;
+		// ---- the rule itself: its word, its install line + key lexem
+		u32 hw = (hw0 & ~(H_NITEMS_MASK << H_NITEMS_SHIFT)) | (nItems << H_NITEMS_SHIFT);
+		hw |= (misc & FSM_END_SET) ? (((sord + 1u) & 0xFFu) << H_END_SHIFT) : (u32)H_ENDZERO;
+		stHot<SP>( L, w, P, r, hw);
+		stKl<SP>( L, w, P, r, ki0 + LANE, w.lbase);
+	}
+	// ---- results (cpp:954-965), in lane order; the items are the key lexem under the key triggers' variables, latest first
+	const u32 nres = (totals >> 16) & 0xFFu;
+	if (nres)
+	{
+		if (w.nStaged + nres > P.spill.maxStaged) { FALLBACK( FB_STAGED); return; }
+		if (have && (misc & FSM_RESULT_NOW))
+		{
+			const u32* K = (const u32*)&P.keyinst[ ki0 + LANE];
+			const u32 handle = K[ 0], fmt = K[ 1], vw = K[ 14];
+			const u32 v0 = vw & 0xFFu, v1 = (vw >> 8) & 0xFFu, v2 = (vw >> 16) & 0xFFu;
+			const u32 va = nItems == 3 ? v2 : nItems == 2 ? v1 : v0;
+			const u32 vb = nItems == 3 ? v1 : v0;
+			const u32 vars = nItems == 0 ? 0u : nItems == 1 ? va : nItems == 2 ? (va | (vb << 8)) : (va | (vb << 8) | (v0 << 16));
+			stageResult( w, P, w.nStaged + (ranks & 0xFFu), handle, fmt, (misc & FSM_START_SET) ? w.lbase : 0u, w.lbase, nItems, vars, w.lbase, w.lbase, w.lbase);
+		}
+		w.nStaged += nres;
+		if (P.withItems) w.nStagedItems += itemsTotal;
+	}
+	// ---- rules that finished or were deleted by their own key event: deactivated after the installs (cpp:1030-1034)
+	const u32 nd = totals >> 24;
+	if (nd)
+	{
+		if (w.nDispose + nd > P.spill.maxRules) { FALLBACK( FB_DISPOSE); return; }
+		if (w.nDispose + nd > (u32)FAST_LISTCAP) w.spill = 1;
+		if (have && (misc & FSM_DISPOSE_NOW))
+		{
+			const u32 at = w.nDispose + ((ranks >> 8) & 0xFFu);
+			if (at < (u32)FAST_LISTCAP) L.list[ at] = (u16)r; else w.sp[ P.spill.oList + at] = r;
+		}
+		w.nDispose += nd;
+	}
+	w.nTrig += totals & 0xFFu;
+	w.nSignals += (totals >> 8) & 0xFFu;
+	WAVE_FENCE();
+}
+
+// pc0, pc1: the compact lines of the event's first batch, requested before its bucket scan (the load is under way while the
+// triggers fire)
+static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb, u32 kc, u32 sord, const uint4 pc0, const uint4 pc1)
+{
 	for (u32 base=0; base<kc && !w.err; base+=64)
 	{
 		const u32 nb = (kc - base) < 64u ? (kc - base) : 64u;
 		const bool have = LANE < nb;
+		uint4 c0 = pc0, c1 = pc1;
+		if (base)
+		{
+			c0 = make_uint4( 0,0,0,0); c1 = c0;
+			if (have) { const u32* S = (const u32*)&P.statics[ kb + base + LANE]; c0 = ld4( S); c1 = ld4( S+4); }
+		}
+#ifdef SPA_PROF_INSTALL
+		u64 pi0 = __builtin_amdgcn_s_memtime();
+#define PROF_I( SLOT, V) do { if (__ballot( (V) == 0xFFFFFFF1u)) w.err = SPD_ERR_INTERNAL; const u64 pi1 = __builtin_amdgcn_s_memtime(); w.prof[ SLOT] += pi1 - pi0; pi0 = pi1; } while (0)
+#else
+#define PROF_I( SLOT, V) do {} while (0)
+#endif
+		if ((bcast0( c1.y) & FSM_BATCH_COMPACT) && sord != 0)
+		{
+			PROF_I( 6, c1.y);
+			// ---- compact static batch: everything but the absolute positions is in the lines
+			const u32 info[ 2] = {c0.y, c0.w};
+			const u32 row = (sord + (c1.y & FSM_RANGE_MASK)) & ((1u << P.expShift) - 1u);
+			u32 cnt = 0, oldB[ 2] = {0,0}, metaB[ 2] = {0,0};
+			bool inst[ 3] = {false,false,false}; u32 hB[ 3] = {0,0,0};
+			if (have)
+			{
+				cnt = (u32)L.expCnt[ row];
+#pragma unroll
+				for (int t=0; t<2; ++t)
+				{
+					if (info[ t] & FSI_PRESENT) { hB[ t] = (info[ t] >> FSI_BUCKET_SHIFT) & 15u; inst[ t] = true; oldB[ t] = L.bsize[ hB[ t]]; metaB[ t] = L.bmeta[ hB[ t]]; }
+				}
+			}
+			w.nInstalled += nb;
+			u32 r;
+			if (!allocRuleIds( L, w, P, __ballot( have), r)) return;
+			if (!w.spill)
+			{
+				if (__ballot( have && cnt + nb > ((u32)FAST_EXPCAP >> P.expShift))) w.spill = 1;	// (upper bound: the whole batch in my row)
+			}
+			if (!checkBuckets( L, w, P, bcast0( c1.w) & 0xFFu, inst, hB)) return;
+			PROF_I( 7, cnt + oldB[ 0] + oldB[ 1] + r);
+			if (w.spill) installCompactT<true>( L, w, P, kb + base, nb, sord, r, c0, c1, row, cnt, oldB, metaB);
+			else installCompactT<false>( L, w, P, kb + base, nb, sord, r, c0, c1, row, cnt, oldB, metaB);
+			PROF_I( 11, 0u);
+			w.bsizeV = L.bsize[ LANE & 15u];
+			continue;
+		}
 		uint4 q0 = make_uint4( 0,0,0,0), q1 = q0, q2 = q0, q3 = q0;
 		if (have)
 		{
@@ -783,7 +985,6 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 		const bool mat = have && !dropped;
 		const u64 matMask = __ballot( mat);
 		const u32 nmat = (u32)__popcll( matMask);
-		const u32 rank = (u32)__popcll( matMask & lanesBelow());
 		// ---- statistics (cpp:1251, :780)
 		w.nInstalled += nb;
 		if (isStatic) w.nSignals += (bcast0( q3.y) >> 8) & 0xFFu;
@@ -792,34 +993,8 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 			u32 incl = waveScanAdd( have ? sim.nFires : 0u);
 			w.nSignals += (u32)__builtin_amdgcn_readlane( incl, 63);
 		}
-		// ---- rule ids: LDS free stack, LDS bump, spill free stack, spill bump
-		u32 r = 0;
-		if (nmat)
-		{
-			const u32 a = w.freeN < nmat ? w.freeN : nmat;
-			const u32 roomL = (u32)R - w.usedL;
-			const u32 b = (nmat - a) < roomL ? (nmat - a) : roomL;
-			const u32 rest = nmat - a - b;
-			if (rest)
-			{
-				const u32 c = w.sFreeN < rest ? w.sFreeN : rest;
-				const u32 d = rest - c;
-				if ((u32)R + w.usedS + d > P.spill.maxRules) { FALLBACK( FB_RULES); return; }
-				w.spill = 1;
-				if (mat && rank >= a+b)
-				{
-					if (rank < a+b+c) r = (u32)R + w.sp[ P.spill.oFree + w.sFreeN - 1 - (rank - a - b)];
-					else r = (u32)R + w.usedS + (rank - a - b - c);
-				}
-				w.sFreeN -= c; w.usedS += d;
-			}
-			if (mat)
-			{
-				if (rank < a) r = (u32)L.freeS[ w.freeN - 1 - rank];
-				else if (rank < a+b) r = w.usedL + (rank - a);
-			}
-			w.freeN -= a; w.usedL += b;
-		}
+		u32 r;
+		if (!allocRuleIds( L, w, P, matMask, r)) return;
 		// ---- an expiry row or a bucket that outgrows its LDS region switches the document to the two-place accessors
 		if (nmat && !w.spill)
 		{
@@ -828,34 +1003,11 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 			if (__ballot( over)) w.spill = 1;
 		}
 		{
-			u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+			bool inst[ 3]; u32 hB[ 3];
 #pragma unroll
-			for (int j=0; j<3; ++j) if (mat && (tInfo[ j] & FTI_INSTALL)) byteInc( c0, c1, c2, c3, (tInfo[ j] >> FTI_BUCKET_SHIFT) & 15u);
+			for (int j=0; j<3; ++j) { inst[ j] = mat && (tInfo[ j] & FTI_INSTALL); hB[ j] = (tInfo[ j] >> FTI_BUCKET_SHIFT) & 15u; }
 			// upper bound without the scan: the batch adds at most nmat x 3 entries to a bucket (a static batch: its total)
-			const u32 bound = isStatic ? (bcast0( q3.y) & 0xFFu) : 3*nmat;
-			bool over = false, fail = false;
-			if (LANE < 16u)
-			{
-				const u32 sz = L.bsize[ LANE], cap = L.bmeta[ LANE] >> 16;
-				over = sz + bound > cap;
-				fail = sz + bound > cap + (u32)FAST_SPILL_BUCKET || sz + bound > 0xFFFu;
-			}
-			if (__ballot( over))
-			{
-				// exact sizes
-				u32 i0 = waveScanAdd( c0), i1 = waveScanAdd( c1), i2 = waveScanAdd( c2), i3 = waveScanAdd( c3);
-				const u32 t0 = (u32)__builtin_amdgcn_readlane( i0, 63), t1 = (u32)__builtin_amdgcn_readlane( i1, 63);
-				const u32 t2 = (u32)__builtin_amdgcn_readlane( i2, 63), t3 = (u32)__builtin_amdgcn_readlane( i3, 63);
-				over = false; fail = false;
-				if (LANE < 16u)
-				{
-					const u32 sz = L.bsize[ LANE] + byteField( t0, t1, t2, t3, LANE), cap = L.bmeta[ LANE] >> 16;
-					over = sz > cap;
-					fail = sz > cap + (u32)FAST_SPILL_BUCKET || sz > 0xFFFu;
-				}
-				if (__ballot( fail)) { FALLBACK( FB_BUCKET_SIZE); return; }
-				if (__ballot( over)) w.spill = 1;
-			}
+			if (!checkBuckets( L, w, P, isStatic ? (bcast0( q3.y) & 0xFFu) : 3*nmat, inst, hB)) return;
 		}
 		if (isStatic)
 		{
@@ -864,6 +1016,7 @@ static __device__ __forceinline__ void installBatch( LR L, Wave& w, KP P, u32 kb
 		}
 		else if (w.spill) installBatchT<true>( L, w, P, kb, nb, sord, matMask, r, q0, q1, q2, sim);
 		else installBatchT<false>( L, w, P, kb, nb, sord, matMask, r, q0, q1, q2, sim);
+		w.bsizeV = L.bsize[ LANE & 15u];		// (the mirror the next batch's capacity check reads)
 	}
 	// the register mirrors of the bucket sizes and the expiry row lengths (requested now, needed at the next event at the earliest)
 	w.bsizeV = L.bsize[ LANE & 15u];
@@ -881,14 +1034,14 @@ static __device__ __forceinline__ void scanAndFire( LR L, Wave& w, KP P, u32 id,
 	for (u32 base=0; base<n && !w.err; base+=64)
 	{
 		const u32 i = base + LANE;
-		u32 e = 0;
-		if (i < n) e = ldEv<SP>( L, w, P, h, meta, i);
-		u64 m = __ballot( i < n && e == id);
+		uint2 en = make_uint2( 0, 0);
+		if (i < n) en = ldEnt<SP>( L, w, P, h, meta, i);		// (whole entries: a hit's trigger word comes out of the lane's register, not out of a second read)
+		u64 m = __ballot( i < n && en.x == id);
 		while (m && !w.err)
 		{
 			const u32 p = (u32)__builtin_ctzll( m);
 			m &= m-1;
-			const u32 tsv = bcast0( ldTs<SP>( L, w, P, h, meta, base + p));
+			const u32 tsv = (u32)__builtin_amdgcn_readlane( en.y, p);
 			fireSignal<SP>( L, w, P, tsv, ordpos);
 		}
 	}
@@ -989,16 +1142,18 @@ static __device__ __forceinline__ void runKernel()
 					w.openLo = lo;
 				}
 				w.nDispose = 0;
+				// the programs keyed by this event: their (compact) install lines are requested now and read after the bucket scan
+				const u32 kb = __builtin_amdgcn_readlane( kBegin, k), kc = __builtin_amdgcn_readlane( kCount, k);
+				const u32 stopIdx = __builtin_amdgcn_readlane( kStop, k);
+				uint4 pc0 = make_uint4( 0,0,0,0), pc1 = pc0;
+				if (LANE < kc) { const u32* S = (const u32*)&P.statics[ kb + LANE]; pc0 = ld4( S); pc1 = ld4( S+4); }
 				if (id)
 				{
 					if (w.spill) scanAndFire<true>( L, w, P, id, ordpos); else scanAndFire<false>( L, w, P, id, ordpos);
 				}
 				PROF_ADD( 0);
 				if (w.err) break;
-				// install the programs keyed by this event
-				const u32 kb = __builtin_amdgcn_readlane( kBegin, k), kc = __builtin_amdgcn_readlane( kCount, k);
-				const u32 stopIdx = __builtin_amdgcn_readlane( kStop, k);
-				if (kc) installBatch( L, w, P, kb, kc, ordpos);
+				if (kc) installBatch( L, w, P, kb, kc, ordpos, pc0, pc1);
 				PROF_ADD( 1);
 				if (w.err) break;
 				// deactivate rules that finished or were deleted
@@ -1107,11 +1262,12 @@ static __device__ __forceinline__ void runKernel()
 } // anonymous namespace
 
 // ================================================================== kernel instances (LDS capacities: rules, bucket entries)
-#ifdef SPA_L2_FAST_WAVES_PER_EU
-#define SPA_L2_FAST_OCC __attribute__((amdgpu_waves_per_eu( SPA_L2_FAST_WAVES_PER_EU, SPA_L2_FAST_WAVES_PER_EU)))
-#else
-#define SPA_L2_FAST_OCC
+// 4 waves per SIMD = 16 per CU is what 10 KB of LDS per document allow; the register budget that goes with it (128) is stated
+// because the kernel is latency bound: one register more would cost a quarter of the documents in flight
+#ifndef SPA_L2_FAST_WAVES_PER_EU
+#define SPA_L2_FAST_WAVES_PER_EU 4
 #endif
+#define SPA_L2_FAST_OCC __attribute__((amdgpu_waves_per_eu( SPA_L2_FAST_WAVES_PER_EU, SPA_L2_FAST_WAVES_PER_EU)))
 #define SPA_FAST_INSTANCE( NAME, RR, TT) \
 	extern "C" __global__ __launch_bounds__(64) SPA_L2_FAST_OCC void NAME( FastParams kernelArgs) { Engine<RR,TT>::runKernel(); }
 SPA_FAST_INSTANCE( spa_l2_fast_kernel_s, 192, 312)

@@ -9,12 +9,14 @@
 namespace spa {
 
 static_assert( sizeof(FastKeyInst) == 64, "one install record per 64-byte line");
+static_assert( sizeof(FastStatic) == 32, "compact static line");
 static_assert( sizeof(FastKeyEntry) == sizeof(DevKeyEntry), "the fast kernel reads the general key table in place");
 
 // Why a rule set is not eligible (diagnostics, SPA_L2_VERBOSE), empty when it is.
-std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out)
+std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out, std::vector<FastStatic>* statics)
 {
 	out.clear();
+	if (statics) statics->clear();
 	if (ft.nofStopWords > FAST_MAXSTOP) return "more than 64 stop words";
 	if (ft.keylist.size() >= (1u<<20)) return "more than 2^20 key list entries";	// (a rule keeps its install line in 20 bits)
 	// events somebody waits for or is keyed by
@@ -53,6 +55,7 @@ std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out
 	}
 	out.resize( ft.keylist.size());
 	std::memset( out.data(), 0, out.size()*sizeof(FastKeyInst));
+	if (statics) { statics->resize( ft.keylist.size() ? ft.keylist.size() : 1); std::memset( statics->data(), 0, statics->size()*sizeof(FastStatic)); }
 	for (size_t ei=0; ei<ft.keytab.size(); ++ei)
 	{
 		const DevKeyEntry& e = ft.keytab[ ei];
@@ -156,6 +159,39 @@ std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out
 				B[ l].flags |= FKF_BATCH_STATIC;
 				B[ l].totals = trigTotal | (firesTotal << 8) | (resTotal << 16) | (dispTotal << 24);
 				B[ l].items |= itemsTotal << 24;
+			}
+			// compact form of the batch (l2_fast.h): every program installs at most two triggers
+			if (!statics) continue;
+			bool compact = true;
+			for (uint32_t l=0; l<nb && compact; ++l)
+			{
+				int n = 0;
+				for (int j=0; j<3; ++j) if (B[ l].trig[ j].info & FTI_INSTALL) ++n;
+				if (n > 2) compact = false;
+			}
+			if (!compact) continue;
+			FastStatic* C = &(*statics)[ e.listBegin + b0];
+			for (uint32_t l=0; l<nb; ++l)
+			{
+				const FastKeyInst& ki = B[ l];
+				FastStatic& fs = C[ l];
+				int n = 0;
+				for (int j=0; j<3; ++j)
+				{
+					const uint32_t info = ki.trig[ j].info;
+					if (!(info & FTI_INSTALL)) continue;
+					const uint32_t sv = (info & FTI_SIGVAL_MASK) | (((info >> FTI_SIGTYPE_SHIFT) & FTI_SIGTYPE_MASK) << 4) | ((info & FTI_HASVAR) ? 0x80u : 0u);
+					const uint32_t ci = sv | ((info >> FTI_VAR_SHIFT) << 8) | (((info >> FTI_BUCKET_SHIFT) & 15u) << FSI_BUCKET_SHIFT)
+						| (((ki.ranksB >> (8*j)) & 0xFFu) << FSI_RANK_SHIFT) | (((ki.ranksB >> (24+j)) & 1u) ? (uint32_t)FSI_LAST : 0u) | (uint32_t)FSI_PRESENT | ((uint32_t)j << FSI_SLOT_SHIFT);
+					if (n == 0) { fs.ev0 = ki.trig[ j].event; fs.info0 = ci; } else { fs.ev1 = ki.trig[ j].event; fs.info1 = ci; }
+					++n;
+				}
+				fs.hw0 = ki.hw0;
+				fs.misc = ((ki.meta >> FKI_RANGE_SHIFT) & FKI_RANGE_MASK) | ((ki.ranksA & 0xFFu) << FSM_EXPRANK_SHIFT) | (((ki.ranksA >> 8) & 0xFFu) << FSM_EXPCLOSE_SHIFT)
+					| ((ki.flags & FKF_END_SET) ? (uint32_t)FSM_END_SET : 0u) | ((ki.flags & FKF_START_SET) ? (uint32_t)FSM_START_SET : 0u)
+					| ((ki.flags & FKF_RESULT_NOW) ? (uint32_t)FSM_RESULT_NOW : 0u) | ((ki.flags & FKF_DISPOSE_NOW) ? (uint32_t)FSM_DISPOSE_NOW : 0u) | (uint32_t)FSM_BATCH_COMPACT;
+				fs.ranks = ((ki.ranksA >> 16) & 0xFFu) | (((ki.ranksA >> 24) & 0xFFu) << 8) | (itemsTotal << 16);
+				fs.totals = ki.totals;
 			}
 		}
 	}
