@@ -218,6 +218,15 @@ static __device__ __forceinline__ void pushList( LR L, Wave& w, KP P, u32 i, u32
 
 // ---------------------------------------------------------------- staged results
 // {resultHandle, formatHandle, first lexem, last lexem, nItems | var0<<8 | var1<<16 | var2<<24, item lexems x3} (items latest first)
+// or, for a rule that completes with what its static install line tells (no read of that line on the way: the epilogue reads it,
+// 64 results at a time): {STAGED_LINE | install line, -, first lexem, last lexem, static items (2) | new item (1) << 2 | its variable << 8, key lexem}
+enum {STAGED_LINE=0x80000000u};
+static __device__ __forceinline__ void stageLineResult( Wave& w, KP P, u32 at, u32 ki, u32 startLex, u32 endLex, u32 nStatic, u32 hasNew, u32 newVar, u32 keyLex)
+{
+	u32* S = &w.sp[ P.spill.oStaged + 8*at];
+	st4( S, (u32)STAGED_LINE | ki, 0u, startLex, endLex);
+	*(uint2*)(S+4) = make_uint2( nStatic | (hasNew << 2) | (newVar << 8), keyLex);
+}
 static __device__ __forceinline__ void stageResult( Wave& w, KP P, u32 at, u32 handle, u32 fmt, u32 startLex, u32 endLex, u32 nItems, u32 vars, u32 i0, u32 i1, u32 i2)
 {
 	u32* S = &w.sp[ P.spill.oStaged + 8*at];
@@ -291,7 +300,22 @@ static __device__ __forceinline__ void fireSignal( LR L, Wave& w, KP P, u32 tsv,
 		}
 		newStart = !(hw & H_HASSTART);
 	}
-	if (!done && (match || newItem || newStart))
+	if (!done && match && !(hw & H_COLD))
+	{
+		// ---- a rule completes with what its install line tells for its key lexem (+ the event that completes it): nothing is read here
+		if (hw & H_VISIBLE)
+		{
+			if (w.nStaged < P.spill.maxStaged)
+			{
+				const u32 kl = bcast0( ldKl<SP>( L, w, P, r)), lx = keyLexemOf( kl, w.lbase);
+				if (LANE == 0) stageLineResult( w, P, w.nStaged, kl & 0xFFFFFu, newStart ? w.lbase : lx, w.lbase, nItems, newItem ? 1u : 0u, variable, lx);
+				w.nStaged += 1; w.nStagedItems += nItems + (newItem ? 1u : 0u);
+			}
+			else FALLBACK( FB_STAGED);
+		}
+		if (newItem) ++nItems;
+	}
+	else if (!done && (match || newItem || newStart))
 	{
 		// ---- what the rule has captured: its record, or the key lexem + the install line
 		u32* cold = &w.sp[ P.spill.oCold + 8*r];		// {resultHandle, formatHandle, first taken lexem, item0, item1, item2, -, -}; item = lexem | variable<<24
@@ -833,15 +857,7 @@ static __device__ __forceinline__ void installCompactT( LR L, Wave& w, KP P, u32
 	{
 		if (w.nStaged + nres > P.spill.maxStaged) { FALLBACK( FB_STAGED); return; }
 		if (have && (misc & FSM_RESULT_NOW))
-		{
-			const u32* K = (const u32*)&P.keyinst[ ki0 + LANE];
-			const u32 handle = K[ 0], fmt = K[ 1], vw = K[ 14];
-			const u32 v0 = vw & 0xFFu, v1 = (vw >> 8) & 0xFFu, v2 = (vw >> 16) & 0xFFu;
-			const u32 va = nItems == 3 ? v2 : nItems == 2 ? v1 : v0;
-			const u32 vb = nItems == 3 ? v1 : v0;
-			const u32 vars = nItems == 0 ? 0u : nItems == 1 ? va : nItems == 2 ? (va | (vb << 8)) : (va | (vb << 8) | (v0 << 16));
-			stageResult( w, P, w.nStaged + (ranks & 0xFFu), handle, fmt, (misc & FSM_START_SET) ? w.lbase : 0u, w.lbase, nItems, vars, w.lbase, w.lbase, w.lbase);
-		}
+			stageLineResult( w, P, w.nStaged + (ranks & 0xFFu), ki0 + LANE, (misc & FSM_START_SET) ? w.lbase : 0u, w.lbase, nItems, 0u, 0u, w.lbase);
 		w.nStaged += nres;
 		if (P.withItems) w.nStagedItems += itemsTotal;
 	}
@@ -1202,6 +1218,28 @@ static __device__ __forceinline__ void runKernel()
 				const bool hv = ri < nres;
 				uint4 s0 = make_uint4( 0,0,0,0), s1 = s0;
 				if (hv) { const u32* S = &w.sp[ P.spill.oStaged + 8*ri]; s0 = ld4( S); s1 = ld4( S+4); }
+				if (hv && (s0.x & (u32)STAGED_LINE))
+				{
+					// handle, format and the variables of the static items come from the install line (latest item first)
+					const u32* K = (const u32*)&P.keyinst[ s0.x & 0xFFFFFu];
+					const u32 handle = K[ 0], fmt = K[ 1], vw = K[ 14];
+					const u32 nStatic = s1.x & 3u, hasNew = (s1.x >> 2) & 1u, newVar = (s1.x >> 8) & 0xFFu, lx = s1.y, endLex = s0.w;
+					u32 vv[ 3] = {0,0,0}, ll[ 3] = {0,0,0};
+					u32 n = 0;
+					if (hasNew) { vv[ 0] = newVar; ll[ 0] = endLex; n = 1; }
+#pragma unroll
+					for (int k=2; k>=0; --k)
+					{
+						if ((u32)k < nStatic)
+						{
+							const u32 v = (vw >> (8*k)) & 0xFFu;
+							if (n == 0) { vv[ 0] = v; ll[ 0] = lx; } else if (n == 1) { vv[ 1] = v; ll[ 1] = lx; } else if (n == 2) { vv[ 2] = v; ll[ 2] = lx; }
+							++n;
+						}
+					}
+					s0.x = handle; s0.y = fmt;
+					s1.x = n | (vv[ 0] << 8) | (vv[ 1] << 16) | (vv[ 2] << 24); s1.y = ll[ 0]; s1.z = ll[ 1]; s1.w = ll[ 2];
+				}
 				const u32 ni = P.withItems ? (s1.x & 0xFFu) : 0u;
 				u32 incl = waveScanAdd( ni);
 				const u64 mine = ip + (incl - ni);

@@ -138,7 +138,7 @@ std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out
 					tmask |= 1u << j; trigTotal += 1;
 				}
 				ki.hw0 = sim.value | (sim.count << H_COUNT_SHIFT) | (uint32_t)H_ACTIVE | (tmask << H_TMASK_SHIFT) | (sim.nItems << H_NITEMS_SHIFT)
-					| ((sim.flags & S_DONE) ? (uint32_t)H_DONE : 0u) | ((sim.flags & S_HASSTART) ? (uint32_t)H_HASSTART : 0u);
+					| ((sim.flags & S_DONE) ? (uint32_t)H_DONE : 0u) | ((sim.flags & S_HASSTART) ? (uint32_t)H_HASSTART : 0u) | (ki.resultHandle ? (uint32_t)H_VISIBLE : 0u);
 				if (sim.end) ki.flags |= FKF_END_SET;
 				if (sim.flags & S_TOOK) ki.flags |= FKF_START_SET;
 				const bool resultNow = (sim.flags & S_RESULT) && ki.resultHandle != 0;
