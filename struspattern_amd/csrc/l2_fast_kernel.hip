@@ -419,9 +419,11 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 			if (__ballot( lk[ 0] == 0xFFFFFFFFu)) w.err = SPD_ERR_INTERNAL;
 #endif
 			PROF_D( 6);
+			const bool slot2 = __ballot( (mask & 4u) != 0) != 0;		// (two-term rules never use their third trigger slot: its code is skipped wave-wide)
 			u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
-			for (int j=0; j<3; ++j) if ((mask >> j) & 1u) byteInc( c0, c1, c2, c3, lk[ j] >> 12);
+			for (int j=0; j<2; ++j) if ((mask >> j) & 1u) byteInc( c0, c1, c2, c3, lk[ j] >> 12);
+			if (slot2) { if (mask & 4u) byteInc( c0, c1, c2, c3, lk[ 2] >> 12); }
 			const u32 i0 = waveScanAdd( c0), i1 = waveScanAdd( c1), i2 = waveScanAdd( c2), i3 = waveScanAdd( c3);	// (fields < 256: 64 x 3)
 			const u32 e0 = i0 - c0, e1 = i1 - c1, e2 = i2 - c2, e3 = i3 - c3;
 			const u32 t0 = (u32)__builtin_amdgcn_readlane( i0, 63), t1 = (u32)__builtin_amdgcn_readlane( i1, 63);
@@ -431,16 +433,22 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 			const u32 qoff = waveScanAdd( tot) - tot;
 			const u32 total = (u32)__builtin_amdgcn_readlane( qoff + tot, 15);
 			// a rule's triggers go last installed first (slot 2, 1, 0)
+			if (slot2)
+			{
+				const u32 h = lk[ 2] >> 12;
+				const u32 qo = (u32)__builtin_amdgcn_ds_bpermute( (int)(h << 2), (int)qoff);	// (all lanes: the lanes that hold the offsets must take part)
+				if (mask & 4u) L.rq[ qo + byteField( e0, e1, e2, e3, h)] = (u16)(4u*r + 2u);
+			}
 #pragma unroll
-			for (int j=2; j>=0; --j)
+			for (int j=1; j>=0; --j)
 			{
 				const u32 h = lk[ j] >> 12;
-				const u32 qo = (u32)__builtin_amdgcn_ds_bpermute( (int)(h << 2), (int)qoff);	// (all lanes: the lanes that hold the offsets must take part)
+				const u32 qo = (u32)__builtin_amdgcn_ds_bpermute( (int)(h << 2), (int)qoff);
 				if ((mask >> j) & 1u)
 				{
 					u32 mineBefore = 0;
-#pragma unroll
-					for (int jj=2; jj>j; --jj) if (((mask >> jj) & 1u) && (lk[ jj] >> 12) == h) ++mineBefore;
+					if (slot2 && (mask & 4u) && (lk[ 2] >> 12) == h) ++mineBefore;
+					if (j == 0 && (mask & 2u) && (lk[ 1] >> 12) == h) ++mineBefore;
 					L.rq[ qo + byteField( e0, e1, e2, e3, h) + mineBefore] = (u16)(4u*r + (u32)j);
 				}
 			}
