@@ -308,6 +308,9 @@ double sp_lexer_ctx_last_kernel_ms(sp_lexer_ctx_t* c);
 /* the same interval split at the boundary of the lexer's two kernels (automaton scan; literals + start of match +
  * handler + ordinal positions) */
 int sp_lexer_ctx_last_kernel_ms_split(sp_lexer_ctx_t* c, double* scan_ms, double* post_ms);
+/* the same in three parts: automaton scan; words kernel (whole-word literals and word shapes, found where runs of word
+ * characters end); start of match + handler + ordinal positions */
+int sp_lexer_ctx_last_kernel_ms_split3(sp_lexer_ctx_t* c, double* scan_ms, double* words_ms, double* post_ms);
 int sp_lexer_ctx_reserve_output(sp_lexer_ctx_t* c, uint64_t lexems);
 int sp_lexer_ctx_grow_arena(sp_lexer_ctx_t* c);
 

@@ -445,6 +445,13 @@ class PatternLexerContext:
             raise PatternError("no timed launch")
         return a.value, b.value
 
+    def lastKernelMsSplit3(self):
+        """(scan kernel ms, words kernel ms, post-processing kernel ms) of the last launch"""
+        a, b, d = ctypes.c_double(-1.0), ctypes.c_double(-1.0), ctypes.c_double(-1.0)
+        if self._L.sp_lexer_ctx_last_kernel_ms_split3(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(d)) != 0:
+            raise PatternError("no timed launch")
+        return a.value, b.value, d.value
+
     def reserveOutput(self, lexems):
         self._L.sp_lexer_ctx_reserve_output(self._h, lexems)
 

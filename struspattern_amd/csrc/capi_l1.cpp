@@ -14,7 +14,7 @@
 #include <vector>
 
 namespace spa {
-hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels);
+hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned wordBlocks, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords);
 }
 using namespace spa;
 
@@ -41,18 +41,22 @@ struct sp_lexer_ctx
 	int device;
 	std::string lasterror;
 	DeviceBuffer dByteClass, dClassCtx, dCharMask, dStartMask, dAcceptMask, dShiftDst, dSelfLoop, dExSrc, dExDst, dExCount,
-		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit, dApprox, dCharCp, dCharPos, dCpBlocks, dCpPages, dUnitStart, dDocSequential, dNullable;
+		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit, dApprox, dCharCp, dCharPos, dCpBlocks, dCpPages, dUnitStart, dDocSequential, dNullable,
+		dScanImage, dShapes, dShapePats;
 	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst; unsigned blockThreads;
-	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus, dQueue, dReportCount;
+	uint32_t imgWords, imgAccept, imgStart, imgShift, imgSelf, imgExSrc, imgExDst;	// offsets inside the image of all passes (dTableImage); lds*: inside the image of the scanned passes
+	bool wordsKernel;		// plain tables: literals and word shapes are found by the words kernel
+	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus, dQueue, dReportCount, dWordQueue, dWordCount;
 	uint32_t queueMul;		// report queue between the two kernels: queueMul/16 reports per text byte (+64 per document)
 	uint32_t queueCap, eventCap;
 	unsigned arenaWaves; uint64_t arenaWords;
 	uint64_t lexemCapacity, minLexemCapacity;
 	unsigned numCUs;
-	hipEvent_t evStart, evMid, evStop; bool evValid;
+	hipEvent_t evStart, evMid, evWords, evStop; bool evValid;
 	hipStream_t lastStream; size_t lastNdocs;
 	sp_lexer_ctx() :inst(0),device(0),ldsWords(0),ldsAccept(0),ldsStart(0),ldsShift(0),ldsSelf(0),ldsExSrc(0),ldsExDst(0),blockThreads(256),queueMul(8),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
-		,numCUs(256),evStart(0),evMid(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0){}
+		,numCUs(256),evStart(0),evMid(0),evWords(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0)
+		,imgWords(0),imgAccept(0),imgStart(0),imgShift(0),imgSelf(0),imgExSrc(0),imgExDst(0),wordsKernel(false){}
 };
 
 extern "C" {
@@ -151,6 +155,15 @@ size_t sp_lexer_dump_tables( const sp_lexer_t* l, uint64_t** out)
 	for (size_t i=0; i<T.cpBlocks.size(); ++i) b.push_back( T.cpBlocks[ i]);
 	b.push_back( T.cpPages.size());
 	for (size_t i=0; i<T.cpPages.size(); ++i) b.push_back( T.cpPages[ i]);
+	// word shapes: passes the scan kernel runs, expressions taken as shapes, then per table entry {tag, key, patCount, pattern indices...}
+	b.push_back( T.scanPasses); b.push_back( T.nofShapes);
+	for (size_t i=0; i<T.shapes.size(); ++i)
+	{
+		const DevShape& e = T.shapes[ i];
+		if (!e.tag) continue;
+		b.push_back( e.tag); b.push_back( e.key); b.push_back( e.patCount);
+		for (uint32_t k=0; k<e.patCount; ++k) b.push_back( T.shapePats[ e.patBegin+k]);
+	}
 	*out = (uint64_t*)std::malloc( (b.size()+1)*sizeof(uint64_t));
 	if (!*out) return 0;
 	std::memcpy( *out, b.data(), b.size()*sizeof(uint64_t));
@@ -202,25 +215,47 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 		if (!T.cpBlocks.empty()) { c->dCpBlocks.upload( T.cpBlocks.data(), T.cpBlocks.size()*2); c->dCpPages.upload( T.cpPages.data(), T.cpPages.size()); }
 		if (!T.nullable.empty()) c->dNullable.upload( T.nullable.data(), T.nullable.size()*sizeof(DevNullable));
 		if (!T.approx.empty()) c->dApprox.upload( T.approx.data(), T.approx.size()*sizeof(DevApproxPattern));
+		c->dShapes.upload( T.shapes.data(), T.shapes.size()*sizeof(DevShape));
+		c->dShapePats.upload( T.shapePats.data(), T.shapePats.size()*4);
+		// literals and word shapes by the words kernel: plain tables (words by ASCII word characters, no classes by code point, no empty matches)
+		c->wordsKernel = T.approx.empty() && !T.ucp && T.cpBlocks.empty() && T.nullable.empty() && !getenv( "SPA_L1_NO_WORDS_KERNEL");
+		if (!c->wordsKernel && T.nofShapes) throw std::runtime_error( "internal: word shapes in a table the words kernel does not take");
 		{
-			// LDS image of the hot tables when it fits (one copy per workgroup; bigger workgroups when the copy is big)
+			// image of all passes: what the kernels that walk an automaton backwards read (global memory)
 			std::vector<uint64_t> img;
 			img.insert( img.end(), T.charMask.begin(), T.charMask.end());
-			c->ldsAccept = (uint32_t)img.size(); img.insert( img.end(), T.acceptMask.begin(), T.acceptMask.end());
-			c->ldsStart = (uint32_t)img.size(); img.insert( img.end(), T.startMask.begin(), T.startMask.end());
-			c->ldsShift = (uint32_t)img.size(); img.insert( img.end(), T.shiftDst.begin(), T.shiftDst.end());
-			c->ldsSelf = (uint32_t)img.size(); img.insert( img.end(), T.selfLoop.begin(), T.selfLoop.end());
-			c->ldsExSrc = (uint32_t)img.size(); img.insert( img.end(), T.exSrc.begin(), T.exSrc.end());
-			c->ldsExDst = (uint32_t)img.size(); img.insert( img.end(), T.exDst.begin(), T.exDst.end());
+			c->imgAccept = (uint32_t)img.size(); img.insert( img.end(), T.acceptMask.begin(), T.acceptMask.end());
+			c->imgStart = (uint32_t)img.size(); img.insert( img.end(), T.startMask.begin(), T.startMask.end());
+			c->imgShift = (uint32_t)img.size(); img.insert( img.end(), T.shiftDst.begin(), T.shiftDst.end());
+			c->imgSelf = (uint32_t)img.size(); img.insert( img.end(), T.selfLoop.begin(), T.selfLoop.end());
+			c->imgExSrc = (uint32_t)img.size(); img.insert( img.end(), T.exSrc.begin(), T.exSrc.end());
+			c->imgExDst = (uint32_t)img.size(); img.insert( img.end(), T.exDst.begin(), T.exDst.end());
+			c->dTableImage.upload( img.data(), img.size()*8);
+			c->imgWords = (uint32_t)img.size();
+		}
+		{
+			// LDS image of the scan kernel: the passes it runs (the word shapes' passes behind them are never scanned), when it fits
+			// (one copy per workgroup; bigger workgroups when the copy is big)
+			const uint32_t sp = c->wordsKernel ? T.scanPasses : T.nofPasses;
+			const size_t maxEx = T.maxExceptions ? T.maxExceptions : 1;
+			std::vector<uint64_t> img;
+			img.insert( img.end(), T.charMask.begin(), T.charMask.begin() + (size_t)sp*T.nofClasses*64);
+			c->ldsAccept = (uint32_t)img.size(); img.insert( img.end(), T.acceptMask.begin(), T.acceptMask.begin() + (size_t)sp*CTX_COUNT*64);
+			c->ldsStart = (uint32_t)img.size(); img.insert( img.end(), T.startMask.begin(), T.startMask.begin() + (size_t)sp*CTX_COUNT*64);
+			c->ldsShift = (uint32_t)img.size(); img.insert( img.end(), T.shiftDst.begin(), T.shiftDst.begin() + (size_t)sp*64);
+			c->ldsSelf = (uint32_t)img.size(); img.insert( img.end(), T.selfLoop.begin(), T.selfLoop.begin() + (size_t)sp*64);
+			c->ldsExSrc = (uint32_t)img.size(); img.insert( img.end(), T.exSrc.begin(), T.exSrc.begin() + (size_t)sp*maxEx*64);
+			c->ldsExDst = (uint32_t)img.size(); img.insert( img.end(), T.exDst.begin(), T.exDst.begin() + (size_t)sp*maxEx*64);
+			if (img.empty()) img.push_back( 0);
 			size_t bytes = img.size()*8;
-			c->dTableImage.upload( img.data(), bytes);
-			if (bytes <= 144*1024 && T.nofPasses <= 8)
+			c->dScanImage.upload( img.data(), bytes);
+			if (bytes <= 144*1024 && sp <= 8)
 			{
 				c->ldsWords = (uint32_t)img.size();
 				// as many workgroups per CU as copies of the image fit into the 160 KB of LDS, sharing the waves
 				// the register budget allows (5 per SIMD up to 2 passes, 4 beyond; two 10-wave workgroups of the
 				// 3-pass instance at 96 registers were measured not to share a CU)
-				const unsigned maxWaves = T.nofPasses <= 2 ? 20u : 16u;
+				const unsigned maxWaves = sp <= 2 ? 20u : 16u;
 				unsigned maxCopies = (unsigned)((160*1024 - 1024) / (bytes ? bytes : 1));
 				if (maxCopies < 1) maxCopies = 1;
 				if (maxCopies > 5) maxCopies = 5;
@@ -243,6 +278,7 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 		c->queueCap = 4096 > 2*npat+256 ? 4096 : 2*npat+256;
 		HIP_CHECK( hipEventCreate( &c->evStart));
 		HIP_CHECK( hipEventCreate( &c->evMid));
+		HIP_CHECK( hipEventCreate( &c->evWords));
 		HIP_CHECK( hipEventCreate( &c->evStop));
 		return c;
 	}
@@ -259,6 +295,7 @@ void sp_lexer_ctx_free( sp_lexer_ctx_t* c)
 	if (!c) return;
 	if (c->evStart) (void)hipEventDestroy( c->evStart);
 	if (c->evMid) (void)hipEventDestroy( c->evMid);
+	if (c->evWords) (void)hipEventDestroy( c->evWords);
 	if (c->evStop) (void)hipEventDestroy( c->evStop);
 	delete c;
 }
@@ -326,6 +363,11 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	c->dUnitStart.reserve( (ndocs+2)*sizeof(uint32_t));
 	c->dDocSequential.reserve( (ndocs+1)*sizeof(uint32_t));
 	c->dQueue.reserve( ((((uint64_t)nbytes * c->queueMul) >> 4) + 64ull*(maxUnits+2)) * 16);
+	if (c->wordsKernel)
+	{
+		c->dWordQueue.reserve( ((((uint64_t)nbytes * c->queueMul) >> 4) + 64ull*(maxUnits+2)) * 16);
+		c->dWordCount.reserve( (maxUnits+1)*sizeof(uint32_t));
+	}
 	if (!T.approx.empty())
 	{
 		// approximate literal table: the decoded characters of every document (code point, byte offset)
@@ -361,11 +403,28 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.nullable = T.nullable.empty() ? 0 : (const DevNullable*)c->dNullable.ptr; P.nofNullable = (uint32_t)T.nullable.size();
 	P.unitStart = (uint32_t*)c->dUnitStart.ptr; P.chunkBytes = chunkBytes; P.docSequential = (uint32_t*)c->dDocSequential.ptr; P.sequentialPass = 0;
 	P.splitPatterns = (T.patterns.size() != c->inst->compiler.nofDefinitions()) ? 1u : 0u;
+	P.shapes = (const DevShape*)c->dShapes.ptr; P.shapePats = (const uint32_t*)c->dShapePats.ptr; P.shapeMask = (uint32_t)T.shapes.size()-1;
+	P.nofShapeVariants = (uint32_t)T.shapeVariants.size();
+	for (size_t i=0; i<T.shapeVariants.size() && i<SHAPE_MAXVARIANTS; ++i) P.shapeVariants[ i] = T.shapeVariants[ i];
+	P.wordQueue = (uint32_t*)c->dWordQueue.ptr; P.wordCount = (uint32_t*)c->dWordCount.ptr; P.wordsKernel = c->wordsKernel ? 1u : 0u;
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
-	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = c->ldsWords;
-	P.ldsAccept = c->ldsAccept; P.ldsStart = c->ldsStart; P.ldsShift = c->ldsShift; P.ldsSelf = c->ldsSelf;
-	P.ldsExSrc = c->ldsExSrc; P.ldsExDst = c->ldsExDst;
-	HIP_CHECK( launchL1Lex( P, nblocks, c->blockThreads, nwaves, stream, c->evMid));
+	// the kernels that walk an automaton backwards read the image of all passes from global memory ...
+	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = 0;
+	P.ldsAccept = c->imgAccept; P.ldsStart = c->imgStart; P.ldsShift = c->imgShift; P.ldsSelf = c->imgSelf;
+	P.ldsExSrc = c->imgExSrc; P.ldsExDst = c->imgExDst;
+	// ... the scan kernel stages the image of the passes it runs in LDS
+	L1Params PS = P;
+	PS.nofPasses = c->wordsKernel ? T.scanPasses : T.nofPasses;
+	PS.tableImage = (const uint64_t*)c->dScanImage.ptr; PS.ldsWords = c->ldsWords;
+	PS.ldsAccept = c->ldsAccept; PS.ldsStart = c->ldsStart; PS.ldsShift = c->ldsShift; PS.ldsSelf = c->ldsSelf;
+	PS.ldsExSrc = c->ldsExSrc; PS.ldsExDst = c->ldsExDst;
+	if (PS.nofPasses == 0) HIP_CHECK( hipMemsetAsync( c->dReportCount.ptr, 0, (maxUnits+1)*sizeof(uint32_t), stream));
+	// words kernel: a wave per unit, workgroups of 16 waves that share one LDS copy of the image of all passes when it fits
+	L1Params PW = P;
+	PW.ldsWords = ((size_t)c->imgWords*8 <= 140*1024 && T.nofShapes) ? c->imgWords : 0u;
+	unsigned wordBlocks = (unsigned)((maxUnits + 15) / 16 < (uint64_t)c->numCUs ? (maxUnits + 15) / 16 : (uint64_t)c->numCUs);
+	if (wordBlocks == 0) wordBlocks = 1;
+	HIP_CHECK( launchL1Lex( PS, PW, P, nblocks, c->blockThreads, wordBlocks, nwaves, stream, c->evMid, c->evWords));
 	HIP_CHECK( hipEventRecord( c->evStop, stream));
 	c->evValid = true; c->lastStream = stream; c->lastNdocs = ndocs;
 }
@@ -430,6 +489,20 @@ int sp_lexer_ctx_last_kernel_ms_split( sp_lexer_ctx_t* c, double* scan_ms, doubl
 	if (hipEventElapsedTime( &a, c->evStart, c->evMid) != hipSuccess) return SP_ERR_INVALID;
 	if (hipEventElapsedTime( &b, c->evMid, c->evStop) != hipSuccess) return SP_ERR_INVALID;
 	*scan_ms = (double)a; *post_ms = (double)b;
+	return SP_OK;
+}
+
+// the same with the words kernel on its own (round 3: automaton scan | literals + word shapes | start of match + handler + ordinal positions)
+int sp_lexer_ctx_last_kernel_ms_split3( sp_lexer_ctx_t* c, double* scan_ms, double* words_ms, double* post_ms)
+{
+	*scan_ms = -1.0; *words_ms = -1.0; *post_ms = -1.0;
+	if (!c->evValid) return SP_ERR_INVALID;
+	float a = 0.0f, b = 0.0f, d = 0.0f;
+	if (hipEventSynchronize( c->evStop) != hipSuccess) return SP_ERR_INVALID;
+	if (hipEventElapsedTime( &a, c->evStart, c->evMid) != hipSuccess) return SP_ERR_INVALID;
+	if (hipEventElapsedTime( &b, c->evMid, c->evWords) != hipSuccess) return SP_ERR_INVALID;
+	if (hipEventElapsedTime( &d, c->evWords, c->evStop) != hipSuccess) return SP_ERR_INVALID;
+	*scan_ms = (double)a; *words_ms = (double)b; *post_ms = (double)d;
 	return SP_OK;
 }
 

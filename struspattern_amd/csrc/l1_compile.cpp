@@ -687,6 +687,112 @@ bool wholeWordLiterals( const Tree& t, std::vector<std::string>& words)
 	return true;
 }
 
+// ---- word shapes (l1_tables.h)
+struct ShapeKey { uint32_t tag, key; };
+static const Tree& ungroup( const Tree& t) { const Tree* p = &t; while (p->op == T_GROUP && p->kids.size() == 1) p = &p->kids[ 0]; return *p; }
+static bool singleWordByte( const Tree& t0, unsigned& b)
+{
+	const Tree& t = ungroup( t0);
+	if (t.op != T_SET || t.set.cpRef >= 0) return false;
+	int only = -1, n = 0;
+	for (unsigned c=0; c<256; ++c) if (t.set.has( c)) { only = (int)c; ++n; }
+	if (n != 1 || !isWordChar( (unsigned)only)) return false;
+	b = (unsigned)only;
+	return true;
+}
+static bool isSetOf( const Tree& t0, bool word)		// one byte position, every member a word character (word) / none of them one (!word)
+{
+	const Tree& t = ungroup( t0);
+	if (t.op != T_SET || t.set.cpRef >= 0 || t.set.empty()) return false;
+	for (unsigned c=0; c<256; ++c) if (t.set.has( c) && isWordChar( c) != word) return false;
+	return true;
+}
+static bool wordAlphabetOnly( const Tree& t)		// no assertion inside, every byte position takes word characters only
+{
+	if (t.op == T_SET) return isSetOf( t, true);
+	if (t.op == T_ASSERT) return false;
+	for (size_t i=0; i<t.kids.size(); ++i) if (!wordAlphabetOnly( t.kids[ i])) return false;
+	return true;
+}
+static unsigned minLength( const Tree& t)
+{
+	switch (t.op)
+	{
+		case T_SET: return 1;
+		case T_CAT: { unsigned n = 0; for (size_t i=0; i<t.kids.size(); ++i) n += minLength( t.kids[ i]); return n; }
+		case T_ALT: { unsigned n = ~0u; for (size_t i=0; i<t.kids.size(); ++i) { unsigned k = minLength( t.kids[ i]); if (k < n) n = k; } return t.kids.empty() ? 0 : n; }
+		case T_PLUS: case T_GROUP: return t.kids.empty() ? 0 : minLength( t.kids[ 0]);
+		default: return 0;
+	}
+}
+static bool isWordBoundary( const Tree& t) { return t.op == T_ASSERT && t.assertion == A_WB; }
+static uint32_t polyHashOf( const std::string& w)
+{
+	uint32_t h = 0;
+	for (size_t i=0; i<w.size(); ++i) h = h * (uint32_t)L1_LITHASH_MUL + (uint32_t)(unsigned char)w[ i] + 1u;
+	return literalHashFinish( h);
+}
+// Is the expression a word shape?  Completeness of the candidates the lexer derives from the key (every match is among them):
+//  SUFFIX   X b1..bk \b, the b word characters: the match's last byte is a word character and \b holds behind it, so the match
+//           ends where a run of word characters ends, and the run's last k bytes are b1..bk (they are adjacent word characters).
+//  PREFIX   \b S1..So b1..bk E \b with every byte position of S, b, E taking word characters only and no assertion inside: the
+//           match consists of word characters, starts where a run starts (\b before a word character) and ends where it ends:
+//           it IS the run, whose bytes [o, o+k) are b1..bk.
+//  PREVWORD \b b1..bn SEP E \b, SEP one position without word characters, E as above and not empty: b1..bn is a whole run
+//           (\b before it, SEP behind it), E the whole next run, one byte apart; the match ends where that run ends.
+static bool wordShapeOf( const Tree& t, ShapeKey& out)
+{
+	if (t.op != T_CAT || t.kids.size() < 3) return false;
+	const size_t n = t.kids.size();
+	if (!isWordBoundary( t.kids[ n-1])) return false;
+	{
+		size_t k = 0; unsigned b;
+		while (k < n-1 && singleWordByte( t.kids[ n-2-k], b)) ++k;
+		if (k >= 2 && k < n-1)
+		{
+			const size_t kk = k > 4 ? 4 : k;
+			uint32_t key = 0;
+			for (size_t i=0; i<kk; ++i) { singleWordByte( t.kids[ n-1-kk+i], b); key |= (uint32_t)b << (8*i); }
+			out.tag = (uint32_t)SHAPE_SUFFIX | ((uint32_t)kk << 4); out.key = key;
+			return true;
+		}
+	}
+	if (!isWordBoundary( t.kids[ 0])) return false;
+	bool allWord = true;
+	for (size_t i=1; i+1<n && allWord; ++i) allWord = wordAlphabetOnly( t.kids[ i]);
+	if (allWord)
+	{
+		for (size_t o=0; o<=3 && 1+o+2 <= n-1; ++o)
+		{
+			if (o && !isSetOf( t.kids[ o], true)) break;		// S1..So: single positions
+			size_t k = 0; unsigned b;
+			while (1+o+k < n-1 && singleWordByte( t.kids[ 1+o+k], b)) ++k;
+			if (k >= 2)
+			{
+				const size_t kk = k > 4 ? 4 : k;
+				uint32_t key = 0;
+				for (size_t i=0; i<kk; ++i) { singleWordByte( t.kids[ 1+o+i], b); key |= (uint32_t)b << (8*i); }
+				out.tag = (uint32_t)SHAPE_PREFIX | ((uint32_t)o << 2) | ((uint32_t)kk << 4); out.key = key;
+				return true;
+			}
+		}
+		return false;
+	}
+	{
+		std::string word; unsigned b;
+		size_t i = 1;
+		while (i+1 < n && singleWordByte( t.kids[ i], b)) { word.push_back( (char)b); ++i; }
+		if (word.empty() || word.size() > 64 || i+1 >= n || !isSetOf( t.kids[ i], false)) return false;
+		++i;
+		if (i+1 > n-1) return false;
+		unsigned restMin = 0;
+		for (size_t r=i; r+1<n; ++r) { if (!wordAlphabetOnly( t.kids[ r])) return false; restMin += minLength( t.kids[ r]); }
+		if (restMin < 1) return false;
+		out.tag = (uint32_t)SHAPE_PREVWORD | ((uint32_t)word.size() << 8); out.key = polyHashOf( word);
+		return true;
+	}
+}
+
 int ctxOfByte( unsigned c) { return c == '\n' ? CTX_NEWLINE : isWordChar( c) ? CTX_WORD : CTX_OTHER; }
 bool ctxIsWord( int ctx) { return ctx == CTX_WORD; }
 // does the conjunction `cond` hold between a byte of context `prev` and one of context `next`?
@@ -964,6 +1070,7 @@ void LexCompiler::compile()
 	std::vector<CpRanges> cpSets;			// code point sets of the leaves with ByteSet::cpRef
 	std::vector<Automaton> autos;
 	std::map<std::string,std::vector<uint32_t> > literalWords;
+	std::vector<std::pair<uint32_t,ShapeKey> > shapeOf;		// (patterns[] entry, key) of the expressions that are word shapes
 	T.patterns.clear();
 	for (size_t di=0; di<m_defs.size(); ++di)
 	{
@@ -1049,7 +1156,35 @@ void LexCompiler::compile()
 			DevNullable nl; nl.pattern = (uint32_t)T.patterns.size(); nl.emptyOk = parts[ 0].emptyOk; nl._pad[0] = 0; nl._pad[1] = 0;
 			T.nullable.push_back( nl);
 		}
+		{
+			ShapeKey sk;
+			if (parts.size() == 1 && !parts[ 0].emptyOk && wordShapeOf( tree, sk)) shapeOf.push_back( std::make_pair( (uint32_t)T.patterns.size(), sk));
+		}
 		for (size_t k=0; k<parts.size(); ++k) { T.patterns.push_back( dp); autos.push_back( parts[ k]); }
+	}
+	// word shapes are taken when the table is a plain one: words by ASCII word characters (no UCP), no classes by code point, the
+	// default layout (SPA_L1_SHAPES=0 keeps every expression in the scanned passes: tests)
+	std::vector<char> isShape( autos.size(), 0);
+	{
+		const char* sw = getenv( "SPA_L1_SHAPES");
+		const bool off = (sw && sw[ 0] == '0') || getenv( "SPA_L1_SHARE") || ucp || !cpSets.empty() || approxTable || (m_options & LEX_ALLOWEMPTY);
+		if (off) shapeOf.clear();
+		// the lexer probes one key per variant (kind, place, length) at every end of a word: the most populated ones are kept
+		std::map<uint32_t,size_t> population;
+		auto variantOf = []( const ShapeKey& k) -> uint32_t { return (k.tag & 3u) == (uint32_t)SHAPE_PREVWORD ? (uint32_t)SHAPE_PREVWORD : k.tag; };
+		for (size_t i=0; i<shapeOf.size(); ++i) population[ variantOf( shapeOf[ i].second)] += 1;
+		if (population.size() > SHAPE_MAXVARIANTS)
+		{
+			std::vector<std::pair<size_t,uint32_t> > byPop;
+			for (std::map<uint32_t,size_t>::const_iterator pi=population.begin(); pi!=population.end(); ++pi) byPop.push_back( std::make_pair( pi->second, pi->first));
+			std::sort( byPop.begin(), byPop.end());
+			std::set<uint32_t> dropped;
+			for (size_t i=0; i+SHAPE_MAXVARIANTS<byPop.size(); ++i) dropped.insert( byPop[ i].second);
+			std::vector<std::pair<uint32_t,ShapeKey> > kept;
+			for (size_t i=0; i<shapeOf.size(); ++i) if (!dropped.count( variantOf( shapeOf[ i].second))) kept.push_back( shapeOf[ i]);
+			shapeOf.swap( kept);
+		}
+		for (size_t i=0; i<shapeOf.size(); ++i) isShape[ shapeOf[ i].first] = 1;
 	}
 	if (T.patterns.size() >= (1u << 24)) throw std::runtime_error( "too many patterns");
 
@@ -1067,7 +1202,7 @@ void LexCompiler::compile()
 		for (size_t pi=0; pi<autos.size(); ++pi)
 		{
 			uint32_t n = (uint32_t)autos[ pi].pos.size();
-			if (T.patterns[ pi].word == L1_WORD_LITERAL) continue;
+			if (T.patterns[ pi].word == L1_WORD_LITERAL || isShape[ pi]) continue;
 			T.nofPositions += n;
 			if (used + n > 64) { ++word; used = 0; }
 			bitBase[ pi] = used; wordOf[ pi] = word; used += n; any = true;
@@ -1082,7 +1217,7 @@ void LexCompiler::compile()
 		if (passesInOrder > passesMin && passesInOrder > 1)
 		{
 			std::vector<size_t> bySize;
-			for (size_t pi=0; pi<autos.size(); ++pi) if (T.patterns[ pi].word != L1_WORD_LITERAL) bySize.push_back( pi);
+			for (size_t pi=0; pi<autos.size(); ++pi) if (T.patterns[ pi].word != L1_WORD_LITERAL && !isShape[ pi]) bySize.push_back( pi);
 			std::stable_sort( bySize.begin(), bySize.end(), [&]( size_t a, size_t b) { return autos[ a].pos.size() > autos[ b].pos.size(); });
 			std::vector<uint32_t> fill;
 			std::vector<uint32_t> base2( autos.size(), 0), word2( autos.size(), 0);
@@ -1104,6 +1239,22 @@ void LexCompiler::compile()
 				T.reportsOrdered = false;
 			}
 		}
+	}
+	// the passes the scan kernel runs end here; the word shapes follow in passes of their own (in definition order)
+	T.scanPasses = (word + L1_WORDS_PER_PASS-1) / L1_WORDS_PER_PASS;
+	T.nofShapes = (uint32_t)shapeOf.size();
+	if (!shapeOf.empty())
+	{
+		uint32_t w2 = T.scanPasses * L1_WORDS_PER_PASS, used = 0;
+		for (size_t pi=0; pi<autos.size(); ++pi)
+		{
+			if (!isShape[ pi]) continue;
+			const uint32_t n = (uint32_t)autos[ pi].pos.size();
+			T.nofPositions += n;
+			if (used + n > 64) { ++w2; used = 0; }
+			bitBase[ pi] = used; wordOf[ pi] = w2; used += n;
+		}
+		word = w2 + 1;
 	}
 	// bit of every position of every pattern inside its word (contiguous in the two layouts above)
 	std::vector<std::vector<uint8_t> > bitOf( autos.size());
@@ -1471,6 +1622,32 @@ void LexCompiler::compile()
 		if (T.litPats.empty()) T.litPats.push_back( 0);
 	}
 
+	// 4c. word shapes: hash table keyed by (kind, place, literal bytes) -> expressions, ascending
+	{
+		std::map<std::pair<uint32_t,uint32_t>,std::vector<uint32_t> > byKey;
+		for (size_t i=0; i<shapeOf.size(); ++i) byKey[ std::make_pair( shapeOf[ i].second.tag, shapeOf[ i].second.key)].push_back( shapeOf[ i].first);
+		size_t size = 1;
+		while (size < byKey.size()*2+1) size <<= 1;
+		DevShape none; std::memset( &none, 0, sizeof(none));
+		T.shapes.assign( size, none);
+		T.shapePats.clear(); T.shapeVariants.clear();
+		std::set<uint32_t> variants;
+		for (std::map<std::pair<uint32_t,uint32_t>,std::vector<uint32_t> >::iterator ki=byKey.begin(); ki!=byKey.end(); ++ki)
+		{
+			std::sort( ki->second.begin(), ki->second.end());
+			DevShape e; e.tag = ki->first.first; e.key = ki->first.second;
+			e.patBegin = (uint32_t)T.shapePats.size(); e.patCount = (uint32_t)ki->second.size();
+			T.shapePats.insert( T.shapePats.end(), ki->second.begin(), ki->second.end());
+			size_t slot = shapeSlotHash( e.tag, e.key) & (size-1);
+			while (T.shapes[ slot].tag) slot = (slot+1) & (size-1);
+			T.shapes[ slot] = e;
+			variants.insert( (e.tag & 3u) == (uint32_t)SHAPE_PREVWORD ? (uint32_t)SHAPE_PREVWORD : e.tag);
+		}
+		T.shapeVariants.assign( variants.begin(), variants.end());
+		if (T.shapeVariants.size() > SHAPE_MAXVARIANTS) throw std::runtime_error( "internal: too many word shape variants");
+		if (T.shapePats.empty()) T.shapePats.push_back( 0);
+	}
+
 	// 5. symbols: one hash table keyed by (lexem id, text)
 	{
 		size_t count = 0;
@@ -1502,7 +1679,7 @@ void LexCompiler::compile()
 }
 
 // ---------------------------------------------------------------- compiled tables as a blob
-static const char L1_MAGIC[ 9] = "SPAL1v07";
+static const char L1_MAGIC[ 9] = "SPAL1v08";
 
 void LexCompiler::save( std::vector<uint8_t>& out) const
 {
@@ -1514,6 +1691,7 @@ void LexCompiler::save( std::vector<uint8_t>& out) const
 	w.vec( T.byteClass); w.vec( T.classCtx); w.vec( T.cpBlocks); w.vec( T.cpPages); w.vec( T.charMask); w.vec( T.startMask); w.vec( T.acceptMask); w.vec( T.shiftDst); w.vec( T.selfLoop);
 	w.vec( T.exCount); w.vec( T.exSrc); w.vec( T.exDst); w.vec( T.wordPatBegin); w.vec( T.wordPats); w.vec( T.patOfBit);
 	w.vec( T.patterns); w.vec( T.symbols); w.vec( T.symbolText); w.vec( T.literals); w.vec( T.literalText); w.vec( T.litPats); w.vec( T.approx); w.vec( T.nullable);
+	w.u32( T.scanPasses); w.u32( T.nofShapes); w.vec( T.shapes); w.vec( T.shapePats); w.vec( T.shapeVariants);
 	w.u32( (uint32_t)m_defs.size());
 	for (size_t i=0; i<m_defs.size(); ++i)
 	{
@@ -1540,6 +1718,13 @@ void LexCompiler::load( const void* blob, size_t size)
 	r.vec( T.byteClass); r.vec( T.classCtx); r.vec( T.cpBlocks); r.vec( T.cpPages); r.vec( T.charMask); r.vec( T.startMask); r.vec( T.acceptMask); r.vec( T.shiftDst); r.vec( T.selfLoop);
 	r.vec( T.exCount); r.vec( T.exSrc); r.vec( T.exDst); r.vec( T.wordPatBegin); r.vec( T.wordPats); r.vec( T.patOfBit);
 	r.vec( T.patterns); r.vec( T.symbols); r.vec( T.symbolText); r.vec( T.literals); r.vec( T.literalText); r.vec( T.litPats); r.vec( T.approx); r.vec( T.nullable);
+	T.scanPasses = r.u32(); T.nofShapes = r.u32(); r.vec( T.shapes); r.vec( T.shapePats); r.vec( T.shapeVariants);
+	if (T.scanPasses > T.nofPasses || T.shapes.empty() || (T.shapes.size() & (T.shapes.size()-1)) || T.shapeVariants.size() > SHAPE_MAXVARIANTS || T.shapePats.empty())
+	{
+		throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	}
+	for (size_t i=0; i<T.shapes.size(); ++i) if (T.shapes[ i].tag && (uint64_t)T.shapes[ i].patBegin + T.shapes[ i].patCount > T.shapePats.size()) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
+	for (size_t i=0; i<T.shapePats.size(); ++i) if (T.shapePats[ i] >= T.patterns.size() && !T.patterns.empty()) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
 	// the shapes the kernel indexes by must fit together (a blob of another build would fault on the device)
 	if (T.byteClass.size() != (T.ucp ? 320u : 256u) || (T.ucp && T.cpBlocks.empty()) || T.classCtx.size() != T.nofClasses
 	||  T.charMask.size() != (size_t)T.nofPasses*T.nofClasses*64 || T.startMask.size() != (size_t)T.nofPasses*CTX_COUNT*64 || T.acceptMask.size() != T.startMask.size()

@@ -45,6 +45,12 @@ struct LexTables
 	std::vector<uint32_t> litPats;
 	std::vector<DevNullable> nullable;	// ALLOWEMPTY: the expressions that match the empty string (at most 64)
 	std::vector<DevApproxPattern> approx;	// non-empty: approximate literal table, the automaton tables are empty
+	// word shapes (l1_tables.h): expressions found at the ends of word runs instead of by an automaton pass
+	std::vector<DevShape> shapes;		// power-of-two size (>=1)
+	std::vector<uint32_t> shapePats;
+	std::vector<uint32_t> shapeVariants;	// the distinct tags (kind | offset << 2 | length << 4; PREVWORD: kind) the table holds
+	uint32_t nofShapes;			// expressions taken as shapes
+	uint32_t scanPasses;			// passes [0, scanPasses) are run by the scan kernel; the rest is only walked backwards
 	uint32_t nofLiterals;
 	uint32_t nofPositions;
 	bool reportsOrdered;			// patterns sit in the words in definition order (else the kernel sorts the reports of one end offset)

@@ -7,7 +7,8 @@
 namespace spa {
 
 enum {L1C_LEXEMS=0, L1C_BYTES=1, L1C_RAW=2, L1C_FAILED=3, L1C_COUNT=8, L1C_CURSOR=8 /*document cursor of the scan kernel, behind the counters*/, L1C_CURSOR2=9 /*of the post-processing kernel*/,
-      L1C_CURSOR3=10 /*of the sequential re-scan*/, L1C_UNITS=11 /*scan units = chunks of all documents*/, L1C_CHUNKED=12 /*some document has more than one chunk*/, L1C_SEQDOCS=13 /*documents scanned again in one piece*/, L1C_ALLOC=14};
+      L1C_CURSOR3=10 /*of the sequential re-scan*/, L1C_UNITS=11 /*scan units = chunks of all documents*/, L1C_CHUNKED=12 /*some document has more than one chunk*/, L1C_SEQDOCS=13 /*documents scanned again in one piece*/,
+      L1C_CURSOR4=14 /*unit cursor of the words kernel*/, L1C_WORDREPORTS=15 /*records the words kernel wrote*/, L1C_ALLOC=16};
 
 struct L1Params
 {
@@ -80,6 +81,15 @@ struct L1Params
 	uint32_t nofNullable;
 	uint32_t ucp;			// option UCP: contexts by Unicode word characters, byteClass has the 64 twin entries [256..319]
 	uint32_t splitPatterns;		// some expression is cut into several patterns entries (same defIndex): their reports are merged
+	// words kernel (round 3): whole-word literals and word shapes (l1_tables.h) are found where runs of word characters end, by a
+	// kernel of its own with a lane per byte; its reports of unit u -- start already known, (end offset, pattern) order, records
+	// of candidates that did not confirm marked L1_DEAD_FLAG -- lie at wordQueue[ 4*queueBase(u) ..), wordCount[u] of them
+	const DevShape* shapes; const uint32_t* shapePats;
+	uint32_t shapeMask, nofShapeVariants;
+	uint32_t shapeVariants[ SHAPE_MAXVARIANTS];
+	uint32_t* wordQueue;
+	uint32_t* wordCount;
+	uint32_t wordsKernel;		// 1: the post-processing kernel merges the two queues (plain tables); 0: it finds the literals itself
 };
 
 } // namespace

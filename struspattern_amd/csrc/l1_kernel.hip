@@ -208,6 +208,36 @@ __device__ __forceinline__ u32 tileClassCtx( const L1Params& P, const unsigned c
 // lane-parallel: lane i resolves report base+i
 struct LaneReport { u32 to, from, id, levelBind, prefixLen, suffixLen, pi, def, skip; };	// one queued report per lane, pattern attributes attached
 
+// the leftmost start of the matches of one pattern (p0 = {id, word, levelBind, prefixLen}, mask = its bits) that end at `to`, R = the
+// positions that consumed byte to-1 and accept there; `to` itself when there is none (a candidate that does not confirm)
+template <bool LDS, bool CP>
+__device__ __forceinline__ u32 leftmostStart( const unsigned char* doc, u32 docLen, const L1Params& P, const LexTab<LDS>& T, u32 word, u64 mask, u32 to, u64 R)
+{
+	const u32 pass = word >> 6, ln = word & 63u;
+	const u64 shiftDst = T.at( T.oShift + pass*64 + ln), selfLoop = T.at( T.oSelf + pass*64 + ln);
+	const u32 nEx = P.exCount[ pass];
+	u32 from = to;
+	long j = (long)to;			// R = positions that consumed byte j-1
+	while (R && j > 0)
+	{
+		int prevctx = ctxAt<CP>( P, doc, docLen, j-2);
+		if (R & T.at( T.oStart + (pass*CTX_COUNT + prevctx)*64 + ln)) from = (u32)(j-1);
+		if (j-1 == 0) break;
+		u64 Rp = ((R & shiftDst) >> 1) | (R & selfLoop);
+		for (u32 e=0; e<nEx; ++e)
+		{
+			const u32 at = (pass*P.maxExceptions + e)*64 + ln;
+			const u64 es = T.at( T.oExSrc + at), ed = T.at( T.oExDst + at);
+			Rp |= (R & ed) ? es : 0ull;
+		}
+		u32 cls = P.byteClass[ doc[ j-2]];
+		if (CP && P.cpBlocks && doc[ j-2] >= 0x80u) { int cx; classCtxAt( P, doc, docLen, j-2, cls, cx); }
+		R = Rp & mask & T.at( (pass*P.nofClasses + cls)*64 + ln);
+		--j;
+	}
+	return from;
+}
+
 template <bool LDS, bool CP>
 __device__ __forceinline__ void resolveStarts( const u32* queue, const unsigned char* doc, u32 docLen, const L1Params& P, const LexTab<LDS>& T, u32 base, u32 count, LaneReport& out)
 {
@@ -216,35 +246,12 @@ __device__ __forceinline__ void resolveStarts( const u32* queue, const unsigned 
 	if (LANE < count)
 	{
 		const uint4 q = *(const uint4*)(queue + 4*(u64)i);	// {to, pattern, accLo|from, accHi}
-		u32 to = q.x, pi = q.y & ~L1_LITERAL_FLAG;
+		u32 to = q.x, pi = q.y & ~(u32)(L1_LITERAL_FLAG | L1_DEAD_FLAG);
 		const uint4 p0 = *(const uint4*)&P.patterns[ pi], p1 = *((const uint4*)&P.patterns[ pi] + 1);	// {id,word,levelBind,prefixLen} {suffixLen,maskLo,maskHi,-}
 		out.to = to; out.id = p0.x; out.levelBind = p0.z; out.prefixLen = p0.w; out.suffixLen = p1.x; out.pi = pi; out.def = p1.w;
-		if (q.y & L1_LITERAL_FLAG) { out.from = q.z; return; }		// whole-word literal: start already known
-		u64 R = ((u64)q.w << 32) | q.z;
-		const u32 pass = p0.y >> 6, ln = p0.y & 63u;
-		const u64 mask = ((u64)p1.z << 32) | p1.y;
-		const u64 shiftDst = T.at( T.oShift + pass*64 + ln), selfLoop = T.at( T.oSelf + pass*64 + ln);
-		const u32 nEx = P.exCount[ pass];
-		u32 from = to;
-		long j = (long)to;			// R = positions that consumed byte j-1
-		while (R && j > 0)
-		{
-			int prevctx = ctxAt<CP>( P, doc, docLen, j-2);
-			if (R & T.at( T.oStart + (pass*CTX_COUNT + prevctx)*64 + ln)) from = (u32)(j-1);
-			if (j-1 == 0) break;
-			u64 Rp = ((R & shiftDst) >> 1) | (R & selfLoop);
-			for (u32 e=0; e<nEx; ++e)
-			{
-				const u32 at = (pass*P.maxExceptions + e)*64 + ln;
-				const u64 es = T.at( T.oExSrc + at), ed = T.at( T.oExDst + at);
-				Rp |= (R & ed) ? es : 0ull;
-			}
-			u32 cls = P.byteClass[ doc[ j-2]];
-			if (CP && P.cpBlocks && doc[ j-2] >= 0x80u) { int cx; classCtxAt( P, doc, docLen, j-2, cls, cx); }
-			R = Rp & mask & T.at( (pass*P.nofClasses + cls)*64 + ln);
-			--j;
-		}
-		out.from = from;
+		if (q.y & L1_DEAD_FLAG) out.skip = 1;				// (words kernel: a candidate that did not confirm)
+		if (q.y & L1_LITERAL_FLAG) { out.from = q.z; return; }		// whole-word literal / word shape: start already known
+		out.from = leftmostStart<LDS,CP>( doc, docLen, P, T, p0.y, ((u64)p1.z << 32) | p1.y, to, ((u64)q.w << 32) | q.z);
 	}
 }
 
@@ -964,6 +971,425 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 	if (!w.err && qi != nq) w.err = L1D_ERR_INTERNAL;
 }
 
+__device__ __forceinline__ u64 queueBase( const L1Params& P, u64 bytePos, u32 unit) { return ((bytePos * P.queueMul) >> 4) + 64ull*unit; }
+__device__ __forceinline__ void docBounds( const L1Params& P, u32 doc, u64& beg, u64& end);
+template <bool LDS> __device__ __forceinline__ void stageTables( const L1Params& P, LexTab<LDS>& T);
+// ---------------------------------------------------------------- words kernel: whole-word literals and word shapes
+// A lane per byte, a wave per scan unit (a document, or a chunk of a long one): everything here is parallel over the text.
+// Where a run of word characters ends, the lane behind it knows the run (start, length, polynomial hash -- one ballot and one
+// segmented scan per 64-byte tile, as tileLiterals) and the run before it, and derives the candidates of that end offset:
+// the literal table's entry of the whole word, and per shape variant of the table (l1_tables.h: PREFIX / SUFFIX / PREVWORD) the
+// entry of the few bytes that pin the shape.  A shape candidate is confirmed by the backward walk of its automaton from the end
+// offset (leftmostStart: exactly what an automaton report of that expression would go through), which also gives the leftmost
+// start.  The unit's records go to its slice of the word queue in (end offset, pattern) order; a candidate that does not confirm
+// keeps its record, marked dead (the lanes reserve their records before they walk).
+struct WordCarry
+{
+	bool in; u32 hash, len, start;			// the run that reaches the end of the tile
+	bool lastValid; u32 lastTo, lastHash, lastLen;	// the last run that ended so far: its end offset (= the byte behind it), hash, length
+};
+
+// start of the run of word characters that byte pos-1 belongs to (pos >= 1, byte pos-1 is a word character)
+__device__ __forceinline__ u32 runStartBefore( const L1Params& P, const unsigned char* doc, u32 pos, u32 ctxReg)
+{
+	for (;;)
+	{
+		const u32 base = pos >= 64u ? pos - 64u : 0u;
+		const u32 at = base + LANE;
+		const u32 b = at < pos ? (u32)doc[ at] : 0u;
+		const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((b >> 2) << 2), (int)ctxReg) >> ((b & 3u)*8)) & 0xFFu;
+		const u64 nonWord = __ballot( at < pos && ctxL != (u32)CTX_WORD);
+		if (nonWord) return base + 64u - (u32)__builtin_clzll( nonWord);		// behind the last byte that is none
+		if (base == 0) return 0;
+		pos = base;
+	}
+}
+
+// The backward walk of leftmostStart for a candidate of the words kernel: class and context of the bytes it visits come from the
+// wave's ring in LDS (the last 128 bytes of the text, written a tile at a time), the automaton's rows from the LDS image -- two
+// LDS round trips per byte instead of four dependent global loads.  A walk that leaves the ring goes on with leftmostStart.
+enum {WORD_RING=128, WORD_WAVES=16};
+__shared__ unsigned short wordRing[ WORD_WAVES][ WORD_RING];
+__shared__ uint4 wordStage[ WORD_WAVES][ 64];		// the candidates of a tile {end offset, pattern | L1_LITERAL_FLAG for a literal, start of a literal, -}: a lane each for the walks
+template <bool LDS>
+__device__ __forceinline__ u32 confirmWalk( const unsigned char* doc, u32 docLen, const L1Params& P, const LexTab<LDS>& T, const unsigned short* ring, u32 ringLo,
+					    u32 word, u64 mask, u32 to)
+{
+	// ring[ q & 127] = class | context << 8 of byte q for ringLo <= q < ringLo + 128
+	const u32 pass = word >> 6, ln = word & 63u;
+	const u32 ccLast = ring[ (to-1u) & (WORD_RING-1)];
+	const u32 nextctx = to < docLen ? ((u32)ring[ to & (WORD_RING-1)] >> 8) : (u32)CTX_EDGE;
+	u64 R = mask & T.at( T.oAccept + (pass*CTX_COUNT + nextctx)*64 + ln) & T.at( (pass*P.nofClasses + (ccLast & 0xFFu))*64 + ln);
+	if (!R) return to;
+	const u64 shiftDst = T.at( T.oShift + pass*64 + ln), selfLoop = T.at( T.oSelf + pass*64 + ln);
+	const u32 nEx = P.exCount[ pass];
+	u32 from = to;
+	u32 j = to;				// R = positions that consumed byte j-1
+	while (R && j > 0)
+	{
+		if (j >= 2u && j-2u < ringLo)
+		{
+			// (rare: a match longer than the ring) the rest of the walk from global memory
+			const u32 f = leftmostStart<LDS,false>( doc, docLen, P, T, word, mask, j, R);
+			return f < j ? f : from;
+		}
+		const u32 cc = j >= 2u ? (u32)ring[ (j-2u) & (WORD_RING-1)] : ((u32)CTX_EDGE << 8);
+		if (R & T.at( T.oStart + (pass*CTX_COUNT + (cc >> 8))*64 + ln)) from = j-1u;
+		if (j == 1u) break;
+		u64 Rp = ((R & shiftDst) >> 1) | (R & selfLoop);
+		for (u32 e=0; e<nEx; ++e)
+		{
+			const u32 at = (pass*P.maxExceptions + e)*64 + ln;
+			const u64 es = T.at( T.oExSrc + at), ed = T.at( T.oExDst + at);
+			Rp |= (R & ed) ? es : 0ull;
+		}
+		R = Rp & mask & T.at( (pass*P.nofClasses + (cc & 0xFFu))*64 + ln);
+		--j;
+	}
+	return from;
+}
+
+template <bool LDS>
+__device__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, const u32 segBeg, const u32 segEnd)
+{
+	const u32 len = w.docLen;
+	unsigned short* ring = wordRing[ (threadIdx.x >> 6) & (WORD_WAVES-1)];
+	u32 ctxReg = 0, clsReg = 0;		// byte -> context, class: lane l keeps the entries of bytes 4l..4l+3
+	for (u32 k=0; k<4; ++k) { const u32 cl = P.byteClass[ 4*LANE + k]; clsReg |= cl << (8*k); ctxReg |= (u32)P.classCtx[ cl] << (8*k); }
+	auto isWordAt = [&]( u32 pos) -> bool { return P.classCtx[ P.byteClass[ uni( (u32)w.doc[ pos])]] == (u32)CTX_WORD; };
+	// where to begin: before the unit, at the start of a run (or between runs), so that every run that ends inside the unit is
+	// seen from its first byte -- and one run further back when that one could be the word before a run of the unit
+	u32 w0 = segBeg > 160u ? segBeg - 160u : 0u;
+	if (w0 > 0 && isWordAt( w0-1)) w0 = runStartBefore( P, w.doc, w0, ctxReg);
+	if (w0 >= 2 && isWordAt( w0-2)) w0 = runStartBefore( P, w.doc, w0-1, ctxReg);
+	WordCarry c; c.in = false; c.hash = 0; c.len = 0; c.start = 0; c.lastValid = false; c.lastTo = 0; c.lastHash = 0; c.lastLen = 0;
+	const u32 nVar = uni( P.nofShapeVariants);
+	for (u32 tile=w0; tile<=len && tile<=segEnd && !w.err; tile+=64)
+	{
+		const u32 inTile = (len - tile) < 64 ? (len - tile) : 64;
+		const u32 mine = LANE < inTile ? (u32)w.doc[ tile + LANE] : 0u;
+		const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> ((mine & 3u)*8)) & 0xFFu;
+		const u32 clsL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)clsReg) >> ((mine & 3u)*8)) & 0xFFu;
+		ring[ (tile + LANE) & (WORD_RING-1)] = (unsigned short)(clsL | (ctxL << 8));		// (the ring keeps this tile and the one before it)
+		__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+		const u32 ringLo = tile >= w0 + 64u ? tile - 64u : w0;
+		const bool isW = LANE < inTile && ctxL == (u32)CTX_WORD;
+		// ---- the runs of the tile (as tileLiterals)
+		const u64 wm = __ballot( isW);
+		const u64 prevW = (wm << 1) | (c.in ? 1ull : 0ull);
+		const u64 startM = wm & ~prevW;
+		const u64 endMask = ~wm & prevW;			// bit e: the run that ended just before byte tile+e
+		const u64 sb = startM & (((1ull << LANE) - 1ull) | (1ull << LANE));
+		const int ss = sb ? 63 - (int)__builtin_clzll( sb) : -1;
+		u32 H = isW ? mine + 1u : 0u, M = (u32)L1_LITHASH_MUL;
+#pragma unroll
+		for (int d=1; d<64; d<<=1)
+		{
+			const u32 Hs = (u32)__shfl_up( (int)H, d), Ms = (u32)__shfl_up( (int)M, d);
+			const bool take = isW && (int)LANE >= d && (int)LANE - d >= ss;
+			if (take) { H = Hs * M + H; M = Ms * M; }
+		}
+		const bool carried = isW && ss < 0;
+		const u32 Htot = carried ? c.hash * M + H : H;
+		u32 runLen = isW ? (carried ? c.len + LANE + 1u : LANE - (u32)ss + 1u) : 0u;
+		if (runLen > 65u) runLen = 65u;
+		const u32 from = carried ? c.start : tile + (u32)(ss < 0 ? 0 : ss);
+		u32 pH = (u32)__shfl_up( (int)Htot, 1), pLen = (u32)__shfl_up( (int)runLen, 1), pFrom = (u32)__shfl_up( (int)from, 1);
+		if (LANE == 0) { pH = c.hash; pLen = c.len; pFrom = c.start; }
+		const bool isEnd = (endMask >> LANE) & 1ull;
+		const u32 to = tile + LANE;
+		// ---- the run before mine, when it ended one byte before mine begins (PREVWORD)
+		u32 qH = 0, qLen = 0;
+		{
+			const u32 want = pFrom - 1u;			// its end offset
+			const u32 src = want - tile;			// lane that saw it end, if in this tile
+			const u32 sH = (u32)__builtin_amdgcn_ds_bpermute( (int)((src & 63u) << 2), (int)pH);
+			const u32 sLen = (u32)__builtin_amdgcn_ds_bpermute( (int)((src & 63u) << 2), (int)pLen);
+			if (isEnd && pFrom >= 2u)
+			{
+				if (want >= tile) { if ((endMask >> (src & 63u)) & 1ull) { qH = sH; qLen = sLen; } }
+				else if (c.lastValid && c.lastTo == want) { qH = c.lastHash; qLen = c.lastLen; }
+			}
+		}
+		// ---- candidates of my end offset: lists of patterns, ascending each
+		const bool emit = isEnd && pLen >= 1u && ((to >= segBeg && to < segEnd) || (to == segEnd && segEnd == len));
+		enum {NLIST=SHAPE_MAXVARIANTS+1};
+		u32 lb[ NLIST], lc[ NLIST];
+#pragma unroll
+		for (int k=0; k<NLIST; ++k) { lb[ k] = 0; lc[ k] = 0; }
+		u32 total = 0;
+		if (emit)
+		{
+			if (P.nofLiterals && pLen <= 64u)
+			{
+				// whole-word literal (the probe of tileLiterals)
+				const u32 h = literalHashFinish( pH);
+				u32 slot = h & P.literalMask;
+				uint4 dw = make_uint4( 0, 0, 0, 0);
+				if (pFrom + 16u <= len) dw = ld128u( w.doc + pFrom);
+				else
+				{
+					u32 d[ 4] = {0,0,0,0};
+					for (u32 q=0; q<16u && pFrom+q<len; ++q) d[ q>>2] |= (u32)w.doc[ pFrom + q] << (8*(q&3u));
+					dw = make_uint4( d[0], d[1], d[2], d[3]);
+				}
+				const u32 m0 = pLen >= 4u ? 0xFFFFFFFFu : ((1u << (8*pLen)) - 1u);
+				const u32 m1 = pLen >= 8u ? 0xFFFFFFFFu : (pLen > 4u ? ((1u << (8*(pLen-4u))) - 1u) : 0u);
+				const u32 m2 = pLen >= 12u ? 0xFFFFFFFFu : (pLen > 8u ? ((1u << (8*(pLen-8u))) - 1u) : 0u);
+				const u32 m3 = pLen >= 16u ? 0xFFFFFFFFu : (pLen > 12u ? ((1u << (8*(pLen-12u))) - 1u) : 0u);
+				for (u32 probes=0; probes<=P.literalMask; ++probes)
+				{
+					const uint4* ep = (const uint4*)&P.literals[ slot];
+					const uint4 e0 = ep[ 0], e1 = ep[ 1], tx = ep[ 2];
+					if (!e0.x) break;
+					if (e0.x == h && e0.y == pLen)
+					{
+						bool same = (((dw.x ^ tx.x) & m0) | ((dw.y ^ tx.y) & m1) | ((dw.z ^ tx.z) & m2) | ((dw.w ^ tx.w) & m3)) == 0;
+						for (u32 k=16; k<pLen && same; k+=4)
+						{
+							const u32 rem = pLen - k;
+							u32 a;
+							if (pFrom + k + 4u <= len) a = ld32u( w.doc + pFrom + k);
+							else { a = 0; for (u32 q=0; q<rem && q<4u; ++q) a |= (u32)w.doc[ pFrom + k + q] << (8*q); }
+							const u32 b = ld32u( P.literalText + e1.w + k);
+							const u32 mask = rem >= 4u ? 0xFFFFFFFFu : ((1u << (8*rem)) - 1u);
+							same = ((a ^ b) & mask) == 0;
+						}
+						if (same) { lb[ 0] = e0.z; lc[ 0] = e0.w; break; }
+					}
+					slot = (slot+1) & P.literalMask;
+				}
+			}
+		}
+#pragma unroll
+		for (int v=0; v<SHAPE_MAXVARIANTS; ++v)
+		{
+			if ((u32)v < nVar)
+			{
+				const u32 var = uni( P.shapeVariants[ v]);
+				const u32 kind = var & 3u, o = (var >> 2) & 3u, k = (var >> 4) & 7u;
+				if (emit)
+				{
+					u32 tag = 0, key = 0;
+					if (kind == (u32)SHAPE_PREVWORD) { if (qLen >= 1u && qLen <= 64u) { tag = (u32)SHAPE_PREVWORD | (qLen << 8); key = literalHashFinish( qH); } }
+					else if (kind == (u32)SHAPE_PREFIX) { if (pLen >= o + k) { tag = var; for (u32 i=0; i<k; ++i) key |= (u32)w.doc[ pFrom + o + i] << (8*i); } }
+					else { if (pLen >= k) { tag = var; for (u32 i=0; i<k; ++i) key |= (u32)w.doc[ to - k + i] << (8*i); } }
+					if (tag)
+					{
+						u32 slot = shapeSlotHash( tag, key) & P.shapeMask;
+						for (u32 probes=0; probes<=P.shapeMask; ++probes)
+						{
+							const uint4 e = *(const uint4*)&P.shapes[ slot];		// {tag, key, patBegin, patCount}
+							if (!e.x) break;
+							if (e.x == tag && e.y == key) { lb[ 1+v] = e.z; lc[ 1+v] = e.w; break; }
+							slot = (slot+1) & P.shapeMask;
+						}
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (int k=0; k<NLIST; ++k) total += lc[ k];
+		// ---- every lane reserves its records, then merges its lists by pattern index and confirms the shape candidates
+		const u32 incl = waveScanAdd( total);
+		const u32 waveTotal = (u32)__builtin_amdgcn_readlane( incl, 63);
+		if (waveTotal)
+		{
+			if (w.nQueue + waveTotal > w.queueCap) { w.err = L1D_ERR_ARENA; break; }
+			u32* out = w.queue + 4*(u64)(w.nQueue + incl - total);
+			// Up to 64 candidates in the tile (the rule): the lanes that saw a run end only ORDER their candidates (merge of their
+			// lists by pattern index) into the wave's staging array; then every candidate gets a lane of its own for the walk that
+			// confirms it -- one round of walks per tile instead of one per candidate of the busiest lane.
+			const bool staged = waveTotal <= 64u;
+			uint4* stage = wordStage[ (threadIdx.x >> 6) & (WORD_WAVES-1)];
+			u32 head[ NLIST];
+#pragma unroll
+			for (int k=0; k<NLIST; ++k) head[ k] = lc[ k] ? (k == 0 ? P.litPats[ lb[ 0]] : P.shapePats[ lb[ k]]) : 0xFFFFFFFFu;
+			for (u32 n=0; n<total; ++n)
+			{
+				u32 best = 0xFFFFFFFFu; int which = 0;
+#pragma unroll
+				for (int k=0; k<NLIST; ++k) if (head[ k] < best) { best = head[ k]; which = k; }
+				// advance that list
+#pragma unroll
+				for (int k=0; k<NLIST; ++k)
+				{
+					if (k == which)
+					{
+						++lb[ k]; --lc[ k];
+						head[ k] = lc[ k] ? (k == 0 ? P.litPats[ lb[ 0]] : P.shapePats[ lb[ k]]) : 0xFFFFFFFFu;
+					}
+				}
+				if (staged) { stage[ incl - total + n] = make_uint4( to, which == 0 ? (best | (u32)L1_LITERAL_FLAG) : best, pFrom, 0u); continue; }
+				u32 fromOut = pFrom, flags = (u32)L1_LITERAL_FLAG;
+				if (which != 0)
+				{
+					const uint2 pw = *(const uint2*)((const u32*)&P.patterns[ best] + 5);	// {maskLo, maskHi}
+					const u32 word = ((const u32*)&P.patterns[ best])[ 1];
+					fromOut = confirmWalk<LDS>( w.doc, len, P, T, ring, ringLo, word, ((u64)pw.y << 32) | pw.x, to);
+					if (fromOut == to) flags |= (u32)L1_DEAD_FLAG;
+				}
+				*(uint4*)(out + 4*(u64)n) = make_uint4( to, best | flags, fromOut, 0u);
+			}
+			if (staged)
+			{
+				__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+				if (LANE < waveTotal)
+				{
+					const uint4 cnd = stage[ LANE];
+					u32 fromOut = cnd.z, flags = (u32)L1_LITERAL_FLAG;
+					const u32 pi = cnd.y & ~(u32)L1_LITERAL_FLAG;
+					if (!(cnd.y & (u32)L1_LITERAL_FLAG))
+					{
+						const uint2 pw = *(const uint2*)((const u32*)&P.patterns[ pi] + 5);	// {maskLo, maskHi}
+						const u32 word = ((const u32*)&P.patterns[ pi])[ 1];
+						fromOut = confirmWalk<LDS>( w.doc, len, P, T, ring, ringLo, word, ((u64)pw.y << 32) | pw.x, cnd.x);
+						if (fromOut == cnd.x) flags |= (u32)L1_DEAD_FLAG;
+					}
+					*(uint4*)(w.queue + 4*(u64)(w.nQueue + LANE)) = make_uint4( cnd.x, pi | flags, fromOut, 0u);
+				}
+				__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+			}
+			w.nQueue += waveTotal;
+		}
+		// ---- carry: the run that reaches the end of the tile, the last run that ended
+		c.in = (wm >> 63) & 1ull;
+		if (c.in)
+		{
+			c.hash = uni( (u32)__shfl( (int)Htot, 63)); c.len = uni( (u32)__shfl( (int)runLen, 63)); c.start = uni( (u32)__shfl( (int)from, 63));
+		}
+		if (endMask)
+		{
+			const u32 e = 63u - (u32)__builtin_clzll( endMask);
+			c.lastValid = true; c.lastTo = tile + e;
+			c.lastHash = (u32)__builtin_amdgcn_readlane( pH, e); c.lastLen = (u32)__builtin_amdgcn_readlane( pLen, e);
+		}
+	}
+}
+
+template <bool LDS>
+__device__ void wordsDocuments( const L1Params& P)
+{
+	if (!P.wordsKernel) return;
+	LexTab<LDS> T;
+	stageTables( P, T);
+	const u32 chunked = ldu( (const u32*)&P.counters[ L1C_CHUNKED]);
+	LexWave w;
+	w.events = 0; w.nEvents = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
+	const u32 nunits = ldu( (const u32*)&P.counters[ L1C_UNITS]);
+	for (u32 round=0; round<=nunits; ++round)
+	{
+		u32 unit = 0;
+		if (LANE == 0) unit = atomicAdd( (u32*)&P.counters[ L1C_CURSOR4], 1u);
+		unit = uni( unit);
+		if (unit >= nunits) break;
+		u32 doc = unit;
+		if (chunked)
+		{
+			u32 lo = 0, hi = P.ndocs;			// last document whose first unit is <= unit
+			while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (ldu( &P.unitStart[ mid]) <= unit) lo = mid; else hi = mid; }
+			doc = lo;
+		}
+		u64 beg, end;
+		docBounds( P, doc, beg, end);
+		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
+		u32 segBeg = 0, segEnd = w.docLen;
+		if (chunked)
+		{
+			segBeg = (unit - ldu( &P.unitStart[ doc])) * P.chunkBytes;
+			segEnd = (w.docLen - segBeg) < P.chunkBytes ? w.docLen : segBeg + P.chunkBytes;
+		}
+		const u64 qb = queueBase( P, beg + segBeg, unit);
+		w.queue = P.wordQueue + 4*qb;
+		w.queueCap = (u32)(queueBase( P, beg + segEnd, unit + 1) - qb);
+		w.nQueue = 0; w.err = 0;
+		wordsUnit<LDS>( w, P, T, segBeg, segEnd);
+		if (LANE == 0)
+		{
+			P.wordCount[ unit] = w.err ? 0u : w.nQueue;
+			if (w.err) P.docStatus[ doc] = (int32_t)w.err;
+			atomicAdd( (unsigned long long*)&P.counters[ L1C_WORDREPORTS], (unsigned long long)w.nQueue);
+		}
+	}
+}
+
+// ---------------------------------------------------------------- stages 2-3 with the words kernel: two queues, merged
+// The automaton's reports (scan kernel) and the word reports (words kernel) of a document, both in (end offset, pattern) order,
+// go through the reference's handler in the order the reference's callback sees them.  Each queue is read 64 records at a time
+// (the automaton's get their leftmost starts on the way, nextBatch); a chunked document has one slice per chunk in either queue.
+struct ReportStream
+{
+	const u32* queue; u32 nq, qi, qb, qn, unit;
+	LaneReport lr;
+};
+template <bool LDS, bool CP, bool CH, bool WORDS>
+__device__ __forceinline__ void streamSlice( ReportStream& s, const LexWave& w, const L1Params& P)
+{
+	const u64 qbase = ((w.docBegin + (u64)(s.unit - w.unit0) * P.chunkBytes) * P.queueMul >> 4) + 64ull*s.unit;
+	s.queue = (WORDS ? P.wordQueue : P.reportQueue) + 4*qbase;
+	s.nq = ldu( WORDS ? &P.wordCount[ s.unit] : &P.reportCount[ s.unit]);
+	s.qi = 0; s.qb = 0; s.qn = 0;
+}
+template <bool LDS, bool CP, bool CH, bool WORDS>
+__device__ __forceinline__ void streamFill( ReportStream& s, const LexWave& w, const L1Params& P, const LexTab<LDS>& T)
+{
+	// the next batch of the current slice, or of the next slice that holds any
+	while (s.qi == s.nq)
+	{
+		if (!CH || s.unit + 1u >= w.unitEnd) return;
+		++s.unit;
+		streamSlice<LDS,CP,CH,WORDS>( s, w, P);
+	}
+	s.qb = s.qi;
+	if (WORDS)
+	{
+		s.qn = (s.nq - s.qb) < 64u ? (s.nq - s.qb) : 64u;
+		resolveStarts<LDS,CP>( s.queue, w.doc, w.docLen, P, T, s.qb, s.qn, s.lr);
+	}
+	else nextBatch<LDS,CP>( s.queue, w.doc, w.docLen, P, T, s.nq, s.qb, s.qn, s.lr);
+}
+template <bool LDS, bool CP, bool CH>
+__device__ void postDocumentMerged( LexWave& w, const L1Params& P, const LexTab<LDS>& T)
+{
+	ReportStream A, B;
+	A.unit = w.unit0; B.unit = w.unit0;
+	A.lr.to = 0; A.lr.from = 0; A.lr.id = 0; A.lr.levelBind = 0; A.lr.prefixLen = 0; A.lr.suffixLen = 0; A.lr.pi = 0; A.lr.def = 0; A.lr.skip = 0;
+	B.lr = A.lr;
+	streamSlice<LDS,CP,CH,false>( A, w, P); streamFill<LDS,CP,CH,false>( A, w, P, T);
+	streamSlice<LDS,CP,CH,true>( B, w, P); streamFill<LDS,CP,CH,true>( B, w, P, T);
+	const u64 NOKEY = ~0ull;
+	while (!w.err)
+	{
+		const u32 xa = A.qi - A.qb, xb = B.qi - B.qb;
+		u64 keyA = NOKEY, keyB = NOKEY;
+		if (A.qi < A.nq) keyA = ((u64)(u32)__builtin_amdgcn_readlane( A.lr.to, xa) << 32) | (u32)__builtin_amdgcn_readlane( A.lr.pi, xa);
+		if (B.qi < B.nq) keyB = ((u64)(u32)__builtin_amdgcn_readlane( B.lr.to, xb) << 32) | (u32)__builtin_amdgcn_readlane( B.lr.pi, xb);
+		if (keyA == NOKEY && keyB == NOKEY) break;
+		if (keyB < keyA)
+		{
+			if (!__builtin_amdgcn_readlane( B.lr.skip, xb))
+			{
+				handleReport( w, P, (u32)__builtin_amdgcn_readlane( B.lr.id, xb), (u32)__builtin_amdgcn_readlane( B.lr.levelBind, xb),
+					(u32)__builtin_amdgcn_readlane( B.lr.prefixLen, xb), (u32)__builtin_amdgcn_readlane( B.lr.suffixLen, xb),
+					(u32)__builtin_amdgcn_readlane( B.lr.from, xb), (u32)(keyB >> 32));
+			}
+			++B.qi;
+			if (B.qi == B.qb + B.qn || B.qi == B.nq) streamFill<LDS,CP,CH,true>( B, w, P, T);
+		}
+		else
+		{
+			if (!__builtin_amdgcn_readlane( A.lr.skip, xa))
+			{
+				handleReport( w, P, (u32)__builtin_amdgcn_readlane( A.lr.id, xa), (u32)__builtin_amdgcn_readlane( A.lr.levelBind, xa),
+					(u32)__builtin_amdgcn_readlane( A.lr.prefixLen, xa), (u32)__builtin_amdgcn_readlane( A.lr.suffixLen, xa),
+					(u32)__builtin_amdgcn_readlane( A.lr.from, xa), (u32)(keyA >> 32));
+			}
+			++A.qi;
+			if (A.qi == A.qb + A.qn || A.qi == A.nq) streamFill<LDS,CP,CH,false>( A, w, P, T);
+		}
+	}
+}
+
 // ---------------------------------------------------------------- stage 4: ordinal positions + output (:893-945)
 // The reference walks the sorted event array once with a little state machine (patternLexer.cpp:893-945):
 // up to the first content/unique event only successor-bound events are kept (position 1); from there on
@@ -1350,7 +1776,6 @@ __device__ void countUnits( const L1Params& P)
 	}
 }
 
-__device__ __forceinline__ u64 queueBase( const L1Params& P, u64 bytePos, u32 unit) { return ((bytePos * P.queueMul) >> 4) + 64ull*unit; }
 
 // SCAN: automaton over the bytes of a unit (a document, or a chunk of a long one), raw reports into the unit's slice of the
 // report queue.  All sets of instances are launched, the ones that are not meant for the batch leave at once.
@@ -1457,12 +1882,17 @@ __device__ void postDocuments( const L1Params& P)
 		w.unit0 = chunked ? ldu( &P.unitStart[ doc]) : doc;
 		w.unitEnd = chunked ? ldu( &P.unitStart[ doc+1]) : doc + 1u;
 		w.unit = w.unit0;
-		sliceOf( w, P);
-		if (CH && !w.nQueue) (void)nextSlice( w, P);
-		w.queueCap = w.nQueue; w.nEvents = 0; w.err = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
+		w.nEvents = 0; w.err = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
 		w.e.id = 0; w.e.pos = 0; w.e.size = 0; w.e.lb = 0;
 		const u64 tDoc = PROF_T();
-		postDocument<LDS,CP,CH>( w, P, T);
+		if (!CP && P.wordsKernel) postDocumentMerged<LDS,CP,CH>( w, P, T);
+		else
+		{
+			sliceOf( w, P);
+			if (CH && !w.nQueue) (void)nextSlice( w, P);
+			w.queueCap = w.nQueue;
+			postDocument<LDS,CP,CH>( w, P, T);
+		}
 		spillLanes( w, 0);
 		__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
 		if (!w.err) emitLexems( w, P, doc);
@@ -1502,6 +1932,7 @@ SPA_L1_KERNEL( p16, 16, 256)
 SPA_L1_KERNEL( p32, 32, 256)
 extern "C" __global__ __launch_bounds__(64) void spa_l1_approx_kernel( L1Params P) { approxDocuments( P); }
 extern "C" __global__ __launch_bounds__(64) void spa_l1_units_kernel( L1Params P) { countUnits( P); }
+extern "C" __global__ __launch_bounds__(64*WORD_WAVES) void spa_l1_words_kernel( L1Params P) { if (P.ldsWords) wordsDocuments<true>( P); else wordsDocuments<false>( P); }
 // the post-processing kernel reads the automaton's tables from global memory (start of match only)
 enum {POST_WAVES=4};
 // The post-processing kernel is bound by the latency of its dependent chains, not by issue slots: it gains from
@@ -1517,7 +1948,9 @@ extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_
 extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel_cp( L1Params P) { postDocuments<false,true,true>( P); }
 
 namespace spa {
-hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels)
+// PS: the parameters of the scan kernel (its table image holds the scanned passes only; nofPasses = 0: nothing to scan);
+// PW: of the words kernel (all passes, in LDS when they fit); P: of the other kernels (all passes, read from global memory)
+hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned wordBlocks, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords)
 {
 	if (P.nofApprox)
 	{
@@ -1525,24 +1958,26 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 		hipLaunchKernelGGL( spa_l1_approx_kernel, dim3( postWaves), dim3( 64), 0, stream, P);
 		hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
-		return betweenKernels ? hipEventRecord( betweenKernels, stream) : hipSuccess;
+		if (betweenKernels) { e = hipEventRecord( betweenKernels, stream); if (e != hipSuccess) return e; }
+		return afterWords ? hipEventRecord( afterWords, stream) : hipSuccess;
 	}
-	const size_t lds = (size_t)P.ldsWords * 8;
+	const size_t lds = (size_t)PS.ldsWords * 8;
 	// the units of the batch (chunks of long documents), then BOTH sets of instances: which one a batch needs is known on
 	// the device only (classes by code point: here; chunked documents: after the units kernel) -- the other one leaves at once
 	hipLaunchKernelGGL( spa_l1_units_kernel, dim3( 1), dim3( 64), 0, stream, P);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	L1Params S = P;
+	L1Params S = PS;
 	S.sequentialPass = 1;
 #define SPA_L1_LAUNCH_ONE( KERNEL, ARGS) do { \
 	if (lds > 65536) { e = hipFuncSetAttribute( (const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
 	hipLaunchKernelGGL( KERNEL, dim3( nblocks), dim3( nthreads), lds, stream, ARGS); } while (0)
 #define SPA_L1_LAUNCH( N) do { \
-	if (P.cpBlocks || P.nofNullable) { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, P); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, S); } \
-	else { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N, P); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, P); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, S); } } while (0)
-	switch (P.nofPasses)
+	if (P.cpBlocks || P.nofNullable) { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, PS); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, S); } \
+	else { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N, PS); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, PS); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, S); } } while (0)
+	switch (PS.nofPasses)
 	{
+		case 0: break;		// (nothing to scan: the caller has cleared the report counts)
 		case 1: SPA_L1_LAUNCH( p1); break;
 		case 2: SPA_L1_LAUNCH( p2); break;
 		case 3: SPA_L1_LAUNCH( p3); break;
@@ -1552,13 +1987,24 @@ hipError_t launchL1Lex( const L1Params& P, unsigned nblocks, unsigned nthreads, 
 		case 7: SPA_L1_LAUNCH( p7); break;
 		case 8: SPA_L1_LAUNCH( p8); break;
 		default:
-			if (P.nofPasses <= 16) SPA_L1_LAUNCH( p16);
-			else if (P.nofPasses <= 32) SPA_L1_LAUNCH( p32);
+			if (PS.nofPasses <= 16) SPA_L1_LAUNCH( p16);
+			else if (PS.nofPasses <= 32) SPA_L1_LAUNCH( p32);
 			else return hipErrorInvalidValue;
 	}
+	if (e != hipSuccess) return e;
 	e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	if (betweenKernels) { e = hipEventRecord( betweenKernels, stream); if (e != hipSuccess) return e; }
+	if (P.wordsKernel)
+	{
+		// (its own copy of the parameters: the image of ALL passes staged in LDS when it fits, PW.ldsWords)
+		const size_t wlds = (size_t)PW.ldsWords * 8;
+		if (wlds > 65536) { e = hipFuncSetAttribute( (const void*)spa_l1_words_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); if (e != hipSuccess) return e; }
+		hipLaunchKernelGGL( spa_l1_words_kernel, dim3( wordBlocks), dim3( 64*WORD_WAVES), wlds, stream, PW);
+		e = hipGetLastError();
+		if (e != hipSuccess) return e;
+	}
+	if (afterWords) { e = hipEventRecord( afterWords, stream); if (e != hipSuccess) return e; }
 	// its own number of waves (one event array each), in workgroups of POST_WAVES
 	if (P.cpBlocks || P.nofNullable) hipLaunchKernelGGL( spa_l1_post_kernel_cp, dim3( (postWaves + POST_WAVES-1) / POST_WAVES), dim3( 64*POST_WAVES), 0, stream, P);
 	else

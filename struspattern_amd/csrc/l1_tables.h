@@ -20,7 +20,8 @@ enum {CTX_WORD=0, CTX_OTHER=1, CTX_NEWLINE=2, CTX_EDGE=3, CTX_COUNT=4};	// EDGE 
 
 enum {L1_WORDS_PER_PASS=64};
 enum {L1_WORD_LITERAL=0xFFFFFFFFu};	// pattern \bWORD\b handled by the token hash instead of automaton bits
-enum {L1_LITERAL_FLAG=0x80000000u};	// queue records: start offset already known
+enum {L1_LITERAL_FLAG=0x80000000u,	// queue records: start offset already known
+      L1_DEAD_FLAG=0x40000000u};	// ... a candidate of the words kernel that did not confirm: skipped
 
 struct DevLexPattern		// 32 B, one per defineLexem call in definition order; an expression too wide for one 64-bit word
 {				// is cut at an alternation into several entries (adjacent, same defIndex) whose reports are merged
@@ -78,6 +79,36 @@ struct DevLiteral		// 48 B, open addressing, hash==0 = empty: a whole-word liter
 	uint32_t textOffset;	// into the literal text pool
 	uint8_t text[ 16];	// the first 16 bytes of the word, zero padded
 };
+
+// WORD SHAPES (round 3).  An expression every match of which ENDS WHERE A RUN OF WORD CHARACTERS ENDS and is pinned by a few
+// literal bytes at a fixed place of that run needs no automaton pass over the text: the lexer looks the bytes up where a run
+// ends, and a candidate is confirmed -- and its leftmost start found -- by running the expression's automaton backwards from
+// the run's end (the start-of-match walk every automaton report goes through anyway).  Three shapes, each with a proof that no
+// match is missed (l1_compile.cpp, wordShapeOf):
+//   PREFIX(o,k)  \b S1..So LIT E \b   all of it word characters: a match is a whole run, LIT = its bytes [o, o+k)
+//   SUFFIX(k)    X LIT \b            LIT word characters: a match ends with a run whose last k bytes are LIT
+//   PREVWORD     \b WORD SEP E \b     WORD, E word characters, SEP one byte that is none: a match ends with a run whose
+//                                     predecessor, one byte before it, is the whole run WORD
+// The expressions keep their automaton positions in the tables (for the backward walk) but in passes of their own behind the
+// passes the scan kernel runs (LexTables::scanPasses).
+enum {SHAPE_PREFIX=1, SHAPE_SUFFIX=2, SHAPE_PREVWORD=3, SHAPE_MAXVARIANTS=8};
+struct DevShape			// 16 B, open addressing (linear probing), tag==0 = empty
+{
+	uint32_t tag;		// kind | offset << 2 | length << 4 (PREFIX / SUFFIX: length 2..4 bytes) ; kind | length << 8 (PREVWORD: length of the word)
+	uint32_t key;		// the literal bytes, first byte lowest; PREVWORD: literalHashFinish( polynomial hash of the word)
+	uint32_t patBegin;	// shapePats[patBegin .. patBegin+patCount): pattern indices, ascending
+	uint32_t patCount;
+};
+static inline
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+uint32_t shapeSlotHash( uint32_t tag, uint32_t key)
+{
+	uint32_t h = key * 0x9E3779B1u ^ (tag * 0x85EBCA6Bu);
+	h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+	return h;
+}
 
 // FNV-1a step used for the symbol hash (lexem id first, then the text bytes); 0 is reserved for
 // "empty" so a zero hash is mapped to 1

@@ -50,6 +50,13 @@ class Tables:
         self.cpBlocks = take(nblk)
         npg = take(1)[0]
         self.cpPages = take(npg)
+        # word shapes: passes the scan kernel runs, expressions taken as shapes, table entries
+        self.scan_passes, self.nof_shapes = take(2)
+        self.npasses = self.nofPasses
+        self.shapes = {}
+        while p < len(d):
+            tag, key, pc = take(3)
+            self.shapes[(tag, key)] = take(pc)
         assert p == len(d)
 
     def _lead(self, text, pos):

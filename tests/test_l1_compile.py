@@ -202,10 +202,12 @@ def test_symbols_and_names():
         lx.defineSymbol(8, 1, "cat")                   # symbol defined twice (:286-290)
 
 
-def test_size_ordered_packing_reports_the_same():
+def test_size_ordered_packing_reports_the_same(monkeypatch):
     """4800 synthetic patterns need two passes in definition order and one when packed by size; the raw
-    reports (sorted by end offset, pattern index) must not depend on the packing."""
+    reports (sorted by end offset, pattern index) must not depend on the packing.  (Every expression in the
+    scanned passes: SPA_L1_SHAPES=0.)"""
     from struspattern_amd import synth
+    monkeypatch.setenv("SPA_L1_SHAPES", "0")
     vocab = synth.vocabulary(6000, 77)
     pats = synth.lexer_patterns(4800, vocab, 6)
     text, offs = synth.text_documents(1, 1500, vocab, 106, utf8=False)
@@ -217,6 +219,26 @@ def test_size_ordered_packing_reports_the_same():
     synth.apply_lexer_patterns(o, pats)
     raw, _ = o.matchDocs(text, [0, len(text)], raw=True)
     assert Tables(dump).raw_reports(text) == [(int(r[0]), int(r[1]), int(r[2])) for r in raw]
+
+
+def test_word_shapes_keep_their_automata_behind_the_scanned_passes():
+    """Expressions pinned by a few literal bytes of a word run (l1_tables.h: PREFIX / SUFFIX / PREVWORD) are found by the
+    words kernel; they keep their automaton positions -- the backward walk that confirms a candidate needs them -- in passes
+    of their own: all passes together still report what the oracle reports, and the scanned passes lose the shapes."""
+    from struspattern_amd import synth
+    vocab = synth.vocabulary(6000, 77)
+    pats = synth.lexer_patterns(4800, vocab, 6)
+    text, offs = synth.text_documents(1, 1500, vocab, 106, utf8=False)
+    lx = spa.PatternLexerInstance()
+    synth.apply_lexer_patterns(lx, pats)
+    dump = lx.dumpTables()
+    t = Tables(dump)
+    o = oracle.L1Lexer()
+    synth.apply_lexer_patterns(o, pats)
+    raw, _ = o.matchDocs(text, [0, len(text)], raw=True)
+    assert t.raw_reports(text) == [(int(r[0]), int(r[1]), int(r[2])) for r in raw]
+    nshape = sum(1 for _, e, _, _, _ in pats if e.startswith("[a-z]+") or ("\\s\\w+" in e) or e.endswith("[a-z]*\\b"))
+    assert t.scan_passes < t.npasses and t.nof_shapes == nshape and nshape > 700
 
 
 def test_classes_covering_all_non_ascii_characters():

@@ -322,20 +322,31 @@ def test_random_regex_sets(seed):
         assert np.array_equal(gpu.lexems, ref), pats
 
 
-# the (11000, ..) case compiles to 3 automaton passes (a pass count that is not a power of two)
+# shapes=True: the default -- whole-word literals and word shapes (l1_tables.h) by the words kernel, the rest by the scan kernel;
+# shapes=False (SPA_L1_SHAPES=0): every expression that is not a literal in the scanned passes -- the (11000, ..) case then compiles
+# to 3 automaton passes (a pass count that is not a power of two), the (4800, ..) case fills one pass only when packed by size and
+# the kernel sorts the reports of an end offset
+@pytest.mark.parametrize("shapes", [True, False])
 @pytest.mark.parametrize("npat,ndocs,docbytes,utf8,seed", [(64, 16, 2000, False, 1), (256, 24, 4096, False, 2), (256, 8, 3000, True, 3), (700, 6, 2000, False, 4),
                                                             (11000, 4, 2000, False, 5),
-                                                            # 4800 patterns fill one pass only when packed by size: the kernel sorts the reports of an end offset
                                                             (4800, 12, 3000, False, 6)])
-def test_synthetic_lexer_workload(npat, ndocs, docbytes, utf8, seed):
+def test_synthetic_lexer_workload(npat, ndocs, docbytes, utf8, seed, shapes, monkeypatch):
+    from tests.l1_table_sim import Tables
+    if not shapes:
+        monkeypatch.setenv("SPA_L1_SHAPES", "0")
     vocab = synth.vocabulary(12000 if npat > 6000 else 6000 if npat > 3000 else 3000, 77)
     pats = synth.lexer_patterns(npat, vocab, seed)
     text, offs = synth.text_documents(ndocs, docbytes, vocab, 100 + seed, utf8=utf8)
     lx, o = _both(lambda x: synth.apply_lexer_patterns(x, pats))
-    if npat == 4800:
-        assert int(lx.dumpTables()[6]) == 0 and int(lx.dumpTables()[0]) == 1
-    if npat == 11000:
-        assert int(lx.dumpTables()[0]) == 3
+    t = Tables(lx.dumpTables())
+    if not shapes:
+        assert t.nof_shapes == 0 and t.scan_passes == t.npasses
+        if npat == 4800:
+            assert int(lx.dumpTables()[6]) == 0 and t.npasses == 1
+        if npat == 11000:
+            assert t.npasses == 3
+    elif npat >= 700:
+        assert t.nof_shapes > npat // 20 and t.scan_passes == 1 and t.npasses > t.scan_passes
     gpu = lx.createContext().matchDocs(text, offs)
     ref, roffs = o.matchDocs(text, offs, nthreads=8)
     assert len(ref) > 100
