@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "GB/s input text scanned + matches/s, 10k-regex lexer + 10k-rule automaton"
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_bench_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_bench_pmc_summary.json")
 
 
 def parse_args():
@@ -189,22 +189,24 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         # per-kernel launch durations: HIP events recorded by the library on the launch stream
-        l1_ms, l2_ms, scan_ms, post_ms = [], [], [], []
+        l1_ms, l2_ms, scan_ms, words_ms, post_ms = [], [], [], [], []
         for _ in range(min(steps, 5)):
             step(sh)
             if lctx is not None:
                 l1_ms.append(lctx.lastKernelMs())
-                a, b = lctx.lastKernelMsSplit()
+                a, b, d = lctx.lastKernelMsSplit3()
                 scan_ms.append(a)
-                post_ms.append(b)
+                words_ms.append(b)
+                post_ms.append(d)
             if mctx is not None:
                 l2_ms.append(mctx.lastKernelMs())
-        lcount = lctx.batchCounters() if lctx is not None else {"lexems": 0, "bytes": 0, "failed_docs": 0, "raw_reports": 0}
+        lcount = lctx.batchCounters() if lctx is not None else {"lexems": 0, "bytes": 0, "failed_docs": 0, "raw_reports": 0, "word_reports": 0}
         mcount = mctx.batchCounters() if mctx is not None else {"results": 0, "items": 0, "events": 0, "failed_docs": 0}
         if lcount["failed_docs"] or mcount["failed_docs"]:
             raise SystemExit("bench: documents failed in the timed region")
         return {"dt": dt, "steps": steps, "l1_ms": float(np.mean(l1_ms)) if l1_ms else 0.0, "l2_ms": float(np.mean(l2_ms)) if l2_ms else 0.0,
-                "l1_scan_ms": float(np.mean(scan_ms)) if scan_ms else 0.0, "l1_post_ms": float(np.mean(post_ms)) if post_ms else 0.0,
+                "l1_scan_ms": float(np.mean(scan_ms)) if scan_ms else 0.0, "l1_words_ms": float(np.mean(words_ms)) if words_ms else 0.0, "l1_post_ms": float(np.mean(post_ms)) if post_ms else 0.0,
+                "word_reports": int(lcount.get("word_reports", 0)), "l2_kernel": (mctx.kernelName() if mctx is not None else None),
                 "raw_reports": int(lcount["raw_reports"]), "lexems": int(lcount["lexems"]), "events": int(mcount["events"]), "results": int(mcount["results"]), "items": int(mcount["items"])}
 
     # secondary shapes first (short, no barrier), the headline shape last so that its outputs are the
@@ -254,24 +256,33 @@ def report(args, wl, world, pats, head, m, tot, dt, secondary, nbytes, h2d_ms):
         value, unit, metric = gbytes * steps / dt / 1e9, "GB/s", METRIC
     # algorithmic bytes per launch: L1 = text + 16 B x lexems; L2 = 16 B x events + 36 B x results;
     # pipeline = text + 36 B x results.  The lexer runs as two kernels with the raw reports (16 B each) between
-    # them: scan = text + raw reports written, post = text + raw reports read + lexems written.
+    # them: scan = text + raw reports written; words (literals and word shapes, found where word runs end) = text + word reports
+    # written; post = raw reports + word reports read + lexems written (it no longer reads the text, only the bytes of matches with symbols).
     b_l1 = float(nbytes) + 16.0 * m["lexems"]
     b_l2 = 16.0 * m["events"] + 36.0 * m["results"]
     roofs = {}
     if m["l1_ms"] > 0:
         roofs["spa_l1_scan_kernel"] = roofline_of("spa_l1_scan_kernel", m["l1_scan_ms"], float(nbytes) + 16.0 * m["raw_reports"],
                                                   *pmc_traffic("spa_l1_scan_kernel", wl, args, m["l1_scan_ms"]))
-        roofs["spa_l1_post_kernel"] = roofline_of("spa_l1_post_kernel", m["l1_post_ms"], float(nbytes) + 16.0 * m["raw_reports"] + 16.0 * m["lexems"],
+        if m["l1_words_ms"] > 0.05:
+            roofs["spa_l1_words_kernel"] = roofline_of("spa_l1_words_kernel", m["l1_words_ms"], float(nbytes) + 16.0 * m["word_reports"],
+                                                       *pmc_traffic("spa_l1_words_kernel", wl, args, m["l1_words_ms"]))
+            post_bytes = 16.0 * (m["raw_reports"] + m["word_reports"]) + 16.0 * m["lexems"]
+        else:
+            post_bytes = float(nbytes) + 16.0 * m["raw_reports"] + 16.0 * m["lexems"]
+        roofs["spa_l1_post_kernel"] = roofline_of("spa_l1_post_kernel", m["l1_post_ms"], post_bytes,
                                                   *pmc_traffic("spa_l1_post_kernel", wl, args, m["l1_post_ms"]))
+    l2name = m.get("l2_kernel") or "spa_l2_match_kernel"
     if m["l2_ms"] > 0:
-        roofs["spa_l2_match_kernel"] = roofline_of("spa_l2_match_kernel", m["l2_ms"], b_l2, *pmc_traffic("spa_l2", wl, args, m["l2_ms"]))
+        roofs[l2name] = roofline_of(l2name, m["l2_ms"], b_l2, *pmc_traffic(l2name, wl, args, m["l2_ms"]))
     dominant = max(roofs.values(), key=lambda r: r["kernel_ms"])
     if m["l1_ms"] > 0:
         roofs["lexer"] = roofline_of("scan + post", m["l1_ms"], b_l1)
     if wl == "pipeline":
         roofs["pipeline"] = roofline_of("lexer + automaton", m["l1_ms"] + m["l2_ms"], float(nbytes) + 36.0 * m["results"])
     workload = {
-        "pipeline": "configs[4] per-GPU shard: %d regexes + %d token rules, %d docs x %s UTF-8 per step" % (len(pats) if pats else 0, args.rules, head.ndocs, head.name),
+        "pipeline": "configs[4] per-GPU shard: %d regexes + %d token rules, %d docs x %s UTF-8 per step (the same %d MB resident in HBM every step; configs[4] asks 32 GB per GPU: %d such steps)" % (
+            len(pats) if pats else 0, args.rules, head.ndocs, head.name, nbytes // 1000000, max(1, int(32e9 // max(1, nbytes)))),
         "lexer": "configs[1]: %d regexes, %d docs x %s ASCII per step (lexer only)" % (len(pats) if pats else 0, head.ndocs, head.name),
         "l2": "configs[2]: %d rules (%s), %d docs x %d tokens per step (rule automaton only)" % (args.rules, args.op or "5-op Zipf mix", head.ndocs, args.docsize),
     }[wl]
@@ -284,7 +295,7 @@ def report(args, wl, world, pats, head, m, tot, dt, secondary, nbytes, h2d_ms):
         "matches_per_s": gresults * steps / dt,
         "events_per_s": gevents * steps / dt,
         "lexems_per_s": glexems * steps / dt,
-        "kernel_ms": {"spa_l1_scan_kernel": m["l1_scan_ms"], "spa_l1_post_kernel": m["l1_post_ms"], "spa_l2_match_kernel": m["l2_ms"]},
+        "kernel_ms": {"spa_l1_scan_kernel": m["l1_scan_ms"], "spa_l1_words_kernel": m["l1_words_ms"], "spa_l1_post_kernel": m["l1_post_ms"], l2name: m["l2_ms"]},
         "roofline": dominant,
         "roofline_all": roofs,
     }

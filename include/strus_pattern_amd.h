@@ -232,6 +232,8 @@ double sp_matcher_ctx_last_kernel_ms(sp_matcher_ctx_t* c);
 /* which kernel the context runs its batches on: 0 general automaton, 1 LDS-resident automaton (flat rule sets),
  * 2 the opt-in join prototype (environment SPA_L2_JOIN=1 at context creation; result SETS with their items, no statistics) */
 int sp_matcher_ctx_kernel_kind(const sp_matcher_ctx_t* c);
+/* name of the kernel that does the work of this context's batches (what rocprofv3 lists) */
+const char* sp_matcher_ctx_kernel_name(const sp_matcher_ctx_t* c);
 /* copies the per-document status words of the last batch to the host (waits for the stream) */
 int sp_matcher_ctx_batch_status(sp_matcher_ctx_t* c, int32_t* status, size_t ndocs);
 /* doubles every per-document working-set capacity (what the host entry points do on SP_DOC_ERR_ARENA) */

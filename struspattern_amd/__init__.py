@@ -210,6 +210,10 @@ class PatternMatcherContext:
         """0 general automaton kernel, 1 LDS-resident kernel (flat rule sets), 2 join prototype (SPA_L2_JOIN=1)"""
         return self._L.sp_matcher_ctx_kernel_kind(self._h)
 
+    def kernelName(self):
+        """name of the kernel that does the work of this context's batches (what rocprofv3 lists)"""
+        return self._L.sp_matcher_ctx_kernel_name(self._h).decode()
+
 
 def _serialize(L, fn, handle, err):
     blob = ctypes.c_void_p()
@@ -427,7 +431,7 @@ class PatternLexerContext:
         if self._L.sp_lexer_ctx_batch_counters(self._h, arr) != 0:
             raise PatternError("reading batch counters failed: " + self._err())
         return {"lexems": arr[0], "bytes": arr[1], "raw_reports": arr[2], "failed_docs": arr[3], "scan_units": arr[4], "rescanned_docs": arr[5],
-                "prof": [arr[4], arr[5], arr[6], arr[7]]}
+                "word_reports": arr[6], "prof": [arr[4], arr[5], arr[6], arr[7]]}
 
     def batchStatus(self, ndocs):
         st = np.zeros(ndocs, np.int32)

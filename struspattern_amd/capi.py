@@ -103,6 +103,7 @@ SIGNATURES = {
     "sp_matcher_ctx_batch_counters": (ctypes.c_int, [c_vp, P(c_u64)]),
     "sp_matcher_ctx_last_kernel_ms": (ctypes.c_double, [c_vp]),
     "sp_matcher_ctx_kernel_kind": (ctypes.c_int, [c_vp]),
+    "sp_matcher_ctx_kernel_name": (ctypes.c_char_p, [c_vp]),
     "sp_matcher_ctx_batch_status": (ctypes.c_int, [c_vp, c_vp, ctypes.c_size_t]),
     "sp_matcher_ctx_grow_arena": (ctypes.c_int, [c_vp]),
     "sp_matcher_ctx_reserve_output": (ctypes.c_int, [c_vp, c_u64, c_u64]),

@@ -14,7 +14,7 @@
 #include <vector>
 
 namespace spa {
-hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned wordBlocks, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords);
+hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned laneBlocks, unsigned wordBlocks, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords);
 }
 using namespace spa;
 
@@ -424,7 +424,13 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	PW.ldsWords = ((size_t)c->imgWords*8 <= 140*1024 && T.nofShapes) ? c->imgWords : 0u;
 	unsigned wordBlocks = (unsigned)((maxUnits + 15) / 16 < (uint64_t)c->numCUs ? (maxUnits + 15) / 16 : (uint64_t)c->numCUs);
 	if (wordBlocks == 0) wordBlocks = 1;
-	HIP_CHECK( launchL1Lex( PS, PW, P, nblocks, c->blockThreads, wordBlocks, nwaves, stream, c->evMid, c->evWords));
+	// (scanWords = 0 keeps the batch off the lane-per-stream scan kernel: an expression that can stay live across blanks would
+	//  fail the warm-up proof of most pieces, SPA_L1_NO_LANES: tests)
+	P.scanWords = PS.scanWords = PW.scanWords = (c->wordsKernel && T.lanesOk && !getenv( "SPA_L1_NO_LANES")) ? T.scanWords : 0u;
+	// lane-per-stream scan kernel (a few automaton words left to scan): a wave per unit, workgroups of four waves
+	unsigned laneBlocks = (unsigned)((maxUnits + 3) / 4 < (uint64_t)c->numCUs*4 ? (maxUnits + 3) / 4 : (uint64_t)c->numCUs*4);
+	if (laneBlocks == 0) laneBlocks = 1;
+	HIP_CHECK( launchL1Lex( PS, PW, P, nblocks, c->blockThreads, laneBlocks, wordBlocks, nwaves, stream, c->evMid, c->evWords));
 	HIP_CHECK( hipEventRecord( c->evStop, stream));
 	c->evValid = true; c->lastStream = stream; c->lastNdocs = ndocs;
 }
@@ -456,7 +462,7 @@ int sp_lexer_ctx_batch_counters( sp_lexer_ctx_t* c, uint64_t counters[8])
 		for (int i=0; i<L1C_COUNT; ++i) counters[ i] = all[ i];
 #ifndef SPA_PROF
 		// (the phase profile of a PROF build lives in 4..7) scan units of the batch and documents scanned again in one piece
-		counters[ 4] = (uint32_t)all[ L1C_UNITS]; counters[ 5] = all[ L1C_SEQDOCS];
+		counters[ 4] = (uint32_t)all[ L1C_UNITS]; counters[ 5] = all[ L1C_SEQDOCS]; counters[ 6] = all[ L1C_WORDREPORTS];
 #endif
 	});
 }

@@ -188,6 +188,14 @@ const char* sp_matcher_format_string( const sp_matcher_t* m, uint32_t format_han
 
 // which kernel the context's batches run on: 0 = general, 1 = LDS-resident (flat rule sets), 2 = join prototype (SPA_L2_JOIN=1)
 int sp_matcher_ctx_kernel_kind( const sp_matcher_ctx_t* c) { return c->join ? 2 : c->fast ? 1 : 0; }
+// name of the kernel that does a batch's work (the instance of the LDS-resident kernel is picked by SPA_L2_FAST_SIZE, default n)
+const char* sp_matcher_ctx_kernel_name( const sp_matcher_ctx_t* c)
+{
+	if (c->join) return "spa_l2_join_kernel";
+	if (!c->fast) return "spa_l2_match_kernel";
+	static const char* names[ 5] = {"spa_l2_fast_kernel_s", "spa_l2_fast_kernel_m", "spa_l2_fast_kernel_l", "spa_l2_fast_kernel_t", "spa_l2_fast_kernel_n"};
+	return names[ c->fastVariant < 5 ? c->fastVariant : 4];
+}
 
 // 1 when the compiled rule set is flat (l2_fast.h) and runs on the LDS-resident kernel, else 0 with the reason
 int sp_matcher_fast_tier( const sp_matcher_t* m, char* why, size_t whysize)

@@ -1242,6 +1242,27 @@ void LexCompiler::compile()
 	}
 	// the passes the scan kernel runs end here; the word shapes follow in passes of their own (in definition order)
 	T.scanPasses = (word + L1_WORDS_PER_PASS-1) / L1_WORDS_PER_PASS;
+	T.scanWords = word;
+	T.lanesOk = true;
+	for (size_t pi=0; pi<autos.size() && T.lanesOk; ++pi)
+	{
+		if (T.patterns[ pi].word == L1_WORD_LITERAL || isShape[ pi]) continue;
+		const Automaton& a = autos[ pi];
+		const size_t n = a.pos.size();
+		for (size_t k=0; k<n && T.lanesOk; ++k)
+		{
+			if (!a.pos[ k].has( ' ')) continue;
+			// is position k on a cycle?  (reachability over the follow edges, at most 64 positions)
+			uint64_t seen = 0, front = a.follow[ k];
+			while (front & ~seen)
+			{
+				const uint64_t fresh = front & ~seen;
+				seen |= fresh; front = 0;
+				for (size_t q=0; q<n; ++q) if (fresh & (1ull << q)) front |= a.follow[ q];
+			}
+			if (seen & (1ull << k)) T.lanesOk = false;
+		}
+	}
 	T.nofShapes = (uint32_t)shapeOf.size();
 	if (!shapeOf.empty())
 	{
@@ -1691,7 +1712,7 @@ void LexCompiler::save( std::vector<uint8_t>& out) const
 	w.vec( T.byteClass); w.vec( T.classCtx); w.vec( T.cpBlocks); w.vec( T.cpPages); w.vec( T.charMask); w.vec( T.startMask); w.vec( T.acceptMask); w.vec( T.shiftDst); w.vec( T.selfLoop);
 	w.vec( T.exCount); w.vec( T.exSrc); w.vec( T.exDst); w.vec( T.wordPatBegin); w.vec( T.wordPats); w.vec( T.patOfBit);
 	w.vec( T.patterns); w.vec( T.symbols); w.vec( T.symbolText); w.vec( T.literals); w.vec( T.literalText); w.vec( T.litPats); w.vec( T.approx); w.vec( T.nullable);
-	w.u32( T.scanPasses); w.u32( T.nofShapes); w.vec( T.shapes); w.vec( T.shapePats); w.vec( T.shapeVariants);
+	w.u32( T.scanPasses); w.u32( T.scanWords); w.u32( T.lanesOk ? 1u : 0u); w.u32( T.nofShapes); w.vec( T.shapes); w.vec( T.shapePats); w.vec( T.shapeVariants);
 	w.u32( (uint32_t)m_defs.size());
 	for (size_t i=0; i<m_defs.size(); ++i)
 	{
@@ -1718,8 +1739,8 @@ void LexCompiler::load( const void* blob, size_t size)
 	r.vec( T.byteClass); r.vec( T.classCtx); r.vec( T.cpBlocks); r.vec( T.cpPages); r.vec( T.charMask); r.vec( T.startMask); r.vec( T.acceptMask); r.vec( T.shiftDst); r.vec( T.selfLoop);
 	r.vec( T.exCount); r.vec( T.exSrc); r.vec( T.exDst); r.vec( T.wordPatBegin); r.vec( T.wordPats); r.vec( T.patOfBit);
 	r.vec( T.patterns); r.vec( T.symbols); r.vec( T.symbolText); r.vec( T.literals); r.vec( T.literalText); r.vec( T.litPats); r.vec( T.approx); r.vec( T.nullable);
-	T.scanPasses = r.u32(); T.nofShapes = r.u32(); r.vec( T.shapes); r.vec( T.shapePats); r.vec( T.shapeVariants);
-	if (T.scanPasses > T.nofPasses || T.shapes.empty() || (T.shapes.size() & (T.shapes.size()-1)) || T.shapeVariants.size() > SHAPE_MAXVARIANTS || T.shapePats.empty())
+	T.scanPasses = r.u32(); T.scanWords = r.u32(); T.lanesOk = r.u32() != 0; T.nofShapes = r.u32(); r.vec( T.shapes); r.vec( T.shapePats); r.vec( T.shapeVariants);
+	if (T.scanPasses > T.nofPasses || T.scanWords > T.scanPasses*64 || T.shapes.empty() || (T.shapes.size() & (T.shapes.size()-1)) || T.shapeVariants.size() > SHAPE_MAXVARIANTS || T.shapePats.empty())
 	{
 		throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
 	}

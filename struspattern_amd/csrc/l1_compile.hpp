@@ -51,6 +51,9 @@ struct LexTables
 	std::vector<uint32_t> shapeVariants;	// the distinct tags (kind | offset << 2 | length << 4; PREVWORD: kind) the table holds
 	uint32_t nofShapes;			// expressions taken as shapes
 	uint32_t scanPasses;			// passes [0, scanPasses) are run by the scan kernel; the rest is only walked backwards
+	uint32_t scanWords;			// automaton words the scanned passes use (<= scanPasses * 64)
+	bool lanesOk;				// no scanned expression can stay live across a blank (a position on a cycle that takes ' '): the state at the
+						// start of a piece of text is then known after a short warm-up, which the lane-per-stream scan kernel relies on
 	uint32_t nofLiterals;
 	uint32_t nofPositions;
 	bool reportsOrdered;			// patterns sit in the words in definition order (else the kernel sorts the reports of one end offset)

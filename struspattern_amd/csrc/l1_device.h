@@ -90,6 +90,7 @@ struct L1Params
 	uint32_t* wordQueue;
 	uint32_t* wordCount;
 	uint32_t wordsKernel;		// 1: the post-processing kernel merges the two queues (plain tables); 0: it finds the literals itself
+	uint32_t scanWords;		// automaton words the scanned passes use: up to 4 words in one pass take the lane-per-stream scan kernel
 };
 
 } // namespace

@@ -974,6 +974,185 @@ __device__ void postDocument( LexWave& w, const L1Params& P, const LexTab<LDS>& 
 __device__ __forceinline__ u64 queueBase( const L1Params& P, u64 bytePos, u32 unit) { return ((bytePos * P.queueMul) >> 4) + 64ull*unit; }
 __device__ __forceinline__ void docBounds( const L1Params& P, u32 doc, u64& beg, u64& end);
 template <bool LDS> __device__ __forceinline__ void stageTables( const L1Params& P, LexTab<LDS>& T);
+// ---------------------------------------------------------------- scan, a lane per stream (round 3)
+// When what is left to scan fits a few automaton words (the literals and the word shapes are found by the words kernel: of the
+// 10 001 expressions of the benchmark set five are left, 17 positions), a wave that steps through ONE byte per instruction
+// stream wastes its lanes.  Here the unit is cut into 64 pieces and every lane runs the whole (small) automaton over its own
+// piece: 64 bytes per step of the wave.  The state at the start of a piece comes from the same warm-up proof the chunks of a
+// long document use (F inside S, scanDocument); a lane whose proof fails sends the document to the sequential re-scan.  The
+// reports of a lane go to the lane's part of the unit's queue slice and are moved together at the end (lane order = offset order).
+__shared__ unsigned short laneCc[ 256];		// byte -> class | context << 8
+template <int W>
+__device__ void scanUnitLanes( LexWave& w, const L1Params& P, const LexTab<true>& T, const u32 segBeg, const u32 segEnd)
+{
+	enum {WARM=256};
+	const u32 len = w.docLen;
+	const u32 nofClasses = uni( P.nofClasses), maxEx = uni( P.maxExceptions), nEx = uni( P.exCount[ 0]);
+	const u32 span = segEnd - segBeg;
+	const u32 per = (((span + 63u) >> 6) + 15u) & ~15u;		// bytes per lane, a multiple of 16
+	u32 b0 = segBeg + LANE*per; if (b0 > segEnd) b0 = segEnd;
+	u32 b1 = b0 + per; if (b1 > segEnd) b1 = segEnd;
+	u64 shiftDst[ W], selfLoop[ W];
+#pragma unroll
+	for (int x=0; x<W; ++x) { shiftDst[ x] = T.at( T.oShift + x); selfLoop[ x] = T.at( T.oSelf + x); }
+	auto stepWords = [&]( u64* st, u32 cls, u32 prevctx, bool inject)
+	{
+#pragma unroll
+		for (int x=0; x<W; ++x)
+		{
+			const u64 s0 = st[ x];
+			u64 nxt = ((s0 << 1) & shiftDst[ x]) | (s0 & selfLoop[ x]) | (inject ? T.at( T.oStart + prevctx*64 + x) : 0ull);
+			for (u32 e=0; e<nEx; ++e)
+			{
+				const u64 es = T.at( T.oExSrc + e*64 + x), ed = T.at( T.oExDst + e*64 + x);
+				nxt |= (s0 & es) ? ed : 0ull;
+			}
+			st[ x] = nxt & T.at( cls*64 + x);
+		}
+	};
+	u64 S[ W];
+#pragma unroll
+	for (int x=0; x<W; ++x) S[ x] = 0;
+	u32 prevctx = (u32)CTX_EDGE;
+	bool unproven = false;
+	if (b0 < b1 && b0 > 0)
+	{
+		// warm-up over the bytes before my piece: F from "every position live" without starts, S from nothing with starts
+		const u32 q = b0 > (u32)WARM ? b0 - (u32)WARM : 0u;
+		u64 F[ W];
+#pragma unroll
+		for (int x=0; x<W; ++x) F[ x] = ~0ull;
+		prevctx = q ? ((u32)laneCc[ w.doc[ q-1]] >> 8) : (u32)CTX_EDGE;
+		for (u32 i=q; i<b0; ++i)
+		{
+			const u32 cc = laneCc[ w.doc[ i]];
+			stepWords( F, cc & 0xFFu, prevctx, false);
+			stepWords( S, cc & 0xFFu, prevctx, true);
+			prevctx = cc >> 8;
+		}
+		if (q)
+		{
+			u64 bad = 0;
+#pragma unroll
+			for (int x=0; x<W; ++x) bad |= F[ x] & ~S[ x];
+			unproven = bad != 0;
+		}
+	}
+	if (__ballot( unproven)) { w.err = L1D_CHUNK_UNPROVEN; return; }
+	// my part of the unit's queue slice
+	const u32 regionCap = w.queueCap >> 6;
+	u32* region = w.queue + 4*(u64)(LANE*regionCap);
+	u32 cnt = 0; bool full = false;
+	auto emit = [&]( u32 to, const u64* st, u32 ctx)
+	{
+#pragma unroll
+		for (int x=0; x<W; ++x)
+		{
+			u64 rem = st[ x] & T.at( T.oAccept + ctx*64 + x);
+			while (rem)
+			{
+				const u32 bit = (u32)__builtin_ctzll( rem);
+				const u32 pi = P.patOfBit[ (u32)x*64 + bit];
+				const uint2 mm = *(const uint2*)&P.patterns[ pi].maskLo;
+				const u64 m = ((u64)mm.y << 32) | mm.x;
+				if (cnt < regionCap) { *(uint4*)(region + 4*(u64)cnt) = make_uint4( to, pi, (u32)(rem & m), (u32)((rem & m) >> 32)); ++cnt; } else full = true;
+				rem &= ~m;
+			}
+		}
+	};
+	for (u32 i=b0; i<b1; i+=16)
+	{
+		uint4 v = make_uint4( 0,0,0,0);
+		if (i + 16u <= len) v = ld128u( w.doc + i);
+		else { u32 d[ 4] = {0,0,0,0}; for (u32 k=0; k<16u && i+k<len; ++k) d[ k>>2] |= (u32)w.doc[ i+k] << (8*(k&3u)); v = make_uint4( d[0], d[1], d[2], d[3]); }
+		const u32 vv[ 4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int k=0; k<16; ++k)
+		{
+			if (i + (u32)k < b1)
+			{
+				const u32 cc = laneCc[ (vv[ k>>2] >> (8*(k&3))) & 0xFFu];
+				emit( i + (u32)k, S, cc >> 8);			// matches that end before this byte
+				stepWords( S, cc & 0xFFu, prevctx, true);
+				prevctx = cc >> 8;
+			}
+		}
+	}
+	// matches that end with the document: by the lane that holds its last byte (an empty document has none)
+	if (segEnd == len && b1 == segEnd && b0 < b1) emit( len, S, (u32)CTX_EDGE);
+	if (__ballot( full)) { w.err = L1D_ERR_ARENA; return; }
+	// ---- the lanes' parts moved together (ascending lanes: a part only moves towards the front)
+	const u32 incl = waveScanAdd( cnt);
+	const u32 excl = incl - cnt;
+	__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+	for (u32 l=1; l<64; ++l)
+	{
+		const u32 n = (u32)__builtin_amdgcn_readlane( cnt, l);
+		if (!n) continue;
+		const u32 dst = (u32)__builtin_amdgcn_readlane( excl, l), src = l*regionCap;
+		if (dst == src) continue;
+		for (u32 k=0; k<n; k+=64)
+		{
+			uint4 rec = make_uint4( 0,0,0,0);
+			if (k + LANE < n) rec = *(const uint4*)(w.queue + 4*(u64)(src + k + LANE));
+			__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+			if (k + LANE < n) *(uint4*)(w.queue + 4*(u64)(dst + k + LANE)) = rec;
+			__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+		}
+	}
+	w.nQueue = (u32)__builtin_amdgcn_readlane( incl, 63);
+}
+
+template <int W>
+__device__ void scanDocumentsLanes( const L1Params& P)
+{
+	LexTab<true> T;
+	for (u32 k=threadIdx.x; k<256u; k+=blockDim.x) { const u32 cl = P.byteClass[ k]; laneCc[ k] = (unsigned short)(cl | ((u32)P.classCtx[ cl] << 8)); }
+	stageTables( P, T);			// (the barrier inside covers laneCc too)
+	const u32 chunked = ldu( (const u32*)&P.counters[ L1C_CHUNKED]);
+	LexWave w;
+	w.events = 0; w.nEvents = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
+	const u32 nunits = ldu( (const u32*)&P.counters[ L1C_UNITS]);
+	for (u32 round=0; round<=nunits; ++round)
+	{
+		u32 unit = 0;
+		if (LANE == 0) unit = atomicAdd( (u32*)&P.counters[ L1C_CURSOR], 1u);
+		unit = uni( unit);
+		if (unit >= nunits) break;
+		u32 doc = unit;
+		if (chunked)
+		{
+			u32 lo = 0, hi = P.ndocs;			// last document whose first unit is <= unit
+			while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (ldu( &P.unitStart[ mid]) <= unit) lo = mid; else hi = mid; }
+			doc = lo;
+		}
+		u64 beg, end;
+		docBounds( P, doc, beg, end);
+		w.doc = P.text + beg; w.docLen = (u32)(end - beg);
+		u32 segBeg = 0, segEnd = w.docLen;
+		if (chunked)
+		{
+			segBeg = (unit - ldu( &P.unitStart[ doc])) * P.chunkBytes;
+			segEnd = (w.docLen - segBeg) < P.chunkBytes ? w.docLen : segBeg + P.chunkBytes;
+		}
+		const u64 qb = queueBase( P, beg + segBeg, unit);
+		w.queue = P.reportQueue + 4*qb;
+		w.queueCap = (u32)(queueBase( P, beg + segEnd, unit + 1) - qb);
+		w.nQueue = 0; w.err = 0;
+		scanUnitLanes<W>( w, P, T, segBeg, segEnd);
+		if (LANE == 0)
+		{
+			if (w.err == L1D_CHUNK_UNPROVEN) { P.docSequential[ doc] = 1; P.reportCount[ unit] = 0; }
+			else
+			{
+				P.reportCount[ unit] = w.err ? 0u : w.nQueue;
+				if (w.err) P.docStatus[ doc] = (int32_t)w.err;
+				atomicAdd( (unsigned long long*)&P.counters[ L1C_RAW], (unsigned long long)w.nQueue);
+			}
+		}
+	}
+}
+
 // ---------------------------------------------------------------- words kernel: whole-word literals and word shapes
 // A lane per byte, a wave per scan unit (a document, or a chunk of a long one): everything here is parallel over the text.
 // Where a run of word characters ends, the lane behind it knows the run (start, length, polynomial hash -- one ballot and one
@@ -1784,7 +1963,9 @@ __device__ void scanDocuments( const L1Params& P)
 {
 	// three sets of instances: plain (no classes by code point, no chunked document in the batch), chunks, classes by code point (+ chunks)
 	const u32 chunked = ldu( (const u32*)&P.counters[ L1C_CHUNKED]);
-	if (CP != (P.cpBlocks != 0 || P.nofNullable != 0) || (!CP && CH != (chunked != 0))) return;
+	// (the sequential pass is launched on the _ch instance only and runs whatever the batch looks like: the lane-per-stream
+	//  kernel cuts every unit into pieces, chunked batch or not)
+	if (CP != (P.cpBlocks != 0 || P.nofNullable != 0) || (!CP && !P.sequentialPass && CH != (chunked != 0))) return;
 	LexTab<LDS> T;
 	stageTables( P, T);
 	LexWave w;
@@ -1932,6 +2113,10 @@ SPA_L1_KERNEL( p16, 16, 256)
 SPA_L1_KERNEL( p32, 32, 256)
 extern "C" __global__ __launch_bounds__(64) void spa_l1_approx_kernel( L1Params P) { approxDocuments( P); }
 extern "C" __global__ __launch_bounds__(64) void spa_l1_units_kernel( L1Params P) { countUnits( P); }
+extern "C" __global__ __launch_bounds__(256) void spa_l1_scan_lanes_kernel( L1Params P)
+{
+	if (P.scanWords <= 1) scanDocumentsLanes<1>( P); else if (P.scanWords == 2) scanDocumentsLanes<2>( P); else scanDocumentsLanes<4>( P);
+}
 extern "C" __global__ __launch_bounds__(64*WORD_WAVES) void spa_l1_words_kernel( L1Params P) { if (P.ldsWords) wordsDocuments<true>( P); else wordsDocuments<false>( P); }
 // the post-processing kernel reads the automaton's tables from global memory (start of match only)
 enum {POST_WAVES=4};
@@ -1950,7 +2135,7 @@ extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_
 namespace spa {
 // PS: the parameters of the scan kernel (its table image holds the scanned passes only; nofPasses = 0: nothing to scan);
 // PW: of the words kernel (all passes, in LDS when they fit); P: of the other kernels (all passes, read from global memory)
-hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned wordBlocks, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords)
+hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned laneBlocks, unsigned wordBlocks, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords)
 {
 	if (P.nofApprox)
 	{
@@ -1975,7 +2160,15 @@ hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& 
 #define SPA_L1_LAUNCH( N) do { \
 	if (P.cpBlocks || P.nofNullable) { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, PS); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_cp, S); } \
 	else { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N, PS); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, PS); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, S); } } while (0)
-	switch (PS.nofPasses)
+	// what is left to scan fits four automaton words: a lane per stream (scanUnitLanes); the documents a piece of which could not
+	// be joined go through the sequential pass of the one-pass instance behind it
+	const bool lanes = PS.nofPasses == 1 && PS.scanWords >= 1 && PS.scanWords <= 4 && PS.reportsOrdered && !P.cpBlocks && !P.nofNullable && PS.ldsWords && lds <= 65536;
+	if (lanes)
+	{
+		hipLaunchKernelGGL( spa_l1_scan_lanes_kernel, dim3( laneBlocks), dim3( 256), lds, stream, PS);
+		SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_p1_ch, S);
+	}
+	else switch (PS.nofPasses)
 	{
 		case 0: break;		// (nothing to scan: the caller has cleared the report counts)
 		case 1: SPA_L1_LAUNCH( p1); break;
