@@ -54,8 +54,10 @@ struct sp_lexer_ctx
 	unsigned numCUs;
 	hipEvent_t evStart, evMid, evWords, evStop; bool evValid;
 	hipStream_t lastStream; size_t lastNdocs;
+	hipStream_t own;		// the context's own stream (non-blocking): the host-buffer entry points of different contexts -- one per host thread,
+				// the reference's threading model -- copy and launch side by side instead of queueing on the null stream
 	sp_lexer_ctx() :inst(0),device(0),ldsWords(0),ldsAccept(0),ldsStart(0),ldsShift(0),ldsSelf(0),ldsExSrc(0),ldsExDst(0),blockThreads(256),queueMul(8),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
-		,numCUs(256),evStart(0),evMid(0),evWords(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0)
+		,numCUs(256),evStart(0),evMid(0),evWords(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0),own(0)
 		,imgWords(0),imgAccept(0),imgStart(0),imgShift(0),imgSelf(0),imgExSrc(0),imgExDst(0),wordsKernel(false){}
 };
 
@@ -276,6 +278,7 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 		c->dCounters.alloc( L1C_ALLOC*sizeof(uint64_t));
 		uint32_t npat = (uint32_t)T.patterns.size();
 		c->queueCap = 4096 > 2*npat+256 ? 4096 : 2*npat+256;
+		HIP_CHECK( hipStreamCreateWithFlags( &c->own, hipStreamNonBlocking));
 		HIP_CHECK( hipEventCreate( &c->evStart));
 		HIP_CHECK( hipEventCreate( &c->evMid));
 		HIP_CHECK( hipEventCreate( &c->evWords));
@@ -293,6 +296,7 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 void sp_lexer_ctx_free( sp_lexer_ctx_t* c)
 {
 	if (!c) return;
+	if (c->own) { (void)hipSetDevice( c->device); (void)hipStreamSynchronize( c->own); (void)hipStreamDestroy( c->own); }
 	if (c->evStart) (void)hipEventDestroy( c->evStart);
 	if (c->evMid) (void)hipEventDestroy( c->evMid);
 	if (c->evWords) (void)hipEventDestroy( c->evWords);
@@ -318,6 +322,12 @@ int sp_lexer_ctx_grow_arena( sp_lexer_ctx_t* c)
 } // extern "C"
 
 namespace {
+// a copy on the context's own stream, complete when the call returns
+inline void copySync( sp_lexer_ctx* c, void* dst, const void* src, size_t n, hipMemcpyKind kind)
+{
+	HIP_CHECK( hipMemcpyAsync( dst, src, n, kind, c->own));
+	HIP_CHECK( hipStreamSynchronize( c->own));
+}
 enum {SPA_L1_POST_WAVES_PER_EU_DEFAULT=6};
 void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, size_t ndocs, size_t nbytes, hipStream_t stream)
 {
@@ -458,7 +468,7 @@ int sp_lexer_ctx_batch_counters( sp_lexer_ctx_t* c, uint64_t counters[8])
 		HIP_CHECK( hipSetDevice( c->device));
 		HIP_CHECK( hipStreamSynchronize( c->lastStream));
 		uint64_t all[ L1C_ALLOC];
-		HIP_CHECK( hipMemcpy( all, c->dCounters.ptr, L1C_ALLOC*sizeof(uint64_t), hipMemcpyDeviceToHost));
+		copySync( c, all, c->dCounters.ptr, L1C_ALLOC*sizeof(uint64_t), hipMemcpyDeviceToHost);
 		for (int i=0; i<L1C_COUNT; ++i) counters[ i] = all[ i];
 #ifndef SPA_PROF
 		// (the phase profile of a PROF build lives in 4..7) scan units of the batch and documents scanned again in one piece
@@ -473,7 +483,7 @@ int sp_lexer_ctx_batch_status( sp_lexer_ctx_t* c, int32_t* status, size_t ndocs)
 		HIP_CHECK( hipSetDevice( c->device));
 		HIP_CHECK( hipStreamSynchronize( c->lastStream));
 		if (ndocs > c->lastNdocs) ndocs = c->lastNdocs;
-		if (ndocs) HIP_CHECK( hipMemcpy( status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+		if (ndocs) copySync( c, status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost);
 	});
 }
 
@@ -525,16 +535,16 @@ int sp_lexer_ctx_match_docs( sp_lexer_ctx_t* c, const char* text, const uint64_t
 		}
 		c->dText.reserve( nbytes+16);
 		c->dDocOffsets.reserve( (ndocs+1)*sizeof(uint64_t));
-		if (nbytes) HIP_CHECK( hipMemcpy( c->dText.ptr, text, nbytes, hipMemcpyHostToDevice));
-		HIP_CHECK( hipMemcpy( c->dDocOffsets.ptr, doc_offsets, (ndocs+1)*sizeof(uint64_t), hipMemcpyHostToDevice));
+		if (nbytes) copySync( c, c->dText.ptr, text, nbytes, hipMemcpyHostToDevice);
+		copySync( c, c->dDocOffsets.ptr, doc_offsets, (ndocs+1)*sizeof(uint64_t), hipMemcpyHostToDevice);
 		uint64_t counters[ L1C_COUNT];
 		std::vector<int32_t> st( ndocs+1);
 		for (int attempt=0;; ++attempt)
 		{
-			launchLex( c, c->dText.ptr, c->dDocOffsets.ptr, ndocs, nbytes, 0);
-			HIP_CHECK( hipStreamSynchronize( 0));
-			HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
-			if (ndocs) HIP_CHECK( hipMemcpy( st.data(), c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+			launchLex( c, c->dText.ptr, c->dDocOffsets.ptr, ndocs, nbytes, c->own);
+			HIP_CHECK( hipStreamSynchronize( c->own));
+			copySync( c, counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost);
+			if (ndocs) copySync( c, st.data(), c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost);
 			bool grow = false;
 			if (counters[ L1C_LEXEMS] > c->lexemCapacity) { c->minLexemCapacity = counters[ L1C_LEXEMS] + counters[ L1C_LEXEMS]/8 + 1024; grow = true; }
 			if (counters[ L1C_FAILED])
@@ -546,10 +556,10 @@ int sp_lexer_ctx_match_docs( sp_lexer_ctx_t* c, const char* text, const uint64_t
 			if (!grow || attempt >= 12) break;
 		}
 		std::vector<uint64_t> range( ndocs*2+2);
-		if (ndocs) HIP_CHECK( hipMemcpy( range.data(), c->dDocRange.ptr, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
+		if (ndocs) copySync( c, range.data(), c->dDocRange.ptr, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost);
 		uint64_t nlex = counters[ L1C_LEXEMS] < c->lexemCapacity ? counters[ L1C_LEXEMS] : c->lexemCapacity;
 		std::vector<sp_lexem_t> raw( nlex+1);
-		if (nlex) HIP_CHECK( hipMemcpy( raw.data(), c->dLexems.ptr, nlex*sizeof(sp_lexem_t), hipMemcpyDeviceToHost));
+		if (nlex) copySync( c, raw.data(), c->dLexems.ptr, nlex*sizeof(sp_lexem_t), hipMemcpyDeviceToHost);
 		out->ndocs = ndocs;
 		out->doc_lexem_offsets = (uint64_t*)std::malloc( (ndocs+1)*sizeof(uint64_t));
 		out->doc_status = (int32_t*)std::malloc( (ndocs+1)*sizeof(int32_t));
@@ -590,7 +600,7 @@ int sp_lexer_ctx_batch_fetch_docs( sp_lexer_ctx_t* c, size_t first_doc, size_t n
 		HIP_CHECK( hipStreamSynchronize( c->lastStream));
 		if (first_doc > c->lastNdocs || ndocs > c->lastNdocs - first_doc) throw std::runtime_error( "document range outside the last batch");
 		uint64_t counters[ L1C_COUNT];
-		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
+		copySync( c, counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost);
 		const uint64_t devLexems = counters[ L1C_LEXEMS] < c->lexemCapacity ? counters[ L1C_LEXEMS] : c->lexemCapacity;
 		std::vector<uint64_t> range( ndocs*2+2);
 		out->ndocs = ndocs;
@@ -599,8 +609,8 @@ int sp_lexer_ctx_batch_fetch_docs( sp_lexer_ctx_t* c, size_t first_doc, size_t n
 		if (!out->doc_lexem_offsets || !out->doc_status) throw std::bad_alloc();
 		if (ndocs)
 		{
-			HIP_CHECK( hipMemcpy( range.data(), (const uint64_t*)c->dDocRange.ptr + 2*first_doc, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
-			HIP_CHECK( hipMemcpy( out->doc_status, (const int32_t*)c->dDocStatus.ptr + first_doc, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+			copySync( c, range.data(), (const uint64_t*)c->dDocRange.ptr + 2*first_doc, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost);
+			copySync( c, out->doc_status, (const int32_t*)c->dDocStatus.ptr + first_doc, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost);
 		}
 		uint64_t total = 0;
 		for (size_t di=0; di<ndocs; ++di)
@@ -614,7 +624,7 @@ int sp_lexer_ctx_batch_fetch_docs( sp_lexer_ctx_t* c, size_t first_doc, size_t n
 		for (size_t di=0; di<ndocs; ++di)
 		{
 			out->doc_lexem_offsets[ di] = lp;
-			if (range[ 2*di+1]) HIP_CHECK( hipMemcpy( out->lexems + lp, (const sp_lexem_t*)c->dLexems.ptr + range[ 2*di], range[ 2*di+1]*sizeof(sp_lexem_t), hipMemcpyDeviceToHost));
+			if (range[ 2*di+1]) copySync( c, out->lexems + lp, (const sp_lexem_t*)c->dLexems.ptr + range[ 2*di], range[ 2*di+1]*sizeof(sp_lexem_t), hipMemcpyDeviceToHost);
 			lp += range[ 2*di+1];
 		}
 		out->doc_lexem_offsets[ ndocs] = lp;

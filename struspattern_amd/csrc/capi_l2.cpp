@@ -117,6 +117,7 @@ struct sp_matcher_ctx
 	size_t lastNdocs;
 	hipEvent_t evStart, evStop; bool evValid;
 	hipStream_t lastStream;
+	hipStream_t own;		// the context's own stream (non-blocking): see sp_lexer_ctx
 	bool withItems;
 	unsigned numCUs;
 	// single-document mode
@@ -125,7 +126,7 @@ struct sp_matcher_ctx
 	sp_matcher_stats_t lastStats;
 
 	sp_matcher_ctx() :inst(0),device(0),keymask(0),nofStopWords(0),fast(false),join(false),joinKeymask(0),joinMaxRange(0),joinDelimiter(0),fastWaves(0),fastBlocksPerCU(0),fastVariant(4),fastMaxRules(2048),fastMaxStaged(32768),arenaWaves(0),withFormats(false),resultCapacity(0),itemCapacity(0),minResultCapacity(0),minItemCapacity(0)
-		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),withItems(true),numCUs(256),curHasSeg(false)
+		,lastNdocs(0),evStart(0),evStop(0),evValid(false),lastStream(0),own(0),withItems(true),numCUs(256),curHasSeg(false)
 	{
 		std::memset( &arena, 0, sizeof(arena));
 		std::memset( &fastSpill, 0, sizeof(fastSpill)); std::memset( fastBucketMeta, 0, sizeof(fastBucketMeta));
@@ -137,6 +138,13 @@ struct sp_matcher_ctx
 		arena.maxGStack = 64; arena.maxStaged = 1024; arena.winCap = 128; arena.scratchCap = 256;
 	}
 };
+
+// a copy on the context's own stream, complete when the call returns
+static void copySync( sp_matcher_ctx* c, void* dst, const void* src, size_t n, hipMemcpyKind kind)
+{
+	HIP_CHECK( hipMemcpyAsync( dst, src, n, kind, c->own));
+	HIP_CHECK( hipStreamSynchronize( c->own));
+}
 
 extern "C" {
 
@@ -324,6 +332,7 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 		}
 		c->dCursor.alloc( 256);		// u32: [0] fast cursor, [1] general cursor (list mode), [2] hand-over count, [16..31] hand-over reasons, [32..47] phase profile (u64 x 8)
 		c->dCounters.alloc( SPC_COUNT*sizeof(uint64_t));
+		HIP_CHECK( hipStreamCreateWithFlags( &c->own, hipStreamNonBlocking));
 		HIP_CHECK( hipEventCreate( &c->evStart));
 		HIP_CHECK( hipEventCreate( &c->evStop));
 		return c;
@@ -339,6 +348,7 @@ sp_matcher_ctx_t* sp_matcher_ctx_create( const sp_matcher_t* m, int device)
 void sp_matcher_ctx_free( sp_matcher_ctx_t* c)
 {
 	if (!c) return;
+	if (c->own) { (void)hipSetDevice( c->device); (void)hipStreamSynchronize( c->own); (void)hipStreamDestroy( c->own); }
 	if (c->evStart) (void)hipEventDestroy( c->evStart);
 	if (c->evStop) (void)hipEventDestroy( c->evStop);
 	delete c;
@@ -369,7 +379,7 @@ void copyOutBatch( sp_matcher_ctx* c, size_t firstDoc, size_t ndocs, const uint6
 {
 	const bool whole = (firstDoc == 0 && ndocs == c->lastNdocs);
 	std::vector<uint64_t> range( ndocs*2+2);
-	if (ndocs) HIP_CHECK( hipMemcpy( range.data(), (const uint64_t*)c->dDocRange.ptr + 2*firstDoc, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost));
+	if (ndocs) copySync( c, range.data(), (const uint64_t*)c->dDocRange.ptr + 2*firstDoc, ndocs*2*sizeof(uint64_t), hipMemcpyDeviceToHost);
 	out->ndocs = ndocs;
 	out->doc_stats = (uint64_t*)std::malloc( (ndocs*4+1)*sizeof(uint64_t));
 	out->doc_status = (int32_t*)std::malloc( (ndocs+1)*sizeof(int32_t));
@@ -377,8 +387,8 @@ void copyOutBatch( sp_matcher_ctx* c, size_t firstDoc, size_t ndocs, const uint6
 	if (!out->doc_stats || !out->doc_status || !out->doc_result_offsets) throw std::bad_alloc();
 	if (ndocs)
 	{
-		HIP_CHECK( hipMemcpy( out->doc_stats, (const uint64_t*)c->dDocStats.ptr + 4*firstDoc, ndocs*4*sizeof(uint64_t), hipMemcpyDeviceToHost));
-		HIP_CHECK( hipMemcpy( out->doc_status, (const int32_t*)c->dDocStatus.ptr + firstDoc, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+		copySync( c, out->doc_stats, (const uint64_t*)c->dDocStats.ptr + 4*firstDoc, ndocs*4*sizeof(uint64_t), hipMemcpyDeviceToHost);
+		copySync( c, out->doc_status, (const int32_t*)c->dDocStatus.ptr + firstDoc, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost);
 	}
 	const uint64_t devResults = counters[ SPC_RESULTS] < c->resultCapacity ? counters[ SPC_RESULTS] : c->resultCapacity;
 	const uint64_t devItems = counters[ SPC_ITEMS] < c->itemCapacity ? counters[ SPC_ITEMS] : c->itemCapacity;
@@ -388,13 +398,13 @@ void copyOutBatch( sp_matcher_ctx* c, size_t firstDoc, size_t ndocs, const uint6
 	if (whole)
 	{
 		raw.resize( devResults+1); rawitems.resize( devItems+1);
-		if (devResults) HIP_CHECK( hipMemcpy( raw.data(), c->dResults.ptr, devResults*sizeof(sp_result_t), hipMemcpyDeviceToHost));
-		if (devItems) HIP_CHECK( hipMemcpy( rawitems.data(), c->dItems.ptr, devItems*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
+		if (devResults) copySync( c, raw.data(), c->dResults.ptr, devResults*sizeof(sp_result_t), hipMemcpyDeviceToHost);
+		if (devItems) copySync( c, rawitems.data(), c->dItems.ptr, devItems*sizeof(sp_result_item_t), hipMemcpyDeviceToHost);
 		if (c->withFormats)
 		{
 			rawrf.resize( devResults+1); rawif.resize( 2*devItems+2);
-			if (devResults) HIP_CHECK( hipMemcpy( rawrf.data(), c->dResultFormat.ptr, devResults*sizeof(uint32_t), hipMemcpyDeviceToHost));
-			if (devItems) HIP_CHECK( hipMemcpy( rawif.data(), c->dItemFormat.ptr, 2*devItems*sizeof(uint32_t), hipMemcpyDeviceToHost));
+			if (devResults) copySync( c, rawrf.data(), c->dResultFormat.ptr, devResults*sizeof(uint32_t), hipMemcpyDeviceToHost);
+			if (devItems) copySync( c, rawif.data(), c->dItemFormat.ptr, 2*devItems*sizeof(uint32_t), hipMemcpyDeviceToHost);
 		}
 	}
 	else
@@ -409,8 +419,8 @@ void copyOutBatch( sp_matcher_ctx* c, size_t firstDoc, size_t ndocs, const uint6
 		{
 			const uint64_t b = range[ 2*di], n = range[ 2*di+1];
 			if (out->doc_status[ di] != 0 || b + n > devResults) { range[ 2*di+1] = 0; continue; }
-			if (n) HIP_CHECK( hipMemcpy( raw.data() + rp0, (const sp_result_t*)c->dResults.ptr + b, n*sizeof(sp_result_t), hipMemcpyDeviceToHost));
-			if (n && c->withFormats) HIP_CHECK( hipMemcpy( rawrf.data() + rp0, (const uint32_t*)c->dResultFormat.ptr + b, n*sizeof(uint32_t), hipMemcpyDeviceToHost));
+			if (n) copySync( c, raw.data() + rp0, (const sp_result_t*)c->dResults.ptr + b, n*sizeof(sp_result_t), hipMemcpyDeviceToHost);
+			if (n && c->withFormats) copySync( c, rawrf.data() + rp0, (const uint32_t*)c->dResultFormat.ptr + b, n*sizeof(uint32_t), hipMemcpyDeviceToHost);
 			range[ 2*di] = rp0; rp0 += n;
 		}
 		uint64_t nitems = 0;
@@ -426,8 +436,8 @@ void copyOutBatch( sp_matcher_ctx* c, size_t firstDoc, size_t ndocs, const uint6
 			for (uint64_t ri=0; ri<n; ++ri) if (raw[ b+ri].item_count) { if (!cnt) first = raw[ b+ri].item_begin; cnt += raw[ b+ri].item_count; }
 			if (!cnt) continue;
 			if (first + cnt > devItems) throw std::runtime_error( "item block of a document lies outside the device buffer");
-			HIP_CHECK( hipMemcpy( rawitems.data() + ip0, (const sp_result_item_t*)c->dItems.ptr + first, cnt*sizeof(sp_result_item_t), hipMemcpyDeviceToHost));
-			if (c->withFormats) HIP_CHECK( hipMemcpy( rawif.data() + 2*ip0, (const uint32_t*)c->dItemFormat.ptr + 2*first, 2*cnt*sizeof(uint32_t), hipMemcpyDeviceToHost));
+			copySync( c, rawitems.data() + ip0, (const sp_result_item_t*)c->dItems.ptr + first, cnt*sizeof(sp_result_item_t), hipMemcpyDeviceToHost);
+			if (c->withFormats) copySync( c, rawif.data() + 2*ip0, (const uint32_t*)c->dItemFormat.ptr + 2*first, 2*cnt*sizeof(uint32_t), hipMemcpyDeviceToHost);
 			for (uint64_t ri=0; ri<n; ++ri) if (raw[ b+ri].item_count) raw[ b+ri].item_begin = (uint32_t)(raw[ b+ri].item_begin - first + ip0);
 			ip0 += cnt;
 		}
@@ -506,7 +516,7 @@ int sp_matcher_ctx_batch_fetch( sp_matcher_ctx_t* c, sp_match_batch_t* out)
 		HIP_CHECK( hipStreamSynchronize( c->lastStream));
 		size_t ndocs = c->lastNdocs;
 		uint64_t counters[ SPC_COUNT];
-		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
+		copySync( c, counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost);
 		copyOutBatch( c, 0, ndocs, counters, out);
 	});
 }
@@ -520,7 +530,7 @@ int sp_matcher_ctx_batch_fetch_docs( sp_matcher_ctx_t* c, size_t first_doc, size
 		HIP_CHECK( hipStreamSynchronize( c->lastStream));
 		if (first_doc > c->lastNdocs || ndocs > c->lastNdocs - first_doc) throw std::runtime_error( "document range outside the last batch");
 		uint64_t counters[ SPC_COUNT];
-		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
+		copySync( c, counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost);
 		copyOutBatch( c, first_doc, ndocs, counters, out);
 	});
 }
@@ -531,7 +541,7 @@ int sp_matcher_ctx_batch_status( sp_matcher_ctx_t* c, int32_t* status, size_t nd
 		HIP_CHECK( hipSetDevice( c->device));
 		HIP_CHECK( hipStreamSynchronize( c->lastStream));
 		if (ndocs > c->lastNdocs) ndocs = c->lastNdocs;
-		if (ndocs) HIP_CHECK( hipMemcpy( status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+		if (ndocs) copySync( c, status, c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost);
 	});
 }
 
@@ -802,14 +812,14 @@ int sp_matcher_ctx_batch_counters( sp_matcher_ctx_t* c, uint64_t counters[8])
 	return guardedCall( c->lasterror, SP_ERR_DEVICE, [&]{
 		HIP_CHECK( hipSetDevice( c->device));
 		HIP_CHECK( hipStreamSynchronize( c->lastStream));
-		HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, SPC_COUNT*sizeof(uint64_t), hipMemcpyDeviceToHost));
+		copySync( c, counters, c->dCounters.ptr, SPC_COUNT*sizeof(uint64_t), hipMemcpyDeviceToHost);
 		if (c->fast && getenv( "SPA_L2_VERBOSE"))
 		{
 			uint32_t diag[ 16];
-			HIP_CHECK( hipMemcpy( diag, (const uint32_t*)c->dCursor.ptr + 16, sizeof(diag), hipMemcpyDeviceToHost));
+			copySync( c, diag, (const uint32_t*)c->dCursor.ptr + 16, sizeof(diag), hipMemcpyDeviceToHost);
 #ifdef SPA_PROF
 			uint64_t prof[ 12];
-			HIP_CHECK( hipMemcpy( prof, (const uint32_t*)c->dCursor.ptr + 32, sizeof(prof), hipMemcpyDeviceToHost));
+			copySync( c, prof, (const uint32_t*)c->dCursor.ptr + 32, sizeof(prof), hipMemcpyDeviceToHost);
 			double tot = 0; for (int i=0; i<6; ++i) tot += (double)prof[ i];
 			
 			fprintf( stderr, "[spa] fast tier phases (share of wave cycles): scan+fire %.1f%% install %.1f%% deactivate %.1f%% expiry %.1f%% results %.1f%% fetch %.1f%% | inside deactivation: loads %.1f%% ranks+queue %.1f%% replay %.1f%% (%.2f replay steps, %.2f batches, %.2f rules per event); %.0f cycles per event\n",
@@ -846,22 +856,22 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 		size_t nlex = ndocs ? (size_t)doc_offsets[ ndocs] : 0;
 		c->dLexems.reserve( (nlex+1)*sizeof(sp_lexem_t));
 		c->dDocOffsets.reserve( (ndocs+1)*sizeof(uint64_t));
-		if (nlex) HIP_CHECK( hipMemcpy( c->dLexems.ptr, lexems, nlex*sizeof(sp_lexem_t), hipMemcpyHostToDevice));
-		HIP_CHECK( hipMemcpy( c->dDocOffsets.ptr, doc_offsets, (ndocs+1)*sizeof(uint64_t), hipMemcpyHostToDevice));
+		if (nlex) copySync( c, c->dLexems.ptr, lexems, nlex*sizeof(sp_lexem_t), hipMemcpyHostToDevice);
+		copySync( c, c->dDocOffsets.ptr, doc_offsets, (ndocs+1)*sizeof(uint64_t), hipMemcpyHostToDevice);
 		const void* dseg = 0;
 		if (origseg)
 		{
 			c->dOrigseg.reserve( (nlex+1)*sizeof(uint32_t));
-			if (nlex) HIP_CHECK( hipMemcpy( c->dOrigseg.ptr, origseg, nlex*sizeof(uint32_t), hipMemcpyHostToDevice));
+			if (nlex) copySync( c, c->dOrigseg.ptr, origseg, nlex*sizeof(uint32_t), hipMemcpyHostToDevice);
 			dseg = c->dOrigseg.ptr;
 		}
 		uint64_t counters[ SPC_COUNT];
 		std::vector<uint32_t> again;		// documents whose working set exceeded the per-wave arena: only they run again
 		for (int attempt=0;; ++attempt)
 		{
-			launchBatch( c, c->dLexems.ptr, dseg, c->dDocOffsets.ptr, ndocs, nlex, 0, 0, again.empty() ? 0 : &again);
-			HIP_CHECK( hipStreamSynchronize( 0));
-			HIP_CHECK( hipMemcpy( counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost));
+			launchBatch( c, c->dLexems.ptr, dseg, c->dDocOffsets.ptr, ndocs, nlex, c->own, 0, again.empty() ? 0 : &again);
+			HIP_CHECK( hipStreamSynchronize( c->own));
+			copySync( c, counters, c->dCounters.ptr, sizeof(counters), hipMemcpyDeviceToHost);
 			// the output counters keep counting past the capacity: if the buffers were too small,
 			// grow them to what this batch needs and run it again (the kernel is deterministic)
 			bool grow = false;
@@ -873,7 +883,7 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 				// documents whose working set exceeded the per-wave arena: double the arena and run THEM again
 				// (the whole batch only when the output buffers have to be reallocated as well)
 				std::vector<int32_t> st( ndocs);
-				HIP_CHECK( hipMemcpy( st.data(), c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost));
+				copySync( c, st.data(), c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost);
 				std::vector<uint32_t> arenaDocs;
 				for (size_t di=0; di<ndocs; ++di) if (st[ di] == SPD_ERR_ARENA) arenaDocs.push_back( (uint32_t)di);
 				if (!arenaDocs.empty() && sp_matcher_ctx_grow_arena( c) == SP_OK)

@@ -12,6 +12,8 @@
 #include "strus/patternMatcherInterface.hpp"
 #include "strus/lib/pattern_resultformat.hpp"
 #include "../../include/strus_pattern_amd.h"
+#include <atomic>
+#include <cstdlib>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -20,6 +22,22 @@
 using namespace strus;
 
 namespace {
+
+// Which GPU a new context runs on.  The reference's threading model is one Context per thread over a shared Instance
+// (tests/randomTokenPatternMatch/src/testRandomTokenPatternMatch.cpp:325-345); contexts are independent here too -- each has its own
+// stream and buffers --, so they are dealt round-robin over the visible devices.  SPA_DEVICE=<n> pins every context to one device.
+int nextDevice()
+{
+	static std::atomic<unsigned> counter( 0);
+	const int ndev = sp_device_count();
+	if (ndev <= 1) return 0;
+	if (const char* e = std::getenv( "SPA_DEVICE"))
+	{
+		const int d = std::atoi( e);
+		if (d >= 0 && d < ndev) return d;
+	}
+	return (int)(counter.fetch_add( 1) % (unsigned)ndev);
+}
 
 ErrorCode codeOf( int rc)
 {
@@ -88,7 +106,7 @@ public:
 	}
 	virtual PatternLexerContextInterface* createContext() const
 	{
-		sp_lexer_ctx_t* c = sp_lexer_ctx_create( m_h, 0/*device*/);
+		sp_lexer_ctx_t* c = sp_lexer_ctx_create( m_h, nextDevice());
 		if (!c) { m_errorhnd->report( ErrorCodeRuntimeError, "failed to create term match context: %s", sp_lexer_last_error( m_h)); return 0; }
 		try { return new LexerContext( c, m_errorhnd); }
 		catch (const std::bad_alloc&) { sp_lexer_ctx_free( c); m_errorhnd->report( ErrorCodeOutOfMem, "memory allocation error in %s", "strus pattern"); return 0; }
@@ -274,7 +292,7 @@ public:
 	}
 	virtual PatternMatcherContextInterface* createContext() const
 	{
-		sp_matcher_ctx_t* c = sp_matcher_ctx_create( m_h, 0/*device*/);
+		sp_matcher_ctx_t* c = sp_matcher_ctx_create( m_h, nextDevice());
 		if (!c) { m_errorhnd->report( ErrorCodeRuntimeError, "failed to create pattern match context: %s", sp_matcher_last_error( m_h)); return 0; }
 		try { return new MatcherContext( c, m_h, &m_resultFormatHandles, m_errorhnd); }
 		catch (const std::bad_alloc&) { sp_matcher_ctx_free( c); m_errorhnd->report( ErrorCodeOutOfMem, "memory allocation error in %s", "strus pattern"); return 0; }

@@ -11,7 +11,11 @@
 #include "strus/patternMatcherInterface.hpp"
 #include "strus/analyzerModule.hpp"
 #include "strus/lib/pattern_resultformat.hpp"
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
+#include <cstdint>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -208,6 +212,114 @@ static void testResultFormat( strus::PatternMatcherInterface* pt, ErrorBuffer& e
 	std::cerr << "resultFormat OK (" << results.size() << " results)" << std::endl;
 }
 
+// ---- the plugin path under the reference's threading model: one Context per thread over a shared Instance
+// (tests/randomTokenPatternMatch/src/testRandomTokenPatternMatch.cpp:325-345): N threads, each with its own lexer context and
+// matcher context, every thread runs every document (match -> putInput per lexem -> fetchResults) `repeat` times.
+// Fixture (tab separated, written by tests/test_host_shim.py): OPTION name | LEXEM id expr resultIndex level haspos |
+// XRULE name op range delim nterms t1 v1 .. | DOC hex(text).  Output: one line per document "DOCSUM index nresults fnv1a64" (what thread 0
+// got; the other threads must get the same) and "THREADS n docs d bytes b seconds s".
+static uint64_t fnv( uint64_t h, const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i=0; i<n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; }
+static uint64_t fnvU( uint64_t h, uint64_t v) { return fnv( h, &v, sizeof(v)); }
+static uint64_t fnvS( uint64_t h, const char* s) { return fnv( fnv( h, s, strlen( s)), "\0", 1); }
+
+static int runThreads( int nthreads, const char* fixture, int repeat)
+{
+	ErrorBuffer err;
+	std::unique_ptr<strus::PatternMatcherInterface> pt( strus::createPatternMatcher_std( &err));
+	std::unique_ptr<strus::PatternLexerInterface> pl( strus::createPatternLexer_std( &err));
+	std::unique_ptr<strus::PatternLexerInstanceInterface> li( pl->createInstance());
+	std::unique_ptr<strus::PatternMatcherInstanceInterface> mi( pt->createInstance());
+	std::vector<std::string> docs;
+	std::vector<std::string> lines = readLines( fixture);
+	for (size_t i=0; i<lines.size(); ++i)
+	{
+		std::vector<std::string> f = split( lines[i]);
+		if (f[0] == "OPTION") li->defineOption( f[1], 0);
+		else if (f[0] == "LEXEM") li->defineLexem( atoi( f[1].c_str()), f[2], atoi( f[3].c_str()), atoi( f[4].c_str()), atoi( f[5].c_str()) ? strus::analyzer::BindContent : strus::analyzer::BindPredecessor);
+		else if (f[0] == "XRULE")
+		{
+			strus::PatternMatcherInstanceInterface::JoinOperation op = strus::PatternMatcherInstanceInterface::OpSequence;
+			if (f[2] == "within") op = strus::PatternMatcherInstanceInterface::OpWithin;
+			else if (f[2] == "sequence_struct") op = strus::PatternMatcherInstanceInterface::OpSequenceStruct;
+			else if (f[2] == "within_struct") op = strus::PatternMatcherInstanceInterface::OpWithinStruct;
+			else if (f[2] == "any") op = strus::PatternMatcherInstanceInterface::OpAny;
+			const unsigned delim = (unsigned)strtoul( f[4].c_str(), 0, 10);
+			const int nterms = atoi( f[5].c_str());
+			int argc = nterms;
+			if (delim) { mi->pushTerm( delim); ++argc; }
+			for (int t=0; t<nterms; ++t) { mi->pushTerm( (unsigned)strtoul( f[6+2*t].c_str(), 0, 10)); mi->attachVariable( f[7+2*t]); }
+			mi->pushExpression( op, argc, atoi( f[3].c_str()), 0);
+			mi->definePattern( f[1], "", true);
+		}
+		else if (f[0] == "DOC")
+		{
+			std::string text;
+			for (size_t k=0; k+1<f[1].size(); k+=2) text.push_back( (char)strtoul( f[1].substr( k, 2).c_str(), 0, 16));
+			docs.push_back( text);
+		}
+	}
+	if (!li->compile() || !mi->compile() || err.hasError()) throw std::runtime_error( std::string("threads: compile failed: ") + err.fetchError());
+	std::vector<std::vector<uint64_t> > sums( nthreads, std::vector<uint64_t>( 2*docs.size(), 0));
+	std::vector<std::string> failures( nthreads);
+	std::atomic<int> ready( 0);
+	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	auto work = [&]( int ti)
+	{
+		try
+		{
+			ErrorBuffer terr;		// (one error buffer slot per thread in the reference; a private buffer here)
+			std::unique_ptr<strus::PatternLexerContextInterface> lc( li->createContext());
+			std::unique_ptr<strus::PatternMatcherContextInterface> mc( mi->createContext());
+			if (!lc.get() || !mc.get()) throw std::runtime_error( "createContext failed");
+			for (int rep=-1; rep<repeat; ++rep)
+			{
+				if (rep == 0)
+				{
+					// the first pass (rep -1) sized every context's buffers; the timed passes start together
+					ready.fetch_add( 1);
+					while (ready.load() < nthreads) std::this_thread::yield();
+					if (ti == 0) t0 = std::chrono::steady_clock::now();
+				}
+				for (size_t di=0; di<docs.size(); ++di)
+				{
+					std::vector<strus::analyzer::PatternLexem> lex = lc->match( docs[ di].c_str(), docs[ di].size());
+					mc->reset();
+					for (size_t k=0; k<lex.size(); ++k) mc->putInput( lex[ k]);
+					std::vector<strus::analyzer::PatternMatcherResult> res = mc->fetchResults();
+					uint64_t h = 1469598103934665603ull;
+					for (size_t r=0; r<res.size(); ++r)
+					{
+						h = fnvS( h, res[ r].name()); h = fnvU( h, res[ r].ordpos()); h = fnvU( h, res[ r].ordend());
+						h = fnvU( h, res[ r].origpos().ofs()); h = fnvU( h, res[ r].origend().ofs());
+						for (size_t q=0; q<res[ r].items().size(); ++q)
+						{
+							const strus::analyzer::PatternMatcherResultItem& it = res[ r].items()[ q];
+							h = fnvS( h, it.name()); h = fnvU( h, it.ordpos()); h = fnvU( h, it.ordend()); h = fnvU( h, it.origpos().ofs()); h = fnvU( h, it.origend().ofs());
+						}
+					}
+					sums[ ti][ 2*di] = res.size(); sums[ ti][ 2*di+1] = h;
+				}
+			}
+		}
+		catch (const std::exception& e) { failures[ ti] = e.what(); }
+	};
+	std::vector<std::thread> th;
+	for (int ti=0; ti<nthreads; ++ti) th.push_back( std::thread( work, ti));
+	for (int ti=0; ti<nthreads; ++ti) th[ ti].join();
+	const double secs = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0).count();
+	if (err.hasError()) throw std::runtime_error( std::string("threads: ") + err.fetchError());
+	for (int ti=0; ti<nthreads; ++ti)
+	{
+		if (!failures[ ti].empty()) throw std::runtime_error( "threads: thread failed: " + failures[ ti]);
+		if (sums[ ti] != sums[ 0]) throw std::runtime_error( "threads: the threads disagree");
+	}
+	size_t bytes = 0;
+	for (size_t di=0; di<docs.size(); ++di) bytes += docs[ di].size();
+	for (size_t di=0; di<docs.size(); ++di) std::cout << "DOCSUM\t" << di << "\t" << sums[ 0][ 2*di] << "\t" << sums[ 0][ 2*di+1] << std::endl;
+	std::cout << "THREADS\t" << nthreads << "\tdocs\t" << (docs.size()*(size_t)repeat*(size_t)nthreads) << "\tbytes\t" << (bytes*(size_t)repeat*(size_t)nthreads) << "\tseconds\t" << secs << std::endl;
+	return 0;
+}
+
 int main( int argc, const char** argv)
 {
 	try
@@ -225,7 +337,8 @@ int main( int argc, const char** argv)
 			for (size_t i=0; i<mo.size(); ++i) std::cout << "matcher\t" << mo[i] << std::endl;
 			return 0;
 		}
-		if (argc < 4) { std::cerr << "usage: testStrusInterface <simple fixture> <regex fixture> <module .so> | --options" << std::endl; return 2; }
+		if (argc == 5 && !strcmp( argv[1], "--threads")) return runThreads( atoi( argv[2]), argv[3], atoi( argv[4]));
+		if (argc < 4) { std::cerr << "usage: testStrusInterface <simple fixture> <regex fixture> <module .so> | --options | --threads <n> <fixture> <repeat>" << std::endl; return 2; }
 		// 1. through the exported factory functions (libstrus_pattern)
 		std::unique_ptr<strus::PatternMatcherInterface> pt( strus::createPatternMatcher_std( &err));
 		std::unique_ptr<strus::PatternLexerInterface> pl( strus::createPatternLexer_std( &err));
