@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--features", type=int, default=10000, help="distinct tokens (workload l2)")
     ap.add_argument("--op", default="", help="fix the rule operator (default: the 5-way Zipf mix)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target size of the bounded CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -225,6 +225,9 @@ def main():
         out = report(args, wl, world, pats, head, m, tot, dt, secondary, nbytes, h2d_ms)
         if not args.no_cpu_baseline:
             base, parity = cpu_baseline(args, wl, pats, rules, text, head, lex, lctx, mctx)
+            ref = base.get("l1_reference") or {}
+            if ref.get("GBps_allcores_extrapolated") and m["l1_ms"] > 0:
+                base["gpu_vs_reference_cpu"] = (nbytes / (m["l1_ms"] * 1e-3) / 1e9) / ref["GBps_allcores_extrapolated"]
             out["cpu_baseline"] = base
             out["parity_sample"] = parity
         if world == 1 and mctx is not None and not args.no_cpu_baseline:
@@ -376,6 +379,56 @@ def canonical_order_mode(wl, rules, head, d_lex, local_rank, m, nbytes):
         return {"available": False, "error": str(e)[:200]}
 
 
+def hyperscan_reference(pats, sample_text, sample_offs, ncores):
+    """The reference's own CPU lexer stage is Intel Hyperscan (src/patternLexer.cpp:875-879).  Probe for libhs; when it is there, time
+    hs_scan over the same sample with the reference's compile flags (src/patternLexer.cpp:391-405: the options | HS_FLAG_SOM_LEFTMOST |
+    HS_FLAG_UTF8, mode HS_MODE_BLOCK, :1078-1086) -- one thread, a callback that only counts, i.e. an upper bound of what the reference's
+    handler would let through.  Returns the `l1_reference` object of cpu_baseline."""
+    import ctypes
+    import ctypes.util
+    name = ctypes.util.find_library("hs")
+    if not name:
+        for cand in ("libhs.so.5", "libhs.so.4", "libhs.so"):
+            try:
+                ctypes.CDLL(cand)
+                name = cand
+                break
+            except OSError:
+                pass
+    if not name:
+        return {"probed": True, "found": False, "note": "libhs (Intel Hyperscan) is not installed on this box: the reference's lexer stage cannot be timed here"}
+    try:
+        hs = ctypes.CDLL(name)
+        HS_FLAG_DOTALL, HS_FLAG_UTF8, HS_FLAG_SOM_LEFTMOST, HS_MODE_BLOCK = 2, 32, 256, 1
+        n = len(pats)
+        exprs = (ctypes.c_char_p * n)(*[e.encode() for _, e, _, _, _ in pats])
+        flags = (ctypes.c_uint * n)(*([HS_FLAG_DOTALL | HS_FLAG_UTF8 | HS_FLAG_SOM_LEFTMOST] * n))
+        ids = (ctypes.c_uint * n)(*range(1, n + 1))
+        db, err, scratch = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        t0 = time.perf_counter()
+        rc = hs.hs_compile_multi(exprs, flags, ids, n, HS_MODE_BLOCK, None, ctypes.byref(db), ctypes.byref(err))
+        tc = time.perf_counter() - t0
+        if rc != 0:
+            return {"probed": True, "found": True, "library": name, "error": "hs_compile_multi returned %d" % rc}
+        hs.hs_alloc_scratch(db, ctypes.byref(scratch))
+        count = [0]
+        CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_uint, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_void_p)
+
+        def on_match(i, frm, to, fl, ctx):
+            count[0] += 1
+            return 0
+        cb = CB(on_match)
+        t0 = time.perf_counter()
+        for d in range(len(sample_offs) - 1):
+            doc = sample_text[int(sample_offs[d]):int(sample_offs[d + 1])]
+            hs.hs_scan(db, doc, len(doc), 0, scratch, cb, None)
+        dt = time.perf_counter() - t0
+        return {"probed": True, "found": True, "library": name, "GBps_1thread": len(sample_text) / dt / 1e9, "raw_matches": count[0], "compile_s": tc,
+                "note": "hs_scan with the reference's flags on the oracle sample, 1 thread, counting callback through ctypes (callback overhead included)"}
+    except Exception as e:          # a library of another ABI must not take the bench line down
+        return {"probed": True, "found": True, "library": name, "error": str(e)[:200]}
+
+
 def first_difference(gl, gr, rl, rr):
     """compares lexems / results / items / statistics of the GPU sample with the oracle's; None when equal"""
     if not (np.array_equal(gl.doc_offsets, rl[1]) and np.array_equal(gl.lexems, rl[0])):
@@ -438,9 +491,14 @@ def cpu_baseline(args, wl, pats, rules, text, head, lex, lctx, mctx):
     t0 = time.perf_counter()
     lexems, loffs = ol.matchDocs(sub_text, offs[:nd + 1], nthreads=nthreads)
     t1 = time.perf_counter()
+    ref = hyperscan_reference(pats, sub_text, offs[:nd + 1], ncores)
     base = {"value": len(sub_text) / (t1 - t0) / 1e9, "unit": "GB/s", "cores": nthreads, "kind": "port",
             "l1": {"GBps": len(sub_text) / (t1 - t0) / 1e9, "cores": nthreads, "kind": "port",
-                   "note": "oracle lexer: scalar NFA restatement, NOT Hyperscan (reference Hyperscan timing unavailable: library absent)"},
+                   "note": "oracle lexer: scalar NFA restatement of Hyperscan's report semantics, NOT Hyperscan -- no yardstick for the GPU lexer"},
+            "l1_reference": ref,
+            "gpu_vs_reference_cpu": None,
+            "gpu_vs_reference_cpu_note": ("GPU lexer GB/s / (libhs GB/s per thread x %d host cores) is in cpu_baseline.l1_reference" % ncores) if ref.get("GBps_1thread")
+                                         else "null: the reference's CPU lexer (Hyperscan) could not be timed on this box (%s)" % (ref.get("note") or ref.get("error") or "probe failed"),
             "sample": "first %d documents of rank 0's shard (%d bytes), oracle lexer %d threads %.1f s" % (nd, len(sub_text), nthreads, t1 - t0)}
     gl = lctx.batchFetch(0, nd)
     gr = rr = None
@@ -466,6 +524,8 @@ def cpu_baseline(args, wl, pats, rules, text, head, lex, lctx, mctx):
         base["l2"] = {"events_per_s_1thread": len(l5) / (t4 - t3), "events_per_s_allcores": len(l5) / (t5 - t4),
                       "matches_per_s_1thread": len(r1.results) / (t4 - t3), "cores": ncores, "kind": "port",
                       "sample": "%d documents (%d events): lexer output of the GPU for rank 0's first documents, oracle/l2_oracle.cpp" % (n2, len(l5))}
+    if ref.get("GBps_1thread"):
+        ref["GBps_allcores_extrapolated"] = ref["GBps_1thread"] * ncores
     diff = first_difference(gl, gr, (lexems, loffs), rr)
     return base, {"docs": nd, "ok": diff is None, "mismatch": diff,
                   "compared": "lexems, results in firing order, items, statistics of the last timed launch vs the oracle"}

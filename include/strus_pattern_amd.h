@@ -102,6 +102,8 @@ const char* sp_version(void);
 /* number of usable HIP devices (0 when no GPU is visible); never initialises more than the runtime */
 int sp_device_count(void);
 void sp_free(void* p);
+/* test hook (tests only): device allocations of at least `bytes` fail like an out-of-memory hipMalloc; 0 switches it off */
+void sp_test_fail_alloc_above(uint64_t bytes);
 
 /* ==== level 2: token pattern matcher ==== */
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "sp_version": (c_cp, []),
     "sp_device_count": (ctypes.c_int, []),
     "sp_free": (None, [c_vp]),
+    "sp_test_fail_alloc_above": (None, [c_u64]),
     "sp_matcher_create": (c_vp, []),
     "sp_matcher_free": (None, [c_vp]),
     "sp_matcher_last_error": (c_cp, [c_vp]),

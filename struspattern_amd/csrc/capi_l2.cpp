@@ -159,6 +159,9 @@ int sp_device_count(void)
 
 void sp_free( void* p) { std::free( p); }
 
+// test hook: device allocations of at least `bytes` fail like an out-of-memory hipMalloc (0 = off)
+void sp_test_fail_alloc_above( uint64_t bytes) { allocFailureThreshold().store( bytes, std::memory_order_relaxed); }
+
 // ------------------------------------------------------------------ instance
 sp_matcher_t* sp_matcher_create(void)
 {
@@ -893,6 +896,18 @@ int sp_matcher_ctx_match_docs( sp_matcher_ctx_t* c, const sp_lexem_t* lexems, co
 				}
 			}
 			if (!grow || attempt >= 12) break;
+		}
+		{
+			// a partial rerun counts failures among the documents it ran again only: the batch's count is what the statuses say
+			std::vector<int32_t> st( ndocs+1);
+			if (ndocs) copySync( c, st.data(), c->dDocStatus.ptr, ndocs*sizeof(int32_t), hipMemcpyDeviceToHost);
+			uint64_t failed = 0;
+			for (size_t di=0; di<ndocs; ++di) if (st[ di] != 0) ++failed;
+			if (failed != counters[ SPC_FAILED])
+			{
+				counters[ SPC_FAILED] = failed;
+				copySync( c, (uint64_t*)c->dCounters.ptr + SPC_FAILED, &failed, sizeof(failed), hipMemcpyHostToDevice);
+			}
 		}
 		copyOutBatch( c, 0, ndocs, counters, out);
 		if (counters[ SPC_FAILED])

@@ -6,6 +6,7 @@
 #include <string>
 #include <cstddef>
 #include <cstdlib>
+#include <atomic>
 
 namespace spa {
 
@@ -16,6 +17,8 @@ struct HipError :public std::runtime_error
 
 #define HIP_CHECK( EXPR) do { hipError_t e_ = (EXPR); if (e_ != hipSuccess) \
 	throw spa::HipError( std::string("HIP error: ") + hipGetErrorString( e_) + " in " #EXPR); } while (0)
+
+inline std::atomic<unsigned long long>& allocFailureThreshold() { static std::atomic<unsigned long long> v( 0); return v; }
 
 struct DeviceBuffer
 {
@@ -29,8 +32,10 @@ struct DeviceBuffer
 	{
 		release();
 		if (n == 0) n = 16;
-		// test hook (tests/test_l2_gpu.py): allocations of at least this many bytes fail like an out-of-memory hipMalloc
-		if (const char* lim = std::getenv( "SPA_TEST_FAIL_ALLOC_ABOVE")) { if (n >= std::strtoull( lim, 0, 10)) throw HipError( "HIP error: out of memory (injected by SPA_TEST_FAIL_ALLOC_ABOVE) in hipMalloc"); }
+		// test hook (sp_test_fail_alloc_above, tests/test_l2_gpu.py): allocations of at least this many bytes fail like an
+		// out-of-memory hipMalloc; 0 = off.  Set through the C-ABI only: nothing on the allocation path reads the environment.
+		const unsigned long long failAbove = allocFailureThreshold().load( std::memory_order_relaxed);
+		if (failAbove && n >= failAbove) throw HipError( "HIP error: out of memory (injected by sp_test_fail_alloc_above) in hipMalloc");
 		HIP_CHECK( hipMalloc( &ptr, n));
 		bytes = n;
 	}

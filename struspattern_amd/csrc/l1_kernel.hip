@@ -2015,7 +2015,8 @@ __device__ void scanDocuments( const L1Params& P)
 			{
 				P.reportCount[ u0] = w.err ? 0u : w.nQueue;
 				for (u32 u=u0+1; u<u1; ++u) P.reportCount[ u] = 0;
-				if (w.err) P.docStatus[ doc] = (int32_t)w.err;
+				// (the sequential pass decides alone about its document: a chunk of the first pass may have left an error behind)
+				if (w.err || P.sequentialPass) P.docStatus[ doc] = (int32_t)w.err;
 				atomicAdd( (unsigned long long*)&P.counters[ L1C_RAW], (unsigned long long)w.nQueue);
 			}
 		}

@@ -173,11 +173,20 @@ def test_long_documents_are_scanned_in_chunks(monkeypatch):
     offs = np.zeros(len(docs2) + 1, np.uint64)
     offs[1:] = np.cumsum([len(d) for d in docs2])
     ctx2 = lx2.createContext()
+    # by default a table with such an expression is not scanned in chunks at all (the chunked pass would be thrown away) ...
+    got = ctx2.matchDocs(b"".join(docs2), offs)
+    c = ctx2.batchCounters()
+    assert c["scan_units"] == len(docs2) and c["rescanned_docs"] == 0
+    for di, d in enumerate(docs2):
+        assert got.doc(di).tolist() == o2.match(d).tolist(), di
+    # ... with chunks forced, the proof fails and the document goes through the sequential pass
+    monkeypatch.setenv("SPA_L1_CHUNK_BYTES", "32768")
     got = ctx2.matchDocs(b"".join(docs2), offs)
     c = ctx2.batchCounters()
     assert c["rescanned_docs"] >= 1
     for di, d in enumerate(docs2):
         assert got.doc(di).tolist() == o2.match(d).tolist(), di
+    monkeypatch.delenv("SPA_L1_CHUNK_BYTES")
 
 
 def test_unicode_property_classes():

@@ -243,6 +243,37 @@ def test_not_ascending_positions_is_an_error():
         ctx.matchDocs(lex, [0, 2])
 
 
+def test_failure_beside_a_document_that_is_run_again(monkeypatch):
+    """One document with descending positions and one whose working set exceeds the (small) arena in the same batch: the
+    second is run again with a larger arena and succeeds, the first stays failed -- the batch must still report a failure
+    (the partial rerun counts failures among the documents it ran again only)."""
+    monkeypatch.setenv("SPA_L2_FAST", "0")              # the general kernel: its arena is what overflows
+    rules = synth.random_rules(400, 30, 93)
+    lex, offs = synth.random_documents(6, 300, 30, 94)
+    lex = lex.copy()
+    a, b = int(offs[2]), int(offs[3])
+    lex[a + 10, 1], lex[a + 11, 1] = lex[a + 11, 1] + 5, lex[a + 10, 1]        # document 2: positions not ascending
+    m = spa.PatternMatcherInstance()
+    o = oracle.L2Matcher()
+    synth.apply_rules(m, rules)
+    synth.apply_rules(o, rules)
+    ctx = m.createContext()
+    ctx.setArena(max_rules=32, max_triggers=32, bucket_capacity=8, max_items=32, max_follow=8)
+    got = ctx.matchDocs(lex, offs, check=False)
+    assert got.status[2] == 1 and all(got.status[d] == 0 for d in (0, 1, 3, 4, 5))
+    assert ctx.batchCounters()["failed_docs"] == 1
+    with pytest.raises(spa.PatternError):
+        ctx.matchDocs(lex, offs)
+    good = [d for d in range(6) if d != 2]
+    sel = np.concatenate([lex[int(offs[d]):int(offs[d + 1])] for d in good])
+    soffs = np.cumsum([0] + [int(offs[d + 1] - offs[d]) for d in good]).astype(np.uint64)
+    ref = o.run(synth.lexems5(sel), soffs)
+    for k, d in enumerate(good):
+        r = got.results[int(got.doc_offsets[d]):int(got.doc_offsets[d + 1]), :7]
+        e = ref.results[int(ref.doc_offsets[k]):int(ref.doc_offsets[k + 1]), :7]
+        assert np.array_equal(r, e), "document %d" % d
+
+
 def test_single_document_interface():
     """putInput / fetchResults / getStatistics / reset (patternMatcher.cpp:131-331)."""
     case = l2_cases.load("simple_token_pattern_match.json")
@@ -275,10 +306,11 @@ def test_failed_allocation_leaves_no_stale_capacity():
     ctx = m.createContext()
     _compare(ctx.matchDocs(lex, offs), ref, 20)           # buffers exist, capacities > 0
     ctx.reserveOutput(12000000, 12000000)                  # the next launch has to grow both output buffers
-    os.environ["SPA_TEST_FAIL_ALLOC_ABOVE"] = str(64 << 20)
+    from struspattern_amd import capi
+    capi.lib().sp_test_fail_alloc_above(64 << 20)
     try:
         with pytest.raises(spa.PatternError):
             ctx.matchDocs(lex, offs)
     finally:
-        del os.environ["SPA_TEST_FAIL_ALLOC_ABOVE"]
+        capi.lib().sp_test_fail_alloc_above(0)
     _compare(ctx.matchDocs(lex, offs), ref, 20)           # reallocated: same results as before
