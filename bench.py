@@ -14,6 +14,7 @@ Workloads (--workload):
             16 KiB documents are timed beside it (config.shapes) unless --docbytes fixes one shape.
   lexer     configs[1]: 256 regexes over 64 KiB ASCII documents, lexer kernel only
   l2        configs[2]: 10k rules over a pre-tokenized event stream, rule-automaton kernel only
+  trees     configs[3]: depth-8 nested within/sequence expression trees (not flat: the general automaton kernel, state in HBM)
 """
 import argparse
 import json
@@ -135,6 +136,9 @@ def main():
         h2d_ms = (time.perf_counter() - t0) * 1e3     # pageable host memory -> HBM, reported separately (never part of `value`)
         for name, g in group:
             shapes.append(Shape(name, np.ascontiguousarray(offs[::g]) if (len(offs) - 1) % g == 0 else np.concatenate([offs[:-1:g], offs[-1:]]), torch))
+    elif wl == "trees":
+        rules = synth.tree_rules(args.rules if args.rules != 10000 else 1000, 60, 8, seed=3)
+        lex, offs = synth.tree_documents(args.docs or 6144, args.docsize, 60, seed=1000 + rank)
     else:
         rules = synth.random_rules(args.rules, args.features, seed=2, op=(args.op or None))
         lex, offs = synth.random_documents(args.docs or 10000, args.docsize, args.features, seed=1000 + rank)
@@ -142,16 +146,19 @@ def main():
         sh = Shape("%dtok" % args.docsize, offs, torch)
         sh.nlexems = len(lex)
         shapes.append(sh)
-    if wl in ("pipeline", "l2"):
+    if wl in ("pipeline", "l2", "trees"):
         mi = spa.PatternMatcherInstance()
-        synth.apply_rules(mi, rules)
+        if wl == "trees":
+            synth.apply_trees(mi, rules)
+        else:
+            synth.apply_rules(mi, rules)
         mctx = mi.createContext(local_rank)
 
     def run_lexer(sh):
         sh.lex_out = lctx.matchDocsDevice(d_text.data_ptr(), sh.d_offs.data_ptr(), sh.ndocs, nbytes, stream)
 
     def run_matcher(sh):
-        if wl == "l2":
+        if wl in ("l2", "trees"):
             mctx.matchDocsDevice(d_lex.data_ptr(), sh.d_offs.data_ptr(), sh.ndocs, sh.nlexems, stream)
         else:
             mctx.matchLexedDevice(sh.lex_out.d_lexems, sh.lex_out.d_doc_ranges, sh.ndocs, sh.nlexems, stream)
@@ -231,7 +238,8 @@ def main():
             out["cpu_baseline"] = base
             out["parity_sample"] = parity
         if world == 1 and mctx is not None and not args.no_cpu_baseline:
-            out["canonical_order_mode"] = canonical_order_mode(wl, rules, head, d_lex if wl == "l2" else None, local_rank, m, nbytes)
+            if wl != "trees":
+                out["canonical_order_mode"] = canonical_order_mode(wl, rules, head, d_lex if wl == "l2" else None, local_rank, m, nbytes)
         print(json.dumps(out))
         if out.get("parity_sample") and not out["parity_sample"]["ok"]:
             if world > 1:
@@ -253,7 +261,7 @@ def roofline_of(kernel, kms, kbytes, traffic=None, source=None):
 def report(args, wl, world, pats, head, m, tot, dt, secondary, nbytes, h2d_ms):
     steps = args.steps
     gbytes, gresults, gevents, glexems = tot["bytes"], tot["results"], tot["events"], tot["lexems"]
-    if wl == "l2":
+    if wl in ("l2", "trees"):
         value, unit, metric = gresults * steps / dt, "matches/s", METRIC + " [rule-automaton stage only: matches/s]"
     else:
         value, unit, metric = gbytes * steps / dt / 1e9, "GB/s", METRIC
@@ -288,11 +296,12 @@ def report(args, wl, world, pats, head, m, tot, dt, secondary, nbytes, h2d_ms):
             len(pats) if pats else 0, args.rules, head.ndocs, head.name, nbytes // 1000000, max(1, int(32e9 // max(1, nbytes)))),
         "lexer": "configs[1]: %d regexes, %d docs x %s ASCII per step (lexer only)" % (len(pats) if pats else 0, head.ndocs, head.name),
         "l2": "configs[2]: %d rules (%s), %d docs x %d tokens per step (rule automaton only)" % (args.rules, args.op or "5-op Zipf mix", head.ndocs, args.docsize),
+        "trees": "configs[3]: %d depth-8 expression trees over 60 features, %d docs x %d tokens per step (rule automaton only, general kernel)" % (args.rules if args.rules != 10000 else 1000, head.ndocs, args.docsize),
     }[wl]
     out = {
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64" if wl != "l2" else "u32", "data": "synthetic",
+        "dtype": "u64" if wl in ("pipeline", "lexer") else "u32", "data": "synthetic",
         "config": {"workload": workload, "bytes_per_step_per_gpu": nbytes, "lexems_per_step_per_gpu": m["lexems"],
                    "events_per_step_per_gpu": m["events"], "matches_per_step_per_gpu": m["results"]},
         "matches_per_s": gresults * steps / dt,
@@ -303,7 +312,7 @@ def report(args, wl, world, pats, head, m, tot, dt, secondary, nbytes, h2d_ms):
         "roofline_all": roofs,
     }
     if secondary:
-        out["config"]["shapes"] = {head.name: {"GB/s": value / world if wl != "l2" else None, "ms_per_step": dt / steps * 1e3,
+        out["config"]["shapes"] = {head.name: {"GB/s": value / world if wl in ("pipeline", "lexer") else None, "ms_per_step": dt / steps * 1e3,
                                                "kernel_ms": [m["l1_ms"], m["l2_ms"]], "matches": m["results"]}}
         for name, s in secondary.items():
             out["config"]["shapes"][name] = {"GB/s": nbytes * s["steps"] / s["dt"] / 1e9, "ms_per_step": s["dt"] / s["steps"] * 1e3,
@@ -456,9 +465,12 @@ def cpu_baseline(args, wl, pats, rules, text, head, lex, lctx, mctx):
     # a one-GPU box grants about 16 host cores to the job whatever os.cpu_count() says
     ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     offs = head.offs
-    if wl == "l2":
+    if wl in ("l2", "trees"):
         o = oracle.L2Matcher()
-        synth.apply_rules(o, rules)
+        if wl == "trees":
+            synth.apply_trees(o, rules)
+        else:
+            synth.apply_rules(o, rules)
         nd = max(1, min(len(offs) - 1, int(args.cpu_seconds * 100000 / max(1, args.docsize))))
         sub = synth.lexems5(lex[:int(offs[nd])])
         t0 = time.perf_counter()

@@ -313,9 +313,25 @@ int sp_lexer_ctx_reserve_output( sp_lexer_ctx_t* c, uint64_t lexems)
 }
 int sp_lexer_ctx_grow_arena( sp_lexer_ctx_t* c)
 {
-	if (c->eventCap >= (1u<<26)) { c->lasterror = "arena at its maximum size"; return SP_ERR_INVALID; }
-	c->eventCap *= 2; c->queueCap *= 2; c->arenaWaves = 0;
-	if (c->queueMul < 4096) c->queueMul *= 2;
+	// SP_DOC_ERR_ARENA has two sources: the slice of a report queue of some scan unit (queueMul), or the event array of some
+	// document (eventCap).  The last batch counted them apart; only what overflowed doubles (both when nothing is known).
+	bool queue = true, events = true;
+	if (c->evValid && hipSetDevice( c->device) == hipSuccess && hipStreamSynchronize( c->lastStream) == hipSuccess)
+	{
+		uint64_t over[ 2] = {0, 0};
+		if (hipMemcpyAsync( over, (const uint64_t*)c->dCounters.ptr + L1C_OVER_QUEUE, sizeof(over), hipMemcpyDeviceToHost, c->own) == hipSuccess
+		&&  hipStreamSynchronize( c->own) == hipSuccess && (over[ 0] || over[ 1])) { queue = over[ 0] != 0; events = over[ 1] != 0; }
+	}
+	if (events)
+	{
+		if (c->eventCap >= (1u<<26)) { c->lasterror = "arena at its maximum size"; return SP_ERR_INVALID; }
+		c->eventCap *= 2; c->arenaWaves = 0;
+	}
+	if (queue)
+	{
+		if (c->queueMul >= 4096) { c->lasterror = "report queue at its maximum size (4096 x 1/16 reports per text byte)"; return SP_ERR_INVALID; }
+		c->queueCap *= 2; c->queueMul *= 2;
+	}
 	return SP_OK;
 }
 
@@ -375,6 +391,23 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	c->dReportCount.reserve( (maxUnits+1)*sizeof(uint32_t));
 	c->dUnitStart.reserve( (ndocs+2)*sizeof(uint32_t));
 	c->dDocSequential.reserve( (ndocs+1)*sizeof(uint32_t));
+	{
+		// the report queues follow the text size: refuse a batch whose queues would not fit beside it instead of running into hipMalloc
+		const uint64_t qbytes = ((((uint64_t)nbytes * c->queueMul) >> 4) + 64ull*(maxUnits+2)) * 16;
+		size_t freeB = 0, totalB = 0;
+		if (hipMemGetInfo( &freeB, &totalB) == hipSuccess)
+		{
+			const uint64_t have = (uint64_t)c->dQueue.bytes + (c->wordsKernel ? (uint64_t)c->dWordQueue.bytes : 0);
+			const uint64_t want = qbytes * (c->wordsKernel ? 2 : 1);
+			if (want > have && want - have > (uint64_t)(0.8 * (double)freeB))
+			{
+				char msg[ 200];
+				snprintf( msg, sizeof(msg), "the report queues of this batch (%llu MB at %u/16 reports per text byte) do not fit the free device memory (%llu MB): pass fewer bytes per batch",
+					(unsigned long long)(want >> 20), c->queueMul, (unsigned long long)(freeB >> 20));
+				throw std::runtime_error( msg);
+			}
+		}
+	}
 	c->dQueue.reserve( ((((uint64_t)nbytes * c->queueMul) >> 4) + 64ull*(maxUnits+2)) * 16);
 	if (c->wordsKernel)
 	{

@@ -8,7 +8,8 @@ namespace spa {
 
 enum {L1C_LEXEMS=0, L1C_BYTES=1, L1C_RAW=2, L1C_FAILED=3, L1C_COUNT=8, L1C_CURSOR=8 /*document cursor of the scan kernel, behind the counters*/, L1C_CURSOR2=9 /*of the post-processing kernel*/,
       L1C_CURSOR3=10 /*of the sequential re-scan*/, L1C_UNITS=11 /*scan units = chunks of all documents*/, L1C_CHUNKED=12 /*some document has more than one chunk*/, L1C_SEQDOCS=13 /*documents scanned again in one piece*/,
-      L1C_CURSOR4=14 /*unit cursor of the words kernel*/, L1C_WORDREPORTS=15 /*records the words kernel wrote*/, L1C_ALLOC=16};
+      L1C_CURSOR4=14 /*unit cursor of the words kernel*/, L1C_WORDREPORTS=15 /*records the words kernel wrote*/,
+      L1C_OVER_QUEUE=16 /*units whose slice of a report queue was too small*/, L1C_OVER_EVENTS=17 /*documents whose event array was too small*/, L1C_ALLOC=18};
 
 struct L1Params
 {

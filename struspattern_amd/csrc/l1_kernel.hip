@@ -448,7 +448,12 @@ __device__ __forceinline__ void handleReport( LexWave& w, const L1Params& P, u32
 	}
 	const u32 levelBind = lb & 0xFFFFu, level = lb & 0xFFu;
 	const bool twin = (patternid != id);
-	if (w.nEvents + 2 > P.eventCap) { w.err = L1D_ERR_ARENA; return; }
+	if (w.nEvents + 2 > P.eventCap)
+	{
+		// (which of the two working sets was too small is counted apart: the host grows only that one)
+		if (LANE == 0) atomicAdd( (unsigned long long*)&P.counters[ L1C_OVER_EVENTS], 1ull);
+		w.err = L1D_ERR_ARENA; return;
+	}
 	if (w.cnt >= 62u) spillLanes( w, 32);
 	if (w.nEvents == 0 || (w.cnt && w.tailPos < from && w.tailEnd < to))
 	{
@@ -1147,6 +1152,7 @@ __device__ void scanDocumentsLanes( const L1Params& P)
 			{
 				P.reportCount[ unit] = w.err ? 0u : w.nQueue;
 				if (w.err) P.docStatus[ doc] = (int32_t)w.err;
+				if (w.err == L1D_ERR_ARENA) atomicAdd( (unsigned long long*)&P.counters[ L1C_OVER_QUEUE], 1ull);
 				atomicAdd( (unsigned long long*)&P.counters[ L1C_RAW], (unsigned long long)w.nQueue);
 			}
 		}
@@ -1487,6 +1493,7 @@ __device__ void wordsDocuments( const L1Params& P)
 		{
 			P.wordCount[ unit] = w.err ? 0u : w.nQueue;
 			if (w.err) P.docStatus[ doc] = (int32_t)w.err;
+			if (w.err == L1D_ERR_ARENA) atomicAdd( (unsigned long long*)&P.counters[ L1C_OVER_QUEUE], 1ull);
 			atomicAdd( (unsigned long long*)&P.counters[ L1C_WORDREPORTS], (unsigned long long)w.nQueue);
 		}
 	}
@@ -2017,6 +2024,7 @@ __device__ void scanDocuments( const L1Params& P)
 				for (u32 u=u0+1; u<u1; ++u) P.reportCount[ u] = 0;
 				// (the sequential pass decides alone about its document: a chunk of the first pass may have left an error behind)
 				if (w.err || P.sequentialPass) P.docStatus[ doc] = (int32_t)w.err;
+				if (w.err == L1D_ERR_ARENA) atomicAdd( (unsigned long long*)&P.counters[ L1C_OVER_QUEUE], 1ull);
 				atomicAdd( (unsigned long long*)&P.counters[ L1C_RAW], (unsigned long long)w.nQueue);
 			}
 		}

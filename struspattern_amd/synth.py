@@ -218,3 +218,65 @@ def pipeline_workload(npatterns, nrules, vocab, seed):
     pats.append((DELIM, "[.]", 0, 5, "content"))
     rules = random_rules(nrules, npatterns, seed + 1)
     return pats, rules
+
+
+# ---------------------------------------------------------------- expression trees (BASELINE.json configs[3])
+def random_tree(rng, nfeat, depth, maxdepth):
+    """(range, push function) of a random expression tree: nested sequence / within / *_struct / any / sequence_imm / and
+    expressions (generator after tests/randomExpressionTreeMatch/src/testRandomExpressionTreeMatch.cpp:239-338 with the depth
+    limit lifted: range = argc + random + sum of the children's ranges).  push(m) issues the PatternMatcherInstanceInterface calls."""
+    if depth >= maxdepth or (depth > 0 and rng.random() < 0.35):
+        t = int(rng.integers(1, nfeat + 1))
+        var = "t%d" % depth if rng.random() < 0.3 else None
+
+        def push_term(m, t=t, var=var):
+            m.pushTerm(t)
+            if var:
+                m.attachVariable(var)
+        return 1, push_term
+    op = ["sequence", "within", "sequence_struct", "within_struct", "any", "sequence_imm", "and"][int(rng.integers(0, 7))]
+    argc = int(rng.integers(2, 4))
+    children = [random_tree(rng, nfeat, depth + 1, maxdepth) for _ in range(argc)]
+    rg = argc + int(rng.integers(0, 4)) + sum(c[0] for c in children)
+    card = int(rng.integers(1, argc + 1)) if op in ("any", "and") and rng.random() < 0.4 else 0
+    var = "e%d" % depth if depth > 0 and rng.random() < 0.3 else None
+
+    def push(m):
+        n = argc
+        if op in ("sequence_struct", "within_struct"):
+            m.pushTerm(DELIM)
+            n += 1
+        for _, c in children:
+            c(m)
+        m.pushExpression(op, n, rg, card)
+        if var:
+            m.attachVariable(var)
+    return rg, push
+
+
+def tree_rules(ntrees, nfeat, maxdepth, seed):
+    """list of push functions, one per tree"""
+    rng = np.random.default_rng(seed)
+    return [random_tree(rng, nfeat, 0, maxdepth)[1] for _ in range(ntrees)]
+
+
+def apply_trees(m, trees, compile=True):
+    for i, push in enumerate(trees):
+        push(m)
+        m.definePattern("tree_%d" % i, "", True)
+    if compile:
+        m.compile()
+
+
+def tree_documents(ndocs, n, nfeat, seed):
+    """documents of n tokens over nfeat features, 5 % sentence delimiters, one token per position"""
+    rng = np.random.default_rng(seed)
+    lex = np.zeros((ndocs * n, 4), np.uint32)
+    offs = np.arange(ndocs + 1, dtype=np.uint64) * n
+    ids = rng.integers(1, nfeat + 1, size=ndocs * n)
+    ids[rng.random(ndocs * n) < 0.05] = DELIM
+    lex[:, 0] = ids
+    lex[:, 1] = np.tile(np.arange(1, n + 1, dtype=np.uint32), ndocs)
+    lex[:, 2] = np.tile(np.arange(n, dtype=np.uint32) * 2, ndocs)
+    lex[:, 3] = 1
+    return lex, offs

@@ -21,7 +21,8 @@ python3 - <<'PY'
 import csv, glob, json, collections
 out = {"command": "python3 bench.py --no-cpu-baseline --docbytes 65536 --steps 2 --warmup 1",
        "note": "FETCH_SIZE/WRITE_SIZE in KB as reported by rocprofv3; hbm_read_bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction of MI355X_MICROARCH.md, HBM section). "
-               "Steady state = launches within 2x of the longest one of a kernel (bench.py starts with short sizing launches). SQ_* per launch; SQ_WAVE_CYCLES / WAIT / ACTIVE are quad-cycles.",
+               "Steady state = launches within 2x of the longest one of a kernel (bench.py starts with short sizing launches). SQ_* per launch; SQ_WAVE_CYCLES / WAIT / ACTIVE are quad-cycles. "
+               "VGPR_Count / SGPR_Count are what the kernel trace reports per dispatch (granule-rounded allocation of the ARCH registers; the code-object metadata is in rNN_kernel_resources.txt).",
        "kernels": {}}
 def group(name):
     return name.split("(")[0]
