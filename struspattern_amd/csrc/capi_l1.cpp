@@ -44,7 +44,7 @@ struct sp_lexer_ctx
 		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit, dApprox, dCharCp, dCharPos, dCpBlocks, dCpPages, dUnitStart, dDocSequential, dNullable,
 		dScanImage, dShapes, dShapePats;
 	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst; unsigned blockThreads;
-	uint32_t imgWords, imgAccept, imgStart, imgShift, imgSelf, imgExSrc, imgExDst;	// offsets inside the image of all passes (dTableImage); lds*: inside the image of the scanned passes
+	uint32_t imgShapeFp, imgWords, imgAccept, imgStart, imgShift, imgSelf, imgExSrc, imgExDst;	// offsets inside the image of all passes (dTableImage); lds*: inside the image of the scanned passes
 	bool wordsKernel;		// plain tables: literals and word shapes are found by the words kernel
 	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus, dQueue, dReportCount, dWordQueue, dWordCount;
 	uint32_t queueMul;		// report queue between the two kernels: queueMul/16 reports per text byte (+64 per document)
@@ -58,7 +58,7 @@ struct sp_lexer_ctx
 				// the reference's threading model -- copy and launch side by side instead of queueing on the null stream
 	sp_lexer_ctx() :inst(0),device(0),ldsWords(0),ldsAccept(0),ldsStart(0),ldsShift(0),ldsSelf(0),ldsExSrc(0),ldsExDst(0),blockThreads(256),queueMul(8),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
 		,numCUs(256),evStart(0),evMid(0),evWords(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0),own(0)
-		,imgWords(0),imgAccept(0),imgStart(0),imgShift(0),imgSelf(0),imgExSrc(0),imgExDst(0),wordsKernel(false){}
+		,imgShapeFp(0),imgWords(0),imgAccept(0),imgStart(0),imgShift(0),imgSelf(0),imgExSrc(0),imgExDst(0),wordsKernel(false){}
 };
 
 extern "C" {
@@ -232,6 +232,7 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 			c->imgSelf = (uint32_t)img.size(); img.insert( img.end(), T.selfLoop.begin(), T.selfLoop.end());
 			c->imgExSrc = (uint32_t)img.size(); img.insert( img.end(), T.exSrc.begin(), T.exSrc.end());
 			c->imgExDst = (uint32_t)img.size(); img.insert( img.end(), T.exDst.begin(), T.exDst.end());
+			c->imgShapeFp = (uint32_t)img.size(); img.insert( img.end(), T.shapeFp.begin(), T.shapeFp.end());	// (the compact shape table rides along: staged in LDS with the rest)
 			c->dTableImage.upload( img.data(), img.size()*8);
 			c->imgWords = (uint32_t)img.size();
 		}
@@ -452,6 +453,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.shapes = (const DevShape*)c->dShapes.ptr; P.shapePats = (const uint32_t*)c->dShapePats.ptr; P.shapeMask = (uint32_t)T.shapes.size()-1;
 	P.nofShapeVariants = (uint32_t)T.shapeVariants.size();
 	for (size_t i=0; i<T.shapeVariants.size() && i<SHAPE_MAXVARIANTS; ++i) P.shapeVariants[ i] = T.shapeVariants[ i];
+	P.shapeFpOffset = c->imgShapeFp; P.shapeSalt = T.shapeSalt;
 	P.wordQueue = (uint32_t*)c->dWordQueue.ptr; P.wordCount = (uint32_t*)c->dWordCount.ptr; P.wordsKernel = c->wordsKernel ? 1u : 0u;
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
 	// the kernels that walk an automaton backwards read the image of all passes from global memory ...

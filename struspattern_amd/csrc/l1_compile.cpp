@@ -1664,6 +1664,25 @@ void LexCompiler::compile()
 			T.shapes[ slot] = e;
 			variants.insert( (e.tag & 3u) == (uint32_t)SHAPE_PREVWORD ? (uint32_t)SHAPE_PREVWORD : e.tag);
 		}
+		// compact form: fingerprints unique among the keys (another salt until they are)
+		T.shapeSalt = 0;
+		for (;; ++T.shapeSalt)
+		{
+			std::set<uint32_t> seen;
+			bool unique = true;
+			for (size_t i=0; i<T.shapes.size() && unique; ++i) if (T.shapes[ i].tag) unique = seen.insert( shapeFingerprint( T.shapes[ i].tag, T.shapes[ i].key, T.shapeSalt)).second;
+			if (unique) break;
+			if (T.shapeSalt > 1000) throw std::runtime_error( "internal: no salt makes the word shape fingerprints unique");
+		}
+		T.shapeFp.assign( T.shapes.size(), 0);
+		for (size_t i=0; i<T.shapes.size(); ++i)
+		{
+			const DevShape& e = T.shapes[ i];
+			if (!e.tag) continue;
+			if (e.patCount > 255 || e.patBegin >= (1u << 24)) throw std::runtime_error( "too many expressions share one word shape key");
+			const uint32_t info = (e.patCount << 24) | (e.patCount == 1 ? T.shapePats[ e.patBegin] : e.patBegin);
+			T.shapeFp[ i] = (uint64_t)shapeFingerprint( e.tag, e.key, T.shapeSalt) | ((uint64_t)info << 32);
+		}
 		T.shapeVariants.assign( variants.begin(), variants.end());
 		if (T.shapeVariants.size() > SHAPE_MAXVARIANTS) throw std::runtime_error( "internal: too many word shape variants");
 		if (T.shapePats.empty()) T.shapePats.push_back( 0);
@@ -1700,7 +1719,7 @@ void LexCompiler::compile()
 }
 
 // ---------------------------------------------------------------- compiled tables as a blob
-static const char L1_MAGIC[ 9] = "SPAL1v08";
+static const char L1_MAGIC[ 9] = "SPAL1v09";
 
 void LexCompiler::save( std::vector<uint8_t>& out) const
 {
@@ -1712,7 +1731,7 @@ void LexCompiler::save( std::vector<uint8_t>& out) const
 	w.vec( T.byteClass); w.vec( T.classCtx); w.vec( T.cpBlocks); w.vec( T.cpPages); w.vec( T.charMask); w.vec( T.startMask); w.vec( T.acceptMask); w.vec( T.shiftDst); w.vec( T.selfLoop);
 	w.vec( T.exCount); w.vec( T.exSrc); w.vec( T.exDst); w.vec( T.wordPatBegin); w.vec( T.wordPats); w.vec( T.patOfBit);
 	w.vec( T.patterns); w.vec( T.symbols); w.vec( T.symbolText); w.vec( T.literals); w.vec( T.literalText); w.vec( T.litPats); w.vec( T.approx); w.vec( T.nullable);
-	w.u32( T.scanPasses); w.u32( T.scanWords); w.u32( T.lanesOk ? 1u : 0u); w.u32( T.nofShapes); w.vec( T.shapes); w.vec( T.shapePats); w.vec( T.shapeVariants);
+	w.u32( T.scanPasses); w.u32( T.scanWords); w.u32( T.lanesOk ? 1u : 0u); w.u32( T.nofShapes); w.vec( T.shapes); w.vec( T.shapePats); w.vec( T.shapeVariants); w.vec( T.shapeFp); w.u32( T.shapeSalt);
 	w.u32( (uint32_t)m_defs.size());
 	for (size_t i=0; i<m_defs.size(); ++i)
 	{
@@ -1739,7 +1758,8 @@ void LexCompiler::load( const void* blob, size_t size)
 	r.vec( T.byteClass); r.vec( T.classCtx); r.vec( T.cpBlocks); r.vec( T.cpPages); r.vec( T.charMask); r.vec( T.startMask); r.vec( T.acceptMask); r.vec( T.shiftDst); r.vec( T.selfLoop);
 	r.vec( T.exCount); r.vec( T.exSrc); r.vec( T.exDst); r.vec( T.wordPatBegin); r.vec( T.wordPats); r.vec( T.patOfBit);
 	r.vec( T.patterns); r.vec( T.symbols); r.vec( T.symbolText); r.vec( T.literals); r.vec( T.literalText); r.vec( T.litPats); r.vec( T.approx); r.vec( T.nullable);
-	T.scanPasses = r.u32(); T.scanWords = r.u32(); T.lanesOk = r.u32() != 0; T.nofShapes = r.u32(); r.vec( T.shapes); r.vec( T.shapePats); r.vec( T.shapeVariants);
+	T.scanPasses = r.u32(); T.scanWords = r.u32(); T.lanesOk = r.u32() != 0; T.nofShapes = r.u32(); r.vec( T.shapes); r.vec( T.shapePats); r.vec( T.shapeVariants); r.vec( T.shapeFp); T.shapeSalt = r.u32();
+	if (T.shapeFp.size() != T.shapes.size()) throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");
 	if (T.scanPasses > T.nofPasses || T.scanWords > T.scanPasses*64 || T.shapes.empty() || (T.shapes.size() & (T.shapes.size()-1)) || T.shapeVariants.size() > SHAPE_MAXVARIANTS || T.shapePats.empty())
 	{
 		throw std::runtime_error( "compiled lexer blob has inconsistent table shapes");

@@ -48,6 +48,8 @@ struct LexTables
 	// word shapes (l1_tables.h): expressions found at the ends of word runs instead of by an automaton pass
 	std::vector<DevShape> shapes;		// power-of-two size (>=1)
 	std::vector<uint32_t> shapePats;
+	std::vector<uint64_t> shapeFp;		// compact form the kernel probes (l1_tables.h): same slots as `shapes`
+	uint32_t shapeSalt;
 	std::vector<uint32_t> shapeVariants;	// the distinct tags (kind | offset << 2 | length << 4; PREVWORD: kind) the table holds
 	uint32_t nofShapes;			// expressions taken as shapes
 	uint32_t scanPasses;			// passes [0, scanPasses) are run by the scan kernel; the rest is only walked backwards

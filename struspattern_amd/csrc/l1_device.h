@@ -91,6 +91,8 @@ struct L1Params
 	uint32_t* wordQueue;
 	uint32_t* wordCount;
 	uint32_t wordsKernel;		// 1: the post-processing kernel merges the two queues (plain tables); 0: it finds the literals itself
+	uint32_t shapeFpOffset;		// the compact shape table (l1_tables.h) lies at this word offset of the table image (LDS or global, like the rest)
+	uint32_t shapeSalt;
 	uint32_t scanWords;		// automaton words the scanned passes use: up to 4 words in one pass take the lane-per-stream scan kernel
 };
 

@@ -1249,10 +1249,12 @@ __device__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, 
 	if (w0 >= 2 && isWordAt( w0-2)) w0 = runStartBefore( P, w.doc, w0-1, ctxReg);
 	WordCarry c; c.in = false; c.hash = 0; c.len = 0; c.start = 0; c.lastValid = false; c.lastTo = 0; c.lastHash = 0; c.lastLen = 0;
 	const u32 nVar = uni( P.nofShapeVariants);
+	u32 ahead = (w0 + LANE < len) ? (u32)w.doc[ w0 + LANE] : 0u;
 	for (u32 tile=w0; tile<=len && tile<=segEnd && !w.err; tile+=64)
 	{
 		const u32 inTile = (len - tile) < 64 ? (len - tile) : 64;
-		const u32 mine = LANE < inTile ? (u32)w.doc[ tile + LANE] : 0u;
+		const u32 mine = ahead;			// (the next tile's bytes are requested one tile ahead)
+		ahead = (tile + 64u + LANE < len) ? (u32)w.doc[ tile + 64u + LANE] : 0u;
 		const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> ((mine & 3u)*8)) & 0xFFu;
 		const u32 clsL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)clsReg) >> ((mine & 3u)*8)) & 0xFFu;
 		ring[ (tile + LANE) & (WORD_RING-1)] = (unsigned short)(clsL | (ctxL << 8));		// (the ring keeps this tile and the one before it)
@@ -1302,7 +1304,7 @@ __device__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, 
 		u32 lb[ NLIST], lc[ NLIST];
 #pragma unroll
 		for (int k=0; k<NLIST; ++k) { lb[ k] = 0; lc[ k] = 0; }
-		u32 total = 0;
+		u32 total = 0, lit0 = 0;
 		if (emit)
 		{
 			if (P.nofLiterals && pLen <= 64u)
@@ -1340,34 +1342,55 @@ __device__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, 
 							const u32 mask = rem >= 4u ? 0xFFFFFFFFu : ((1u << (8*rem)) - 1u);
 							same = ((a ^ b) & mask) == 0;
 						}
-						if (same) { lb[ 0] = e0.z; lc[ 0] = e0.w; break; }
+						if (same) { lb[ 0] = e0.z; lc[ 0] = e0.w; lit0 = e1.x; break; }
 					}
 					slot = (slot+1) & P.literalMask;
 				}
 			}
 		}
-#pragma unroll
-		for (int v=0; v<SHAPE_MAXVARIANTS; ++v)
+		// ---- shape variants: the key bytes come out of two unaligned words of the text (the run's first four bytes, its last
+		// four); the compact table (fingerprint, pattern or list) sits in LDS beside the automaton tables: no global round trip
+		if (nVar && __ballot( emit))
 		{
-			if ((u32)v < nVar)
+			u32 first4 = 0, last4 = 0;
+			if (emit)
 			{
-				const u32 var = uni( P.shapeVariants[ v]);
-				const u32 kind = var & 3u, o = (var >> 2) & 3u, k = (var >> 4) & 7u;
-				if (emit)
+				if (pFrom + 4u <= len) first4 = ld32u( w.doc + pFrom); else for (u32 i=0; i<4u && pFrom+i<len; ++i) first4 |= (u32)w.doc[ pFrom+i] << (8*i);
+				if (to >= 4u) last4 = ld32u( w.doc + to - 4u); else for (u32 i=0; i<to; ++i) last4 |= (u32)w.doc[ i] << (8*(4u-to+i));
+			}
+#pragma unroll
+			for (int v=0; v<SHAPE_MAXVARIANTS; ++v)
+			{
+				if ((u32)v < nVar)
 				{
-					u32 tag = 0, key = 0;
-					if (kind == (u32)SHAPE_PREVWORD) { if (qLen >= 1u && qLen <= 64u) { tag = (u32)SHAPE_PREVWORD | (qLen << 8); key = literalHashFinish( qH); } }
-					else if (kind == (u32)SHAPE_PREFIX) { if (pLen >= o + k) { tag = var; for (u32 i=0; i<k; ++i) key |= (u32)w.doc[ pFrom + o + i] << (8*i); } }
-					else { if (pLen >= k) { tag = var; for (u32 i=0; i<k; ++i) key |= (u32)w.doc[ to - k + i] << (8*i); } }
-					if (tag)
+					const u32 var = uni( P.shapeVariants[ v]);
+					const u32 kind = var & 3u, o = (var >> 2) & 3u, k = (var >> 4) & 7u;
+					const u32 kmask = k >= 4u ? 0xFFFFFFFFu : ((1u << (8*k)) - 1u);
+					if (emit)
 					{
-						u32 slot = shapeSlotHash( tag, key) & P.shapeMask;
-						for (u32 probes=0; probes<=P.shapeMask; ++probes)
+						u32 tag = 0, key = 0;
+						if (kind == (u32)SHAPE_PREVWORD) { if (qLen >= 1u && qLen <= 64u) { tag = (u32)SHAPE_PREVWORD | (qLen << 8); key = literalHashFinish( qH); } }
+						else if (kind == (u32)SHAPE_PREFIX)
 						{
-							const uint4 e = *(const uint4*)&P.shapes[ slot];		// {tag, key, patBegin, patCount}
-							if (!e.x) break;
-							if (e.x == tag && e.y == key) { lb[ 1+v] = e.z; lc[ 1+v] = e.w; break; }
-							slot = (slot+1) & P.shapeMask;
+							if (pLen >= o + k)
+							{
+								tag = var;
+								if (o + k <= 4u) key = (first4 >> (8*o)) & kmask;
+								else for (u32 i=0; i<k; ++i) key |= (u32)w.doc[ pFrom + o + i] << (8*i);
+							}
+						}
+						else if (pLen >= k) { tag = var; key = k >= 4u ? last4 : (last4 >> (8*(4u-k))); }
+						if (tag)
+						{
+							const u32 fp = shapeFingerprint( tag, key, P.shapeSalt);
+							u32 slot = shapeSlotHash( tag, key) & P.shapeMask;
+							for (u32 probes=0; probes<=P.shapeMask; ++probes)
+							{
+								const u64 e = T.at( P.shapeFpOffset + slot);		// fingerprint | (count << 24 | pattern or list) << 32
+								if (!(u32)e) break;
+								if ((u32)e == fp) { lb[ 1+v] = (u32)(e >> 32) & 0xFFFFFFu; lc[ 1+v] = (u32)(e >> 56); break; }
+								slot = (slot+1) & P.shapeMask;
+							}
 						}
 					}
 				}
@@ -1387,9 +1410,43 @@ __device__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, 
 			// confirms it -- one round of walks per tile instead of one per candidate of the busiest lane.
 			const bool staged = waveTotal <= 64u;
 			uint4* stage = wordStage[ (threadIdx.x >> 6) & (WORD_WAVES-1)];
-			u32 head[ NLIST];
+			// The usual tile: no list longer than one pattern, no end offset with more than four candidates.  Then a lane's candidates
+			// are a handful of keys (pattern << 1 | literal) in registers, ordered by a five-comparator network: no loop, no load.
+			bool simple = total <= 4u;
 #pragma unroll
-			for (int k=0; k<NLIST; ++k) head[ k] = lc[ k] ? (k == 0 ? P.litPats[ lb[ 0]] : P.shapePats[ lb[ k]]) : 0xFFFFFFFFu;
+			for (int k=0; k<NLIST; ++k) if (lc[ k] > 1u) simple = false;
+			if (staged && !__ballot( !simple))
+			{
+				u32 c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu, c3 = 0xFFFFFFFFu, nc = 0;
+#pragma unroll
+				for (int k=0; k<NLIST; ++k)
+				{
+					if (lc[ k])
+					{
+						const u32 key = k == 0 ? ((lit0 << 1) | 1u) : (lb[ k] << 1);
+						c0 = nc == 0 ? key : c0; c1 = nc == 1 ? key : c1; c2 = nc == 2 ? key : c2; c3 = nc == 3 ? key : c3;
+						++nc;
+					}
+				}
+#define SPA_CSWAP( A, B) { const u32 lo = A < B ? A : B, hi = A < B ? B : A; A = lo; B = hi; }
+				SPA_CSWAP( c0, c1) SPA_CSWAP( c2, c3) SPA_CSWAP( c0, c2) SPA_CSWAP( c1, c3) SPA_CSWAP( c1, c2)
+#undef SPA_CSWAP
+				const u32 at = incl - total;
+				if (total > 0) stage[ at] = make_uint4( to, (c0 >> 1) | ((c0 & 1u) ? (u32)L1_LITERAL_FLAG : 0u), pFrom, 0u);
+				if (total > 1) stage[ at+1] = make_uint4( to, (c1 >> 1) | ((c1 & 1u) ? (u32)L1_LITERAL_FLAG : 0u), pFrom, 0u);
+				if (total > 2) stage[ at+2] = make_uint4( to, (c2 >> 1) | ((c2 & 1u) ? (u32)L1_LITERAL_FLAG : 0u), pFrom, 0u);
+				if (total > 3) stage[ at+3] = make_uint4( to, (c3 >> 1) | ((c3 & 1u) ? (u32)L1_LITERAL_FLAG : 0u), pFrom, 0u);
+				total = 0;		// (nothing left for the general merge below)
+			}
+			u32 head[ NLIST]; bool single[ NLIST];
+#pragma unroll
+			for (int k=0; k<NLIST; ++k) single[ k] = lc[ k] == 1u;
+#pragma unroll
+			for (int k=0; k<NLIST; ++k)
+			{
+				head[ k] = 0xFFFFFFFFu;
+				if (lc[ k]) head[ k] = k == 0 ? lit0 : (lc[ k] == 1u ? lb[ k] : P.shapePats[ lb[ k]]);	// (a shape entry of one pattern holds the pattern in place of the list)
+			}
 			for (u32 n=0; n<total; ++n)
 			{
 				u32 best = 0xFFFFFFFFu; int which = 0;
@@ -1401,8 +1458,12 @@ __device__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, 
 				{
 					if (k == which)
 					{
-						++lb[ k]; --lc[ k];
-						head[ k] = lc[ k] ? (k == 0 ? P.litPats[ lb[ 0]] : P.shapePats[ lb[ k]]) : 0xFFFFFFFFu;
+						if (k != 0 && single[ k]) { lc[ k] = 0; head[ k] = 0xFFFFFFFFu; }
+						else
+						{
+							++lb[ k]; --lc[ k];
+							head[ k] = lc[ k] ? (k == 0 ? P.litPats[ lb[ 0]] : P.shapePats[ lb[ k]]) : 0xFFFFFFFFu;
+						}
 					}
 				}
 				if (staged) { stage[ incl - total + n] = make_uint4( to, which == 0 ? (best | (u32)L1_LITERAL_FLAG) : best, pFrom, 0u); continue; }

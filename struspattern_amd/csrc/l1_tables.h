@@ -99,6 +99,19 @@ struct DevShape			// 16 B, open addressing (linear probing), tag==0 = empty
 	uint32_t patBegin;	// shapePats[patBegin .. patBegin+patCount): pattern indices, ascending
 	uint32_t patCount;
 };
+// What the kernel probes is a compact form of that table (8 bytes per entry, small enough to sit in LDS beside the automaton
+// tables): fingerprint of (tag, key) -- nonzero, unique among the table's keys for the salt the compiler found -- and
+// count << 24 | (count == 1 ? the pattern : patBegin).  A fingerprint that matches by chance costs a walk that does not confirm.
+static inline
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+uint32_t shapeFingerprint( uint32_t tag, uint32_t key, uint32_t salt)
+{
+	uint32_t h = (key ^ salt) * 0x85EBCA6Bu + tag * 0xC2B2AE35u;
+	h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+	return h ? h : 1u;
+}
 static inline
 #if defined(__HIPCC__)
 __host__ __device__
