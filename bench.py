@@ -136,12 +136,13 @@ def main():
         h2d_ms = (time.perf_counter() - t0) * 1e3     # pageable host memory -> HBM, reported separately (never part of `value`)
         for name, g in group:
             shapes.append(Shape(name, np.ascontiguousarray(offs[::g]) if (len(offs) - 1) % g == 0 else np.concatenate([offs[:-1:g], offs[-1:]]), torch))
-    elif wl == "trees":
-        rules = synth.tree_rules(args.rules if args.rules != 10000 else 1000, 60, 8, seed=3)
-        lex, offs = synth.tree_documents(args.docs or 6144, args.docsize, 60, seed=1000 + rank)
     else:
-        rules = synth.random_rules(args.rules, args.features, seed=2, op=(args.op or None))
-        lex, offs = synth.random_documents(args.docs or 10000, args.docsize, args.features, seed=1000 + rank)
+        if wl == "trees":
+            rules = synth.tree_rules(args.rules if args.rules != 10000 else 1000, 60, 8, seed=3)
+            lex, offs = synth.tree_documents(args.docs or 6144, args.docsize, 60, seed=1000 + rank)
+        else:
+            rules = synth.random_rules(args.rules, args.features, seed=2, op=(args.op or None))
+            lex, offs = synth.random_documents(args.docs or 10000, args.docsize, args.features, seed=1000 + rank)
         d_lex = torch.from_numpy(lex.view(np.int32)).cuda()
         sh = Shape("%dtok" % args.docsize, offs, torch)
         sh.nlexems = len(lex)

@@ -379,7 +379,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	{
 		size_t full = (size_t)c->numCUs*postPerCU;
 		if (full * perWaveWords*4 > ((size_t)48 << 30)) full = ((size_t)48 << 30) / (perWaveWords*4);
-		unsigned alloc = nwaves < full ? (unsigned)full : nwaves;
+		unsigned alloc = (nwaves >= 64 && nwaves < full) ? (unsigned)full : nwaves;		// (single documents, the plugin path: a small arena per context)
 		c->arenaWaves = 0;
 		c->dArena.alloc( (size_t)alloc * perWaveWords * 4);
 		c->arenaWaves = alloc; c->arenaWords = perWaveWords;

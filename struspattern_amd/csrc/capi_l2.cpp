@@ -599,7 +599,9 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		size_t perWave = (size_t)c->arena.totalWords * sizeof(uint32_t);
 		size_t full = (size_t)c->numCUs*SPA_L2_WAVES_PER_CU;
 		if (full * perWave > ((size_t)48 << 30)) full = ((size_t)48 << 30) / perWave;
-		unsigned alloc = (nwaves < full && !rerun) ? (unsigned)full : nwaves;	// allocate for the full machine once (a rerun of a few large documents: for those)
+		// batches of many documents: for the full machine at once; a context that sees single documents (the plugin path: one context per
+		// host thread) keeps a small arena -- the full one is gigabytes per context
+		unsigned alloc = (nwaves >= 64 && nwaves < full && !rerun) ? (unsigned)full : nwaves;
 		c->arenaWaves = 0;
 		c->dArena.alloc( (size_t)alloc * perWave);
 		c->arenaWaves = alloc;
@@ -719,8 +721,9 @@ void launchBatch( sp_matcher_ctx* c, const void* d_lexems, const void* d_origseg
 		if (c->fastWaves < fblocks)
 		{
 			c->fastWaves = 0;
-			c->dSpill.alloc( fslots * (size_t)c->fastSpill.totalWords * sizeof(uint32_t));
-			c->fastWaves = (unsigned)fslots;
+			const size_t spillSlots = fblocks >= 64 ? fslots : fblocks;		// (single documents: a small spill area, see the arena)
+			c->dSpill.alloc( spillSlots * (size_t)c->fastSpill.totalWords * sizeof(uint32_t));
+			c->fastWaves = (unsigned)spillSlots;
 			if (getenv( "SPA_L2_VERBOSE")) fprintf( stderr, "[spa] fast tier: %u waves/CU, LDS capacities R %u T %u, spill %.2f MB per wave\n", c->fastBlocksPerCU, fR, fT, c->fastSpill.totalWords*4/1e6);
 		}
 		c->dFallbackList.reserve( (ndocs+1)*sizeof(uint32_t));

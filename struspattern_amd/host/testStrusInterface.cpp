@@ -301,7 +301,7 @@ static int runThreads( int nthreads, const char* fixture, int repeat)
 				}
 			}
 		}
-		catch (const std::exception& e) { failures[ ti] = e.what(); }
+		catch (const std::exception& e) { failures[ ti] = e.what(); ready.fetch_add( 1); /*(the others must not wait for a thread that has given up)*/ }
 	};
 	std::vector<std::thread> th;
 	for (int ti=0; ti<nthreads; ++ti) th.push_back( std::thread( work, ti));
