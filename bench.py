@@ -139,7 +139,10 @@ def main():
     else:
         if wl == "trees":
             rules = synth.tree_rules(args.rules if args.rules != 10000 else 1000, 60, 8, seed=3)
-            lex, offs = synth.tree_documents(args.docs or 6144, args.docsize, 60, seed=1000 + rank)
+            # (every token keys about 1900 of these programs, 130 x the installs per event of the pipeline's rule set: shorter documents)
+            if args.docsize == 1000:
+                args.docsize = 200
+            lex, offs = synth.tree_documents(args.docs or 1024, args.docsize, 60, seed=1000 + rank)
         else:
             rules = synth.random_rules(args.rules, args.features, seed=2, op=(args.op or None))
             lex, offs = synth.random_documents(args.docs or 10000, args.docsize, args.features, seed=1000 + rank)
