@@ -987,6 +987,7 @@ template <bool LDS> __device__ __forceinline__ void stageTables( const L1Params&
 // long document use (F inside S, scanDocument); a lane whose proof fails sends the document to the sequential re-scan.  The
 // reports of a lane go to the lane's part of the unit's queue slice and are moved together at the end (lane order = offset order).
 __shared__ unsigned short laneCc[ 256];		// byte -> class | context << 8
+__shared__ uint4 laneText[ 4][ 8*64];		// per wave: the next 128 bytes of every lane's piece of the text
 template <int W>
 __device__ void scanUnitLanes( LexWave& w, const L1Params& P, const LexTab<true>& T, const u32 segBeg, const u32 segEnd)
 {
@@ -1065,21 +1066,40 @@ __device__ void scanUnitLanes( LexWave& w, const L1Params& P, const LexTab<true>
 			}
 		}
 	};
-	for (u32 i=b0; i<b1; i+=16)
+	// 128 bytes of my piece per refill, parked in LDS (a lane's loads are 512 bytes apart from its neighbours': read 16 bytes at
+	// a time straight from memory, every 128-byte line of the text came in eight times -- 11 GB of traffic for 0.8 GB of text)
+	uint4* park = laneText[ threadIdx.x >> 6] + LANE;		// [8][64]: block q of lane l at park[ q*64]
+	for (u32 i=b0; i<b1; i+=128)
 	{
-		uint4 v = make_uint4( 0,0,0,0);
-		if (i + 16u <= len) v = ld128u( w.doc + i);
-		else { u32 d[ 4] = {0,0,0,0}; for (u32 k=0; k<16u && i+k<len; ++k) d[ k>>2] |= (u32)w.doc[ i+k] << (8*(k&3u)); v = make_uint4( d[0], d[1], d[2], d[3]); }
-		const u32 vv[ 4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-		for (int k=0; k<16; ++k)
+#pragma unroll 1
+		for (u32 q=0; q<8u; ++q)
 		{
-			if (i + (u32)k < b1)
+			const u32 at = i + 16u*q;
+			if (at >= b1) break;
+			if (at + 16u <= len) park[ q*64] = ld128u( w.doc + at);
+			else
 			{
-				const u32 cc = laneCc[ (vv[ k>>2] >> (8*(k&3))) & 0xFFu];
-				emit( i + (u32)k, S, cc >> 8);			// matches that end before this byte
-				stepWords( S, cc & 0xFFu, prevctx, true);
-				prevctx = cc >> 8;
+				// (the document's last bytes: one at a time, nothing is read behind the text)
+				park[ q*64] = make_uint4( 0,0,0,0);
+				for (u32 k=0; k<16u && at+k<len; ++k) ((unsigned char*)&park[ q*64])[ k] = w.doc[ at+k];
+			}
+		}
+#pragma unroll 1
+		for (u32 q=0; q<8u && i + 16u*q < b1; ++q)
+		{
+			const uint4 v = park[ q*64];
+			const u32 vv[ 4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int k=0; k<16; ++k)
+			{
+				const u32 at = i + 16u*q + (u32)k;
+				if (at < b1)
+				{
+					const u32 cc = laneCc[ (vv[ k>>2] >> (8*(k&3))) & 0xFFu];
+					emit( at, S, cc >> 8);			// matches that end before this byte
+					stepWords( S, cc & 0xFFu, prevctx, true);
+					prevctx = cc >> 8;
+				}
 			}
 		}
 	}
