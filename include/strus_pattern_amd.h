@@ -315,6 +315,8 @@ int sp_lexer_ctx_last_kernel_ms_split(sp_lexer_ctx_t* c, double* scan_ms, double
 /* the same in three parts: automaton scan; words kernel (whole-word literals and word shapes, found where runs of word
  * characters end); start of match + handler + ordinal positions */
 int sp_lexer_ctx_last_kernel_ms_split3(sp_lexer_ctx_t* c, double* scan_ms, double* words_ms, double* post_ms);
+/* name of the scan kernel the last launch of this context went through ("(none)" before the first launch) */
+const char* sp_lexer_ctx_scan_kernel_name(const sp_lexer_ctx_t* c);
 int sp_lexer_ctx_reserve_output(sp_lexer_ctx_t* c, uint64_t lexems);
 int sp_lexer_ctx_grow_arena(sp_lexer_ctx_t* c);
 

@@ -456,6 +456,10 @@ class PatternLexerContext:
             raise PatternError("no timed launch")
         return a.value, b.value, d.value
 
+    def scanKernelName(self):
+        """the scan kernel the last launch went through"""
+        return self._L.sp_lexer_ctx_scan_kernel_name(self._h).decode()
+
     def reserveOutput(self, lexems):
         self._L.sp_lexer_ctx_reserve_output(self._h, lexems)
 

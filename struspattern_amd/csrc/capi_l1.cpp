@@ -14,6 +14,7 @@
 #include <vector>
 
 namespace spa {
+bool l1ScanByLanes( const L1Params& PS, const L1Params& P);
 hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned laneBlocks, unsigned wordBlocks, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords);
 }
 using namespace spa;
@@ -53,6 +54,7 @@ struct sp_lexer_ctx
 	uint64_t lexemCapacity, minLexemCapacity;
 	unsigned numCUs;
 	hipEvent_t evStart, evMid, evWords, evStop; bool evValid;
+	char scanKernel[ 48] = "(none)";
 	hipStream_t lastStream; size_t lastNdocs;
 	hipStream_t own;		// the context's own stream (non-blocking): the host-buffer entry points of different contexts -- one per host thread,
 				// the reference's threading model -- copy and launch side by side instead of queueing on the null stream
@@ -479,6 +481,10 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	unsigned laneBlocks = (unsigned)((maxUnits + 3) / 4 < (uint64_t)c->numCUs*4 ? (maxUnits + 3) / 4 : (uint64_t)c->numCUs*4);
 	if (laneBlocks == 0) laneBlocks = 1;
 	HIP_CHECK( launchL1Lex( PS, PW, P, nblocks, c->blockThreads, laneBlocks, wordBlocks, nwaves, stream, c->evMid, c->evWords));
+	if (P.nofApprox) std::snprintf( c->scanKernel, sizeof(c->scanKernel), "spa_l1_approx_kernel");
+	else if (l1ScanByLanes( PS, P)) std::snprintf( c->scanKernel, sizeof(c->scanKernel), "spa_l1_scan_lanes_kernel");
+	else if (PS.nofPasses == 0) std::snprintf( c->scanKernel, sizeof(c->scanKernel), "(none)");
+	else std::snprintf( c->scanKernel, sizeof(c->scanKernel), "spa_l1_scan_kernel_p%u", PS.nofPasses <= 8 ? PS.nofPasses : PS.nofPasses <= 16 ? 16u : 32u);
 	HIP_CHECK( hipEventRecord( c->evStop, stream));
 	c->evValid = true; c->lastStream = stream; c->lastNdocs = ndocs;
 }
@@ -544,6 +550,12 @@ int sp_lexer_ctx_last_kernel_ms_split( sp_lexer_ctx_t* c, double* scan_ms, doubl
 	if (hipEventElapsedTime( &b, c->evMid, c->evStop) != hipSuccess) return SP_ERR_INVALID;
 	*scan_ms = (double)a; *post_ms = (double)b;
 	return SP_OK;
+}
+
+// the scan kernel the last launch went through (bench.py prices and names the kernel that ran)
+const char* sp_lexer_ctx_scan_kernel_name( const sp_lexer_ctx_t* c)
+{
+	return c->scanKernel;
 }
 
 // the same with the words kernel on its own (round 3: automaton scan | literals + word shapes | start of match + handler + ordinal positions)

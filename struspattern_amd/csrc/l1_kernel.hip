@@ -2225,6 +2225,11 @@ extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_
 namespace spa {
 // PS: the parameters of the scan kernel (its table image holds the scanned passes only; nofPasses = 0: nothing to scan);
 // PW: of the words kernel (all passes, in LDS when they fit); P: of the other kernels (all passes, read from global memory)
+bool l1ScanByLanes( const L1Params& PS, const L1Params& P)
+{
+	return PS.nofPasses == 1 && PS.scanWords >= 1 && PS.scanWords <= 4 && PS.reportsOrdered && !P.cpBlocks && !P.nofNullable && PS.ldsWords && (size_t)PS.ldsWords * 8 <= 65536;
+}
+
 hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned laneBlocks, unsigned wordBlocks, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords)
 {
 	if (P.nofApprox)
@@ -2252,7 +2257,7 @@ hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& 
 	else { SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N, PS); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, PS); SPA_L1_LAUNCH_ONE( spa_l1_scan_kernel_##N##_ch, S); } } while (0)
 	// what is left to scan fits four automaton words: a lane per stream (scanUnitLanes); the documents a piece of which could not
 	// be joined go through the sequential pass of the one-pass instance behind it
-	const bool lanes = PS.nofPasses == 1 && PS.scanWords >= 1 && PS.scanWords <= 4 && PS.reportsOrdered && !P.cpBlocks && !P.nofNullable && PS.ldsWords && lds <= 65536;
+	const bool lanes = l1ScanByLanes( PS, P);
 	if (lanes)
 	{
 		hipLaunchKernelGGL( spa_l1_scan_lanes_kernel, dim3( laneBlocks), dim3( 256), lds, stream, PS);
