@@ -476,6 +476,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	if (wordBlocks == 0) wordBlocks = 1;
 	// (scanWords = 0 keeps the batch off the lane-per-stream scan kernel: an expression that can stay live across blanks would
 	//  fail the warm-up proof of most pieces, SPA_L1_NO_LANES: tests)
+	P.postClusters = getenv( "SPA_L1_POST_SEQ") ? 0u : 1u;		// (SPA_L1_POST_SEQ: tests and A/B runs, one report after the other)
 	P.scanWords = PS.scanWords = PW.scanWords = (c->wordsKernel && T.lanesOk && !getenv( "SPA_L1_NO_LANES")) ? T.scanWords : 0u;
 	// lane-per-stream scan kernel (a few automaton words left to scan): a wave per unit, workgroups of four waves
 	unsigned laneBlocks = (unsigned)((maxUnits + 3) / 4 < (uint64_t)c->numCUs*4 ? (maxUnits + 3) / 4 : (uint64_t)c->numCUs*4);

@@ -1657,6 +1657,272 @@ __device__ void postDocumentMerged( LexWave& w, const L1Params& P, const LexTab<
 	}
 }
 
+// ---------------------------------------------------------------- stage 3, a cluster of reports per lane (round 3)
+// The reference's handler (patternLexer.cpp:727-822) looks at its event array from the back only: the delete pass stops at the first event
+// that starts left of the new match, the ignore pass at the first that ends left of its end, the insertion at the first that does not
+// start right of it.  Take the reports in callback order r0 r1 ... and say there is a BOUNDARY before ri when every report from ri on
+// starts right of every earlier report's start and ends right of every earlier report's end: then none of the three scans of a report
+// behind the boundary ever gets past the events the reports behind the boundary have left -- the handler works on the events of its own
+// CLUSTER (the reports between two boundaries) as if the array began there, and what a cluster leaves is appended to the array as it is.
+// A window of 64 merged reports has its boundaries found with two prefix maxima and two suffix minima; every complete cluster of the
+// window is then run through the handler by ONE LANE on a little event array of its own in LDS, all clusters at once, and the survivors
+// are appended to the wave's event array with one prefix sum.  What the lanes cannot take goes through handleReport one report after
+// the other, as before: the reports in front of the window's first boundary (they may reach into the array), a cluster that leaves more
+// than LOC_CAP events or holds a symbol lookup, a cluster as long as the window.  The last cluster of a window waits for the next one
+// unless the input has ended (its last reports may still be to come).
+enum {WIN_CAP=192, LOC_CAP=6, REC_SYMBOL=1u<<16, REC_SIZEERR=1u<<31};
+
+__device__ __forceinline__ u32 waveSuffixMin( u32 v)		// inclusive, identity ~0
+{
+	u32 t;
+	t = (u32)__builtin_amdgcn_update_dpp( -1, (int)v, 0x101, 0xF, 0xF, false); v = t < v ? t : v;	// row_shl:1
+	t = (u32)__builtin_amdgcn_update_dpp( -1, (int)v, 0x102, 0xF, 0xF, false); v = t < v ? t : v;
+	t = (u32)__builtin_amdgcn_update_dpp( -1, (int)v, 0x104, 0xF, 0xF, false); v = t < v ? t : v;
+	t = (u32)__builtin_amdgcn_update_dpp( -1, (int)v, 0x108, 0xF, 0xF, false); v = t < v ? t : v;
+	const u32 m1 = (u32)__builtin_amdgcn_readlane( v, 16), m2 = (u32)__builtin_amdgcn_readlane( v, 32), m3 = (u32)__builtin_amdgcn_readlane( v, 48);
+	const u32 s2 = m2 < m3 ? m2 : m3, s1 = m1 < s2 ? m1 : s2;
+	const u32 behind = LANE < 16u ? s1 : (LANE < 32u ? s2 : (LANE < 48u ? m3 : ~0u));
+	return behind < v ? behind : v;
+}
+
+// the record of a resolved report as the handler takes it: {end, start, lexem id, level|posbind<<8|flags}, sub expression selection
+// applied (patternLexer.cpp:731-741); false: the report is dropped
+__device__ __forceinline__ bool preparedRecord( const LaneReport& lr, uint4& rec)
+{
+	u32 from = lr.from, to = lr.to;
+	u32 fl = lr.levelBind & 0x1FFFFu;
+	if (to - from >= 65535u) fl |= (u32)REC_SIZEERR;						// :727-730, raised when the handler gets there
+	bool live = !lr.skip;
+	if (lr.levelBind & (1u<<17))
+	{
+		if (lr.prefixLen + lr.suffixLen > to - from) live = (fl & (u32)REC_SIZEERR) != 0;
+		else { from += lr.prefixLen; to -= lr.suffixLen; }
+	}
+	rec = make_uint4( to, from, lr.id, fl);
+	return live;
+}
+
+// ranks of the live records of two sorted batches in their merge (keys are distinct: a pattern reports through one of the queues only)
+__device__ __forceinline__ void mergeRanks( u64 liveX, u32 xHi, u32 xLo, u32& rankX, bool isLiveY, u32 yHi, u32 yLo, u32& rankY)
+{
+	const u64 keyY = ((u64)yHi << 32) | yLo;
+	while (liveX)
+	{
+		const u32 x = (u32)__builtin_ctzll( liveX);
+		liveX &= liveX - 1;
+		const u64 kx = ((u64)(u32)__builtin_amdgcn_readlane( xHi, x) << 32) | (u32)__builtin_amdgcn_readlane( xLo, x);
+		const bool less = isLiveY && keyY < kx;
+		const u32 c = (u32)__builtin_popcountll( __ballot( less));
+		if (LANE == x) rankX += c;
+		if (isLiveY && !less) ++rankY;
+	}
+}
+
+template <bool LDS, bool CP, bool CH>
+__device__ void postDocumentClusters( LexWave& w, const L1Params& P, const LexTab<LDS>& T)
+{
+	__shared__ uint4 postWin[ 4][ WIN_CAP];
+	__shared__ uint4 postLoc[ 4][ LOC_CAP*64];
+	uint4* win = postWin[ (threadIdx.x >> 6) & 3u];
+	uint4* loc = postLoc[ (threadIdx.x >> 6) & 3u] + LANE;		// event j of this lane's cluster: loc[ 64*j]
+	ReportStream A, B;
+	A.unit = w.unit0; B.unit = w.unit0;
+	A.lr.to = 0; A.lr.from = 0; A.lr.id = 0; A.lr.levelBind = 0; A.lr.prefixLen = 0; A.lr.suffixLen = 0; A.lr.pi = 0; A.lr.def = 0; A.lr.skip = 0;
+	B.lr = A.lr;
+	streamSlice<LDS,CP,CH,false>( A, w, P); streamFill<LDS,CP,CH,false>( A, w, P, T);
+	streamSlice<LDS,CP,CH,true>( B, w, P); streamFill<LDS,CP,CH,true>( B, w, P, T);
+	u32 wi = 0, wn = 0;			// the window: win[ wi .. wn)
+	u32 carryF = 0, carryT = 0;		// 1 + the greatest start / end of the reports handled so far (0: none)
+	bool exhausted = false;
+	const u64 NOKEY = ~0ull;
+	auto sequential = [&]( const uint4& rec, u32 s, u32 e)
+	{
+		if (w.cnt == 0 && w.nEvents) { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront"); reloadLanes( w); readTail( w); }
+		for (u32 x=s; x<e && !w.err; ++x)
+		{
+			const u32 fl = (u32)__builtin_amdgcn_readlane( rec.w, x);
+			if (fl & (u32)REC_SIZEERR) { w.err = L1D_ERR_LEXEMSIZE; break; }
+			handleReport( w, P, (u32)__builtin_amdgcn_readlane( rec.z, x), fl & 0x1FFFFu, 0, 0, (u32)__builtin_amdgcn_readlane( rec.y, x), (u32)__builtin_amdgcn_readlane( rec.x, x));
+		}
+	};
+	while (!w.err)
+	{
+		// ---- refill: what is left of the window moves to its front, the next records of the two queues are merged in behind it
+		while (wn - wi < 64u && !exhausted)
+		{
+			const bool haveA = A.qi < A.nq, haveB = B.qi < B.nq;
+			if (!haveA && !haveB) { exhausted = true; break; }
+			const u32 left = wn - wi;
+			uint4 keep = make_uint4( 0, 0, 0, 0);
+			if (LANE < left) keep = win[ wi + LANE];
+			const u32 xa = A.qi - A.qb, xb = B.qi - B.qb;
+			// nothing behind a batch's last key is known yet: records up to the smaller of the two last keys are taken
+			u64 limit = NOKEY;
+			if (haveA && (A.qb + A.qn < A.nq || (CH && A.unit + 1u < w.unitEnd)))
+				limit = ((u64)(u32)__builtin_amdgcn_readlane( A.lr.to, A.qn-1) << 32) | (u32)__builtin_amdgcn_readlane( A.lr.pi, A.qn-1);
+			if (haveB && (B.qb + B.qn < B.nq || (CH && B.unit + 1u < w.unitEnd)))
+			{
+				const u64 lb = ((u64)(u32)__builtin_amdgcn_readlane( B.lr.to, B.qn-1) << 32) | (u32)__builtin_amdgcn_readlane( B.lr.pi, B.qn-1);
+				if (lb < limit) limit = lb;
+			}
+			const bool takeA = haveA && LANE >= xa && LANE < A.qn && ((((u64)A.lr.to << 32) | A.lr.pi) <= limit);
+			const bool takeB = haveB && LANE >= xb && LANE < B.qn && ((((u64)B.lr.to << 32) | B.lr.pi) <= limit);
+			uint4 recA, recB;
+			const bool liveA = preparedRecord( A.lr, recA) && takeA, liveB = preparedRecord( B.lr, recB) && takeB;
+			const u64 liveAm = __ballot( liveA), liveBm = __ballot( liveB);
+			u32 rankA = (u32)__builtin_amdgcn_mbcnt_hi( (u32)(liveAm >> 32), __builtin_amdgcn_mbcnt_lo( (u32)liveAm, 0));
+			u32 rankB = (u32)__builtin_amdgcn_mbcnt_hi( (u32)(liveBm >> 32), __builtin_amdgcn_mbcnt_lo( (u32)liveBm, 0));
+			if (liveAm && liveBm)
+			{
+				if (__builtin_popcountll( liveAm) <= __builtin_popcountll( liveBm)) mergeRanks( liveAm, A.lr.to, A.lr.pi, rankA, liveB, B.lr.to, B.lr.pi, rankB);
+				else mergeRanks( liveBm, B.lr.to, B.lr.pi, rankB, liveA, A.lr.to, A.lr.pi, rankA);
+			}
+			__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+			if (LANE < left) win[ LANE] = keep;
+			if (liveA) win[ left + rankA] = recA;
+			if (liveB) win[ left + rankB] = recB;
+			__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+			wi = 0; wn = left + (u32)__builtin_popcountll( liveAm) + (u32)__builtin_popcountll( liveBm);
+			const u32 tookA = (u32)__builtin_popcountll( __ballot( takeA)), tookB = (u32)__builtin_popcountll( __ballot( takeB));
+			if (tookA) { A.qi += tookA; if (A.qi == A.qb + A.qn || A.qi == A.nq) streamFill<LDS,CP,CH,false>( A, w, P, T); }
+			if (tookB) { B.qi += tookB; if (B.qi == B.qb + B.qn || B.qi == B.nq) streamFill<LDS,CP,CH,true>( B, w, P, T); }
+			if (!tookA && !tookB) { w.err = L1D_ERR_INTERNAL; break; }
+		}
+		if (w.err) break;
+		const u32 avail = (wn - wi) < 64u ? (wn - wi) : 64u;
+		if (!avail) break;
+		const bool valid = LANE < avail;
+		uint4 rec = make_uint4( 0, 0, 0, 0);
+		if (valid) rec = win[ wi + LANE];
+		// ---- boundaries
+		const u32 inclF = waveScanMax( valid ? rec.y + 1u : 0u), inclT = waveScanMax( valid ? rec.x + 1u : 0u);
+		u32 exclF = laneFromBelow( inclF), exclT = laneFromBelow( inclT);
+		exclF = exclF > carryF ? exclF : carryF; exclT = exclT > carryT ? exclT : carryT;
+		const u32 sufF = waveSuffixMin( valid ? rec.y + 1u : ~0u), sufT = waveSuffixMin( valid ? rec.x + 1u : ~0u);
+		const u64 bounds = __ballot( valid && sufF > exclF && sufT > exclT);
+		const u32 first = bounds ? (u32)__builtin_ctzll( bounds) : 64u;
+		auto carryTo = [&]( u32 upTo)		// the reports [0, upTo) of the view are done
+		{
+			if (!upTo) return;
+			const u32 f = (u32)__builtin_amdgcn_readlane( inclF, upTo-1), t = (u32)__builtin_amdgcn_readlane( inclT, upTo-1);
+			carryF = f > carryF ? f : carryF; carryT = t > carryT ? t : carryT;
+		};
+		if (first)
+		{
+			// the reports in front of the first boundary may reach into the array
+			const u32 e = first < avail ? first : avail;
+			sequential( rec, 0, e);
+			carryTo( e); wi += e;
+			continue;
+		}
+		const bool final = exhausted && avail == wn - wi;
+		const u32 lastB = 63u - (u32)__builtin_clzll( bounds);
+		const u32 procEnd = final ? avail : lastB;
+		if (procEnd == 0)
+		{
+			// one cluster as long as the view
+			sequential( rec, 0, avail);
+			carryTo( avail); wi += avail;
+			continue;
+		}
+		// ---- every complete cluster through the handler, one lane each
+		const bool head = ((bounds >> LANE) & 1ull) != 0 && LANE < procEnd;
+		u32 len = 0;
+		{
+			const u64 above = (bounds >> LANE) >> 1;
+			const u32 nextB = above ? LANE + 1u + (u32)__builtin_ctzll( above) : 64u;
+			len = (nextB < procEnd ? nextB : procEnd) - LANE;
+		}
+		u32 n = 0;
+		bool hard = false;
+		for (u32 k=0; __ballot( head && !hard && k < len) != 0; ++k)
+		{
+			if (head && !hard && k < len)
+			{
+				const uint4 r = win[ wi + LANE + k];
+				if (r.w & ((u32)REC_SYMBOL | (u32)REC_SIZEERR)) hard = true;
+				else
+				{
+					const u32 level = r.w & 0xFFu, from = r.y, lastPos = r.x;
+					u32 nofDeletes = 0;
+					// delete pass (:757-777)
+					for (u32 q=n; q>0; --q)
+					{
+						const uint4 m = loc[ 64*(q-1)];
+						if (!(m.y >= from)) break;
+						const u32 mlevel = m.w & 0xFFu;
+						if ((r.z == m.x && m.y == from && mlevel == level) || (mlevel < level && m.y + m.z <= lastPos))
+						{
+							for (u32 t=q-1; t+1<n; ++t) loc[ 64*t] = loc[ 64*(t+1)];
+							--n; ++nofDeletes;
+						}
+					}
+					bool ignored = false;
+					if (!nofDeletes)
+					{
+						// ignore pass (:778-792)
+						for (u32 q=n; q>0; --q)
+						{
+							const uint4 m = loc[ 64*(q-1)];
+							if (!(m.y + m.z >= lastPos)) break;
+							if ((m.w & 0xFFu) > level && m.y <= from) { ignored = true; break; }
+						}
+					}
+					if (!ignored)
+					{
+						if (n == (u32)LOC_CAP) hard = true;
+						else
+						{
+							// insert (:793-822)
+							u32 at = n;
+							for (; at>0; --at)
+							{
+								const uint4 m = loc[ 64*(at-1)];
+								if (!(m.y > from)) break;
+								loc[ 64*at] = m;
+							}
+							loc[ 64*at] = make_uint4( r.z, from, lastPos - from, r.w & 0xFFFFu);
+							++n;
+						}
+					}
+				}
+			}
+		}
+		const u64 hardm = __ballot( head && hard);
+		const u32 firstHard = hardm ? (u32)__builtin_ctzll( hardm) : 64u;
+		// ---- what the clusters in front of the first one that has to go the slow way have left is appended
+		const bool mine = head && LANE < firstHard;
+		const u32 cnt = mine ? n : 0u;
+		const u32 incl = waveScanAdd( cnt);
+		const u32 total = (u32)__builtin_amdgcn_readlane( incl, 63);
+		if (w.nEvents + total + 2u > P.eventCap)
+		{
+			if (LANE == 0) atomicAdd( (unsigned long long*)&P.counters[ L1C_OVER_EVENTS], 1ull);
+			w.err = L1D_ERR_ARENA; break;
+		}
+		if (total)
+		{
+			if (w.cnt) spillLanes( w, 0);
+			uint4* dst = (uint4*)w.events + w.nEvents + (incl - cnt);
+			for (u32 j=0; j<(u32)LOC_CAP; ++j)
+			{
+				if (j < cnt) dst[ j] = loc[ 64*j];
+			}
+			w.nEvents += total;
+		}
+		if (firstHard < 64u)
+		{
+			const u32 hlen = (u32)__builtin_amdgcn_readlane( len, firstHard);
+			if (total) __builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront");
+			carryTo( firstHard);
+			sequential( rec, firstHard, firstHard + hlen);
+			carryTo( firstHard + hlen); wi += firstHard + hlen;
+		}
+		else { carryTo( procEnd); wi += procEnd; }
+	}
+	if (!w.err && (A.qi != A.nq || B.qi != B.nq)) w.err = L1D_ERR_INTERNAL;
+}
+
 // ---------------------------------------------------------------- stage 4: ordinal positions + output (:893-945)
 // The reference walks the sorted event array once with a little state machine (patternLexer.cpp:893-945):
 // up to the first content/unique event only successor-bound events are kept (position 1); from there on
@@ -2156,7 +2422,8 @@ __device__ void postDocuments( const L1Params& P)
 		w.nEvents = 0; w.err = 0; w.cnt = 0; w.tailPos = 0; w.tailEnd = 0;
 		w.e.id = 0; w.e.pos = 0; w.e.size = 0; w.e.lb = 0;
 		const u64 tDoc = PROF_T();
-		if (!CP && P.wordsKernel) postDocumentMerged<LDS,CP,CH>( w, P, T);
+		if (!CP && P.wordsKernel && P.postClusters) postDocumentClusters<LDS,CP,CH>( w, P, T);
+		else if (!CP && P.wordsKernel) postDocumentMerged<LDS,CP,CH>( w, P, T);
 		else
 		{
 			sliceOf( w, P);
@@ -2218,8 +2485,10 @@ enum {POST_WAVES=4};
 #define SPA_L1_POST_WAVES_PER_EU 6
 #endif
 #define SPA_L1_POST_OCC __attribute__((amdgpu_waves_per_eu( SPA_L1_POST_WAVES_PER_EU, SPA_L1_POST_WAVES_PER_EU)))
-extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel( L1Params P) { postDocuments<false,false,false>( P); }
-extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel_ch( L1Params P) { postDocuments<false,false,true>( P); }
+// (the two instances with the cluster-per-lane handler hold 9 KB of LDS per wave: 16 waves per CU)
+#define SPA_L1_POST_OCC4 __attribute__((amdgpu_waves_per_eu( 4, 4)))
+extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC4 void spa_l1_post_kernel( L1Params P) { postDocuments<false,false,false>( P); }
+extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC4 void spa_l1_post_kernel_ch( L1Params P) { postDocuments<false,false,true>( P); }
 extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel_cp( L1Params P) { postDocuments<false,true,true>( P); }
 
 namespace spa {
