@@ -386,3 +386,70 @@ def test_edge_cases_empty_documents_and_errors():
     lx2.defineLexem(1, "a", 0, 1, "content")
     with pytest.raises(spa.PatternError):
         lx2.createContext()
+
+
+# The handler of the post-processing kernel takes a cluster of reports per lane (postDocumentClusters); this set makes the cases it
+# hands back to the one-report-after-the-other path: more survivors on one word than a lane's event array holds, symbol lookups,
+# chains of two-word matches that tie a whole line into one cluster, sub expression selection that moves the end of a match.
+@pytest.mark.parametrize("mode", ["clusters", "sequential", "clusters-chunked"])
+def test_handler_clusters_against_the_oracle(mode, monkeypatch):
+    if mode == "sequential":
+        monkeypatch.setenv("SPA_L1_POST_SEQ", "1")
+    if mode == "clusters-chunked":
+        monkeypatch.setenv("SPA_L1_CHUNK_BYTES", "1024")
+    rng = random.Random(99)
+    words = ["banana", "bandana", "cabana", "aa", "ab", "nab", "bank", "an", "na", "ana", "band", "a", "b", "kab", "abba", "nanana"]
+    posbinds = ["content", "content", "content", "predecessor", "successor", "unique"]
+
+    def build(x):
+        x.defineOption("DOTALL")
+        lid = 1
+        # every prefix and suffix shape of "banana" at one level: seven and more events survive on that word
+        for k in range(1, 6):
+            x.defineLexem(lid, "\\b%s[a-z]*\\b" % "banana"[:k], 0, 2, "content"); lid += 1
+            x.defineLexem(lid, "[a-z]+%s\\b" % "banana"[-k:], 0, 2, "content"); lid += 1
+        r = random.Random(7)
+        for w in words:
+            x.defineLexem(lid, "\\b%s\\b" % w, 0, r.randint(1, 4), r.choice(posbinds)); lid += 1
+        for w in ("aa", "ab", "an", "banana"):
+            x.defineLexem(lid, "\\b%s\\s\\w+\\b" % w, 0, r.randint(1, 4), r.choice(posbinds)); lid += 1
+        for suf in ("b", "na", "nd", "k"):
+            x.defineLexem(lid, "[a-z]+%s\\b" % suf, 0, r.randint(1, 4), r.choice(posbinds)); lid += 1
+        for pre in ("ca", "n", "ab"):
+            x.defineLexem(lid, "\\b%s[a-z]*\\b" % pre, 0, r.randint(1, 4), r.choice(posbinds)); lid += 1
+        x.defineLexem(lid, "[a-z]+[.][a-z]+", 0, 3, "content"); lid += 1          # (automaton queue)
+        x.defineLexem(lid, "[0-9]+", 0, 1, "successor"); lid += 1
+        x.defineLexem(lid, "\\b(x)([a-z]+)(y)\\b", 2, 2, "content"); lid += 1      # sub expression selection
+        x.defineLexem(lid, "\\b\\w+\\b", 0, 1, "content")
+        x.defineSymbol(900, lid, "bank")
+        x.defineSymbol(901, lid, "aa")
+        x.compile()
+    lx, o = _both(build)
+    docs = []
+    for d in range(40):
+        toks = []
+        for _ in range(rng.randint(0, 260)):
+            u = rng.random()
+            if u < 0.75:
+                toks.append(rng.choice(words))
+            elif u < 0.80:
+                toks.append(str(rng.randint(0, 999)))
+            elif u < 0.85:
+                toks.append("x" + rng.choice(words) + "y")
+            elif u < 0.90:
+                toks.append(rng.choice(words) + "." + rng.choice(words))
+            else:
+                toks.append("aa " * rng.randint(2, 90))               # (one cluster longer than a window)
+            toks.append(rng.choice([" ", " ", " ", ". ", "\n", ", "]))
+        docs.append("".join(toks).encode())
+    docs.append(("aa " * 6000).encode())
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
+    text = b"".join(docs)
+    ctx = lx.createContext()
+    gpu = ctx.matchDocs(text, offs)
+    assert ctx.batchCounters()["word_reports"] > 1000
+    ref, roffs = o.matchDocs(text, offs, nthreads=8)
+    assert len(ref) > 5000
+    assert np.array_equal(gpu.status, np.zeros(len(docs), np.int32))
+    assert np.array_equal(gpu.doc_offsets, roffs)
+    assert np.array_equal(gpu.lexems, ref)
