@@ -471,8 +471,8 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	if (PS.nofPasses == 0) HIP_CHECK( hipMemsetAsync( c->dReportCount.ptr, 0, (maxUnits+1)*sizeof(uint32_t), stream));
 	// words kernel: a wave per unit, workgroups of 16 waves that share one LDS copy of the image of all passes when it fits
 	L1Params PW = P;
-	PW.ldsWords = ((size_t)c->imgWords*8 <= 140*1024 && T.nofShapes) ? c->imgWords : 0u;
-	unsigned wordBlocks = (unsigned)((maxUnits + 15) / 16 < (uint64_t)c->numCUs ? (maxUnits + 15) / 16 : (uint64_t)c->numCUs);
+	PW.ldsWords = ((size_t)c->imgWords*8 + L1_WORDS_STATIC_LDS <= 160*1024 && T.nofShapes) ? c->imgWords : 0u;
+	unsigned wordBlocks = (unsigned)((maxUnits + L1_WORD_WAVES-1) / L1_WORD_WAVES < (uint64_t)c->numCUs ? (maxUnits + L1_WORD_WAVES-1) / L1_WORD_WAVES : (uint64_t)c->numCUs);
 	if (wordBlocks == 0) wordBlocks = 1;
 	// (scanWords = 0 keeps the batch off the lane-per-stream scan kernel: an expression that can stay live across blanks would
 	//  fail the warm-up proof of most pieces, SPA_L1_NO_LANES: tests)

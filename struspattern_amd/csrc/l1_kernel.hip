@@ -1213,9 +1213,14 @@ __device__ __forceinline__ u32 runStartBefore( const L1Params& P, const unsigned
 // The backward walk of leftmostStart for a candidate of the words kernel: class and context of the bytes it visits come from the
 // wave's ring in LDS (the last 128 bytes of the text, written a tile at a time), the automaton's rows from the LDS image -- two
 // LDS round trips per byte instead of four dependent global loads.  A walk that leaves the ring goes on with leftmostStart.
-enum {WORD_RING=128, WORD_WAVES=16};
+enum {WORD_RING=512, WORD_WAVES=L1_WORD_WAVES, WORD_ENDS=96, WORD_ENDWORDS=5};
 __shared__ unsigned short wordRing[ WORD_WAVES][ WORD_RING];
-__shared__ uint4 wordStage[ WORD_WAVES][ 64];		// the candidates of a tile {end offset, pattern | L1_LITERAL_FLAG for a literal, start of a literal, -}: a lane each for the walks
+// the run ends that wait for their probes, {end offset, start of the run, hash of the run, hash of the word before it, length | length of
+// the word before << 8} each; while a batch of them is worked on (they are in registers then) the first 1 KB holds the candidates
+// {end offset, pattern | L1_LITERAL_FLAG for a literal, start of the run, -}: a lane each for the walks
+__shared__ __attribute__((aligned(16))) u32 wordEnds[ WORD_WAVES][ WORD_ENDS*WORD_ENDWORDS];
+static_assert( sizeof(wordRing) + sizeof(wordEnds) <= L1_WORDS_STATIC_LDS, "static LDS of the words kernel");
+static_assert( 64*WORD_ENDWORDS*4 >= 64*16, "the candidates lie over the ends of the batch");
 template <bool LDS>
 __device__ __forceinline__ u32 confirmWalk( const unsigned char* doc, u32 docLen, const L1Params& P, const LexTab<LDS>& T, const unsigned short* ring, u32 ringLo,
 					    u32 word, u64 mask, u32 to)
@@ -1254,11 +1259,226 @@ __device__ __forceinline__ u32 confirmWalk( const unsigned char* doc, u32 docLen
 	return from;
 }
 
+// One batch of up to 64 run ends, a lane each: literal probe, shape probes, the candidates ordered by (end offset, pattern) into the
+// unit's queue, every candidate that is not a literal confirmed by a backward walk on a lane of its own (64 candidates a round).
 template <bool LDS>
-__device__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, const u32 segBeg, const u32 segEnd)
+__device__ __forceinline__ void wordsFlush( LexWave& w, const L1Params& P, const LexTab<LDS>& T, const unsigned short* ring, const u32 ringLo, u32* ends, const u32 count, const u32 nVar)
 {
 	const u32 len = w.docLen;
-	unsigned short* ring = wordRing[ (threadIdx.x >> 6) & (WORD_WAVES-1)];
+	const bool emit = LANE < count;
+	u32 to = 0, pFrom = 0, pH = 0, qH = 0, pLen = 0, qLen = 0;
+	if (emit)
+	{
+		const u32* e = ends + WORD_ENDWORDS*LANE;
+		to = e[ 0]; pFrom = e[ 1]; pH = e[ 2]; qH = e[ 3];
+		const u32 l = e[ 4]; pLen = l & 0xFFu; qLen = l >> 8;
+	}
+	__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");		// (the candidates overwrite the batch from here on)
+	// ---- candidates of my end offset: lists of patterns, ascending each
+	enum {NLIST=SHAPE_MAXVARIANTS+1};
+	u32 lb[ NLIST], lc[ NLIST];
+#pragma unroll
+	for (int k=0; k<NLIST; ++k) { lb[ k] = 0; lc[ k] = 0; }
+	u32 total = 0, lit0 = 0;
+	if (emit)
+	{
+		if (P.nofLiterals && pLen <= 64u)
+		{
+			// whole-word literal (the probe of tileLiterals)
+			const u32 h = literalHashFinish( pH);
+			u32 slot = h & P.literalMask;
+			uint4 dw = make_uint4( 0, 0, 0, 0);
+			if (pFrom + 16u <= len) dw = ld128u( w.doc + pFrom);
+			else
+			{
+				u32 d[ 4] = {0,0,0,0};
+				for (u32 q=0; q<16u && pFrom+q<len; ++q) d[ q>>2] |= (u32)w.doc[ pFrom + q] << (8*(q&3u));
+				dw = make_uint4( d[0], d[1], d[2], d[3]);
+			}
+			const u32 m0 = pLen >= 4u ? 0xFFFFFFFFu : ((1u << (8*pLen)) - 1u);
+			const u32 m1 = pLen >= 8u ? 0xFFFFFFFFu : (pLen > 4u ? ((1u << (8*(pLen-4u))) - 1u) : 0u);
+			const u32 m2 = pLen >= 12u ? 0xFFFFFFFFu : (pLen > 8u ? ((1u << (8*(pLen-8u))) - 1u) : 0u);
+			const u32 m3 = pLen >= 16u ? 0xFFFFFFFFu : (pLen > 12u ? ((1u << (8*(pLen-12u))) - 1u) : 0u);
+			for (u32 probes=0; probes<=P.literalMask; ++probes)
+			{
+				const uint4* ep = (const uint4*)&P.literals[ slot];
+				const uint4 e0 = ep[ 0], e1 = ep[ 1], tx = ep[ 2];
+				if (!e0.x) break;
+				if (e0.x == h && e0.y == pLen)
+				{
+					bool same = (((dw.x ^ tx.x) & m0) | ((dw.y ^ tx.y) & m1) | ((dw.z ^ tx.z) & m2) | ((dw.w ^ tx.w) & m3)) == 0;
+					for (u32 k=16; k<pLen && same; k+=4)
+					{
+						const u32 rem = pLen - k;
+						u32 a;
+						if (pFrom + k + 4u <= len) a = ld32u( w.doc + pFrom + k);
+						else { a = 0; for (u32 q=0; q<rem && q<4u; ++q) a |= (u32)w.doc[ pFrom + k + q] << (8*q); }
+						const u32 b = ld32u( P.literalText + e1.w + k);
+						const u32 mask = rem >= 4u ? 0xFFFFFFFFu : ((1u << (8*rem)) - 1u);
+						same = ((a ^ b) & mask) == 0;
+					}
+					if (same) { lb[ 0] = e0.z; lc[ 0] = e0.w; lit0 = e1.x; break; }
+				}
+				slot = (slot+1) & P.literalMask;
+			}
+		}
+	}
+	// ---- shape variants: the key bytes come out of two unaligned words of the text (the run's first four bytes, its last
+	// four); the compact table (fingerprint, pattern or list) sits in LDS beside the automaton tables: no global round trip
+	if (nVar)
+	{
+		u32 first4 = 0, last4 = 0;
+		if (emit)
+		{
+			if (pFrom + 4u <= len) first4 = ld32u( w.doc + pFrom); else for (u32 i=0; i<4u && pFrom+i<len; ++i) first4 |= (u32)w.doc[ pFrom+i] << (8*i);
+			if (to >= 4u) last4 = ld32u( w.doc + to - 4u); else for (u32 i=0; i<to; ++i) last4 |= (u32)w.doc[ i] << (8*(4u-to+i));
+		}
+#pragma unroll
+		for (int v=0; v<SHAPE_MAXVARIANTS; ++v)
+		{
+			if ((u32)v < nVar)
+			{
+				const u32 var = uni( P.shapeVariants[ v]);
+				const u32 kind = var & 3u, o = (var >> 2) & 3u, k = (var >> 4) & 7u;
+				const u32 kmask = k >= 4u ? 0xFFFFFFFFu : ((1u << (8*k)) - 1u);
+				if (emit)
+				{
+					u32 tag = 0, key = 0;
+					if (kind == (u32)SHAPE_PREVWORD) { if (qLen >= 1u && qLen <= 64u) { tag = (u32)SHAPE_PREVWORD | (qLen << 8); key = literalHashFinish( qH); } }
+					else if (kind == (u32)SHAPE_PREFIX)
+					{
+						if (pLen >= o + k)
+						{
+							tag = var;
+							if (o + k <= 4u) key = (first4 >> (8*o)) & kmask;
+							else for (u32 i=0; i<k; ++i) key |= (u32)w.doc[ pFrom + o + i] << (8*i);
+						}
+					}
+					else if (pLen >= k) { tag = var; key = k >= 4u ? last4 : (last4 >> (8*(4u-k))); }
+					if (tag)
+					{
+						const u32 fp = shapeFingerprint( tag, key, P.shapeSalt);
+						u32 slot = shapeSlotHash( tag, key) & P.shapeMask;
+						for (u32 probes=0; probes<=P.shapeMask; ++probes)
+						{
+							const u64 e = T.at( P.shapeFpOffset + slot);		// fingerprint | (count << 24 | pattern or list) << 32
+							if (!(u32)e) break;
+							if ((u32)e == fp) { lb[ 1+v] = (u32)(e >> 32) & 0xFFFFFFu; lc[ 1+v] = (u32)(e >> 56); break; }
+							slot = (slot+1) & P.shapeMask;
+						}
+					}
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int k=0; k<NLIST; ++k) total += lc[ k];
+	// ---- every lane reserves its records; 64 candidates a round get a lane each for the walk that confirms them
+	const u32 incl = waveScanAdd( total);
+	const u32 waveTotal = (u32)__builtin_amdgcn_readlane( incl, 63);
+	if (!waveTotal) return;
+	if (w.nQueue + waveTotal > w.queueCap) { w.err = L1D_ERR_ARENA; return; }
+	uint4* stage = (uint4*)ends;
+	// The usual lane: no list longer than one pattern, no more than four candidates.  Then its candidates are a handful of keys
+	// (pattern << 1 | literal) in registers, ordered by a five-comparator network; the others merge their lists by pattern index.
+	bool simple = total <= 4u;
+#pragma unroll
+	for (int k=0; k<NLIST; ++k) if (lc[ k] > 1u) simple = false;
+	u32 c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu, c3 = 0xFFFFFFFFu;
+	u32 head[ NLIST];
+	if (simple)
+	{
+		u32 nc = 0;
+#pragma unroll
+		for (int k=0; k<NLIST; ++k)
+		{
+			if (lc[ k])
+			{
+				const u32 key = k == 0 ? ((lit0 << 1) | 1u) : (lb[ k] << 1);
+				c0 = nc == 0 ? key : c0; c1 = nc == 1 ? key : c1; c2 = nc == 2 ? key : c2; c3 = nc == 3 ? key : c3;
+				++nc;
+			}
+		}
+#define SPA_CSWAP( A, B) { const u32 lo = A < B ? A : B, hi = A < B ? B : A; A = lo; B = hi; }
+		SPA_CSWAP( c0, c1) SPA_CSWAP( c2, c3) SPA_CSWAP( c0, c2) SPA_CSWAP( c1, c3) SPA_CSWAP( c1, c2)
+#undef SPA_CSWAP
+	}
+	const bool anyGeneral = __ballot( !simple && total) != 0;
+	if (anyGeneral)
+	{
+#pragma unroll
+		for (int k=0; k<NLIST; ++k)
+		{
+			head[ k] = 0xFFFFFFFFu;
+			if (!simple && lc[ k]) head[ k] = k == 0 ? lit0 : (lc[ k] == 1u ? lb[ k] : P.shapePats[ lb[ k]]);	// (a shape entry of one pattern holds the pattern in place of the list)
+		}
+	}
+	const u32 base = incl - total;
+	u32 produced = 0;
+	for (u32 r0=0; r0<waveTotal; r0+=64)
+	{
+		while (produced < total && base + produced < r0 + 64u)
+		{
+			u32 cand;
+			if (simple)
+			{
+				const u32 key = produced == 0 ? c0 : (produced == 1 ? c1 : (produced == 2 ? c2 : c3));
+				cand = (key >> 1) | ((key & 1u) ? (u32)L1_LITERAL_FLAG : 0u);
+			}
+			else
+			{
+				u32 best = 0xFFFFFFFFu; int which = 0;
+#pragma unroll
+				for (int k=0; k<NLIST; ++k) if (head[ k] < best) { best = head[ k]; which = k; }
+#pragma unroll
+				for (int k=0; k<NLIST; ++k)
+				{
+					if (k == which)
+					{
+						if (k != 0 && lc[ k] == 1u) { lc[ k] = 0; head[ k] = 0xFFFFFFFFu; }
+						else
+						{
+							++lb[ k]; --lc[ k];
+							head[ k] = lc[ k] ? (k == 0 ? P.litPats[ lb[ 0]] : P.shapePats[ lb[ k]]) : 0xFFFFFFFFu;
+						}
+					}
+				}
+				cand = which == 0 ? (best | (u32)L1_LITERAL_FLAG) : best;
+			}
+			stage[ base + produced - r0] = make_uint4( to, cand, pFrom, 0u);
+			++produced;
+		}
+		__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+		const u32 nr = (waveTotal - r0) < 64u ? (waveTotal - r0) : 64u;
+		if (LANE < nr)
+		{
+			const uint4 cnd = stage[ LANE];
+			u32 fromOut = cnd.z, flags = (u32)L1_LITERAL_FLAG;
+			const u32 pi = cnd.y & ~(u32)L1_LITERAL_FLAG;
+			if (!(cnd.y & (u32)L1_LITERAL_FLAG))
+			{
+				const uint2 pw = *(const uint2*)((const u32*)&P.patterns[ pi] + 5);	// {maskLo, maskHi}
+				const u32 word = ((const u32*)&P.patterns[ pi])[ 1];
+				fromOut = confirmWalk<LDS>( w.doc, len, P, T, ring, ringLo, word, ((u64)pw.y << 32) | pw.x, cnd.x);
+				if (fromOut == cnd.x) flags |= (u32)L1_DEAD_FLAG;
+			}
+			*(uint4*)(w.queue + 4*(u64)(w.nQueue + r0 + LANE)) = make_uint4( cnd.x, pi | flags, fromOut, 0u);
+		}
+		__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+	}
+	w.nQueue += waveTotal;
+}
+
+// The runs of word characters of a unit, a lane per byte: where a run ends the lane knows the run's start, length and hash and those of
+// the word before it.  Only one byte in six ends a run, so the ends are collected -- up to 64 of them, over several tiles -- before
+// they are probed with a lane each (wordsFlush).
+template <bool LDS>
+__device__ __forceinline__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, const u32 segBeg, const u32 segEnd)
+{
+	const u32 len = w.docLen;
+	const u32 wv = uni( threadIdx.x >> 6);
+	unsigned short* ring = wordRing[ wv];
+	u32* ends = wordEnds[ wv];
 	u32 ctxReg = 0, clsReg = 0;		// byte -> context, class: lane l keeps the entries of bytes 4l..4l+3
 	for (u32 k=0; k<4; ++k) { const u32 cl = P.byteClass[ 4*LANE + k]; clsReg |= cl << (8*k); ctxReg |= (u32)P.classCtx[ cl] << (8*k); }
 	auto isWordAt = [&]( u32 pos) -> bool { return P.classCtx[ P.byteClass[ uni( (u32)w.doc[ pos])]] == (u32)CTX_WORD; };
@@ -1269,17 +1489,17 @@ __device__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, 
 	if (w0 >= 2 && isWordAt( w0-2)) w0 = runStartBefore( P, w.doc, w0-1, ctxReg);
 	WordCarry c; c.in = false; c.hash = 0; c.len = 0; c.start = 0; c.lastValid = false; c.lastTo = 0; c.lastHash = 0; c.lastLen = 0;
 	const u32 nVar = uni( P.nofShapeVariants);
+	u32 nEnds = 0, firstTile = 0;		// ends that wait, the tile the oldest of them was seen in
 	u32 ahead = (w0 + LANE < len) ? (u32)w.doc[ w0 + LANE] : 0u;
-	for (u32 tile=w0; tile<=len && tile<=segEnd && !w.err; tile+=64)
+	u32 tile = w0;
+	for (; tile<=len && tile<=segEnd && !w.err; tile+=64)
 	{
 		const u32 inTile = (len - tile) < 64 ? (len - tile) : 64;
 		const u32 mine = ahead;			// (the next tile's bytes are requested one tile ahead)
 		ahead = (tile + 64u + LANE < len) ? (u32)w.doc[ tile + 64u + LANE] : 0u;
 		const u32 ctxL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)ctxReg) >> ((mine & 3u)*8)) & 0xFFu;
 		const u32 clsL = ((u32)__builtin_amdgcn_ds_bpermute( (int)((mine >> 2) << 2), (int)clsReg) >> ((mine & 3u)*8)) & 0xFFu;
-		ring[ (tile + LANE) & (WORD_RING-1)] = (unsigned short)(clsL | (ctxL << 8));		// (the ring keeps this tile and the one before it)
-		__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
-		const u32 ringLo = tile >= w0 + 64u ? tile - 64u : w0;
+		ring[ (tile + LANE) & (WORD_RING-1)] = (unsigned short)(clsL | (ctxL << 8));		// (the ring keeps the last 512 bytes)
 		const bool isW = LANE < inTile && ctxL == (u32)CTX_WORD;
 		// ---- the runs of the tile (as tileLiterals)
 		const u64 wm = __ballot( isW);
@@ -1318,206 +1538,21 @@ __device__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, 
 				else if (c.lastValid && c.lastTo == want) { qH = c.lastHash; qLen = c.lastLen; }
 			}
 		}
-		// ---- candidates of my end offset: lists of patterns, ascending each
+		// ---- the ends that count go behind the ones that wait
 		const bool emit = isEnd && pLen >= 1u && ((to >= segBeg && to < segEnd) || (to == segEnd && segEnd == len));
-		enum {NLIST=SHAPE_MAXVARIANTS+1};
-		u32 lb[ NLIST], lc[ NLIST];
-#pragma unroll
-		for (int k=0; k<NLIST; ++k) { lb[ k] = 0; lc[ k] = 0; }
-		u32 total = 0, lit0 = 0;
-		if (emit)
+		const u64 em = __ballot( emit);
+		if (em)
 		{
-			if (P.nofLiterals && pLen <= 64u)
-			{
-				// whole-word literal (the probe of tileLiterals)
-				const u32 h = literalHashFinish( pH);
-				u32 slot = h & P.literalMask;
-				uint4 dw = make_uint4( 0, 0, 0, 0);
-				if (pFrom + 16u <= len) dw = ld128u( w.doc + pFrom);
-				else
-				{
-					u32 d[ 4] = {0,0,0,0};
-					for (u32 q=0; q<16u && pFrom+q<len; ++q) d[ q>>2] |= (u32)w.doc[ pFrom + q] << (8*(q&3u));
-					dw = make_uint4( d[0], d[1], d[2], d[3]);
-				}
-				const u32 m0 = pLen >= 4u ? 0xFFFFFFFFu : ((1u << (8*pLen)) - 1u);
-				const u32 m1 = pLen >= 8u ? 0xFFFFFFFFu : (pLen > 4u ? ((1u << (8*(pLen-4u))) - 1u) : 0u);
-				const u32 m2 = pLen >= 12u ? 0xFFFFFFFFu : (pLen > 8u ? ((1u << (8*(pLen-8u))) - 1u) : 0u);
-				const u32 m3 = pLen >= 16u ? 0xFFFFFFFFu : (pLen > 12u ? ((1u << (8*(pLen-12u))) - 1u) : 0u);
-				for (u32 probes=0; probes<=P.literalMask; ++probes)
-				{
-					const uint4* ep = (const uint4*)&P.literals[ slot];
-					const uint4 e0 = ep[ 0], e1 = ep[ 1], tx = ep[ 2];
-					if (!e0.x) break;
-					if (e0.x == h && e0.y == pLen)
-					{
-						bool same = (((dw.x ^ tx.x) & m0) | ((dw.y ^ tx.y) & m1) | ((dw.z ^ tx.z) & m2) | ((dw.w ^ tx.w) & m3)) == 0;
-						for (u32 k=16; k<pLen && same; k+=4)
-						{
-							const u32 rem = pLen - k;
-							u32 a;
-							if (pFrom + k + 4u <= len) a = ld32u( w.doc + pFrom + k);
-							else { a = 0; for (u32 q=0; q<rem && q<4u; ++q) a |= (u32)w.doc[ pFrom + k + q] << (8*q); }
-							const u32 b = ld32u( P.literalText + e1.w + k);
-							const u32 mask = rem >= 4u ? 0xFFFFFFFFu : ((1u << (8*rem)) - 1u);
-							same = ((a ^ b) & mask) == 0;
-						}
-						if (same) { lb[ 0] = e0.z; lc[ 0] = e0.w; lit0 = e1.x; break; }
-					}
-					slot = (slot+1) & P.literalMask;
-				}
-			}
-		}
-		// ---- shape variants: the key bytes come out of two unaligned words of the text (the run's first four bytes, its last
-		// four); the compact table (fingerprint, pattern or list) sits in LDS beside the automaton tables: no global round trip
-		if (nVar && __ballot( emit))
-		{
-			u32 first4 = 0, last4 = 0;
+			const u32 rank = (u32)__builtin_amdgcn_mbcnt_hi( (u32)(em >> 32), __builtin_amdgcn_mbcnt_lo( (u32)em, 0));
 			if (emit)
 			{
-				if (pFrom + 4u <= len) first4 = ld32u( w.doc + pFrom); else for (u32 i=0; i<4u && pFrom+i<len; ++i) first4 |= (u32)w.doc[ pFrom+i] << (8*i);
-				if (to >= 4u) last4 = ld32u( w.doc + to - 4u); else for (u32 i=0; i<to; ++i) last4 |= (u32)w.doc[ i] << (8*(4u-to+i));
+				u32* e = ends + WORD_ENDWORDS*(nEnds + rank);
+				e[ 0] = to; e[ 1] = pFrom; e[ 2] = pH; e[ 3] = qH; e[ 4] = (pLen > 65u ? 65u : pLen) | ((qLen > 65u ? 65u : qLen) << 8);
 			}
-#pragma unroll
-			for (int v=0; v<SHAPE_MAXVARIANTS; ++v)
-			{
-				if ((u32)v < nVar)
-				{
-					const u32 var = uni( P.shapeVariants[ v]);
-					const u32 kind = var & 3u, o = (var >> 2) & 3u, k = (var >> 4) & 7u;
-					const u32 kmask = k >= 4u ? 0xFFFFFFFFu : ((1u << (8*k)) - 1u);
-					if (emit)
-					{
-						u32 tag = 0, key = 0;
-						if (kind == (u32)SHAPE_PREVWORD) { if (qLen >= 1u && qLen <= 64u) { tag = (u32)SHAPE_PREVWORD | (qLen << 8); key = literalHashFinish( qH); } }
-						else if (kind == (u32)SHAPE_PREFIX)
-						{
-							if (pLen >= o + k)
-							{
-								tag = var;
-								if (o + k <= 4u) key = (first4 >> (8*o)) & kmask;
-								else for (u32 i=0; i<k; ++i) key |= (u32)w.doc[ pFrom + o + i] << (8*i);
-							}
-						}
-						else if (pLen >= k) { tag = var; key = k >= 4u ? last4 : (last4 >> (8*(4u-k))); }
-						if (tag)
-						{
-							const u32 fp = shapeFingerprint( tag, key, P.shapeSalt);
-							u32 slot = shapeSlotHash( tag, key) & P.shapeMask;
-							for (u32 probes=0; probes<=P.shapeMask; ++probes)
-							{
-								const u64 e = T.at( P.shapeFpOffset + slot);		// fingerprint | (count << 24 | pattern or list) << 32
-								if (!(u32)e) break;
-								if ((u32)e == fp) { lb[ 1+v] = (u32)(e >> 32) & 0xFFFFFFu; lc[ 1+v] = (u32)(e >> 56); break; }
-								slot = (slot+1) & P.shapeMask;
-							}
-						}
-					}
-				}
-			}
+			if (!nEnds) firstTile = tile;
+			nEnds += (u32)__builtin_popcountll( em);
 		}
-#pragma unroll
-		for (int k=0; k<NLIST; ++k) total += lc[ k];
-		// ---- every lane reserves its records, then merges its lists by pattern index and confirms the shape candidates
-		const u32 incl = waveScanAdd( total);
-		const u32 waveTotal = (u32)__builtin_amdgcn_readlane( incl, 63);
-		if (waveTotal)
-		{
-			if (w.nQueue + waveTotal > w.queueCap) { w.err = L1D_ERR_ARENA; break; }
-			u32* out = w.queue + 4*(u64)(w.nQueue + incl - total);
-			// Up to 64 candidates in the tile (the rule): the lanes that saw a run end only ORDER their candidates (merge of their
-			// lists by pattern index) into the wave's staging array; then every candidate gets a lane of its own for the walk that
-			// confirms it -- one round of walks per tile instead of one per candidate of the busiest lane.
-			const bool staged = waveTotal <= 64u;
-			uint4* stage = wordStage[ (threadIdx.x >> 6) & (WORD_WAVES-1)];
-			// The usual tile: no list longer than one pattern, no end offset with more than four candidates.  Then a lane's candidates
-			// are a handful of keys (pattern << 1 | literal) in registers, ordered by a five-comparator network: no loop, no load.
-			bool simple = total <= 4u;
-#pragma unroll
-			for (int k=0; k<NLIST; ++k) if (lc[ k] > 1u) simple = false;
-			if (staged && !__ballot( !simple))
-			{
-				u32 c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu, c3 = 0xFFFFFFFFu, nc = 0;
-#pragma unroll
-				for (int k=0; k<NLIST; ++k)
-				{
-					if (lc[ k])
-					{
-						const u32 key = k == 0 ? ((lit0 << 1) | 1u) : (lb[ k] << 1);
-						c0 = nc == 0 ? key : c0; c1 = nc == 1 ? key : c1; c2 = nc == 2 ? key : c2; c3 = nc == 3 ? key : c3;
-						++nc;
-					}
-				}
-#define SPA_CSWAP( A, B) { const u32 lo = A < B ? A : B, hi = A < B ? B : A; A = lo; B = hi; }
-				SPA_CSWAP( c0, c1) SPA_CSWAP( c2, c3) SPA_CSWAP( c0, c2) SPA_CSWAP( c1, c3) SPA_CSWAP( c1, c2)
-#undef SPA_CSWAP
-				const u32 at = incl - total;
-				if (total > 0) stage[ at] = make_uint4( to, (c0 >> 1) | ((c0 & 1u) ? (u32)L1_LITERAL_FLAG : 0u), pFrom, 0u);
-				if (total > 1) stage[ at+1] = make_uint4( to, (c1 >> 1) | ((c1 & 1u) ? (u32)L1_LITERAL_FLAG : 0u), pFrom, 0u);
-				if (total > 2) stage[ at+2] = make_uint4( to, (c2 >> 1) | ((c2 & 1u) ? (u32)L1_LITERAL_FLAG : 0u), pFrom, 0u);
-				if (total > 3) stage[ at+3] = make_uint4( to, (c3 >> 1) | ((c3 & 1u) ? (u32)L1_LITERAL_FLAG : 0u), pFrom, 0u);
-				total = 0;		// (nothing left for the general merge below)
-			}
-			u32 head[ NLIST]; bool single[ NLIST];
-#pragma unroll
-			for (int k=0; k<NLIST; ++k) single[ k] = lc[ k] == 1u;
-#pragma unroll
-			for (int k=0; k<NLIST; ++k)
-			{
-				head[ k] = 0xFFFFFFFFu;
-				if (lc[ k]) head[ k] = k == 0 ? lit0 : (lc[ k] == 1u ? lb[ k] : P.shapePats[ lb[ k]]);	// (a shape entry of one pattern holds the pattern in place of the list)
-			}
-			for (u32 n=0; n<total; ++n)
-			{
-				u32 best = 0xFFFFFFFFu; int which = 0;
-#pragma unroll
-				for (int k=0; k<NLIST; ++k) if (head[ k] < best) { best = head[ k]; which = k; }
-				// advance that list
-#pragma unroll
-				for (int k=0; k<NLIST; ++k)
-				{
-					if (k == which)
-					{
-						if (k != 0 && single[ k]) { lc[ k] = 0; head[ k] = 0xFFFFFFFFu; }
-						else
-						{
-							++lb[ k]; --lc[ k];
-							head[ k] = lc[ k] ? (k == 0 ? P.litPats[ lb[ 0]] : P.shapePats[ lb[ k]]) : 0xFFFFFFFFu;
-						}
-					}
-				}
-				if (staged) { stage[ incl - total + n] = make_uint4( to, which == 0 ? (best | (u32)L1_LITERAL_FLAG) : best, pFrom, 0u); continue; }
-				u32 fromOut = pFrom, flags = (u32)L1_LITERAL_FLAG;
-				if (which != 0)
-				{
-					const uint2 pw = *(const uint2*)((const u32*)&P.patterns[ best] + 5);	// {maskLo, maskHi}
-					const u32 word = ((const u32*)&P.patterns[ best])[ 1];
-					fromOut = confirmWalk<LDS>( w.doc, len, P, T, ring, ringLo, word, ((u64)pw.y << 32) | pw.x, to);
-					if (fromOut == to) flags |= (u32)L1_DEAD_FLAG;
-				}
-				*(uint4*)(out + 4*(u64)n) = make_uint4( to, best | flags, fromOut, 0u);
-			}
-			if (staged)
-			{
-				__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
-				if (LANE < waveTotal)
-				{
-					const uint4 cnd = stage[ LANE];
-					u32 fromOut = cnd.z, flags = (u32)L1_LITERAL_FLAG;
-					const u32 pi = cnd.y & ~(u32)L1_LITERAL_FLAG;
-					if (!(cnd.y & (u32)L1_LITERAL_FLAG))
-					{
-						const uint2 pw = *(const uint2*)((const u32*)&P.patterns[ pi] + 5);	// {maskLo, maskHi}
-						const u32 word = ((const u32*)&P.patterns[ pi])[ 1];
-						fromOut = confirmWalk<LDS>( w.doc, len, P, T, ring, ringLo, word, ((u64)pw.y << 32) | pw.x, cnd.x);
-						if (fromOut == cnd.x) flags |= (u32)L1_DEAD_FLAG;
-					}
-					*(uint4*)(w.queue + 4*(u64)(w.nQueue + LANE)) = make_uint4( cnd.x, pi | flags, fromOut, 0u);
-				}
-				__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
-			}
-			w.nQueue += waveTotal;
-		}
+		__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
 		// ---- carry: the run that reaches the end of the tile, the last run that ended
 		c.in = (wm >> 63) & 1ull;
 		if (c.in)
@@ -1530,11 +1565,34 @@ __device__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, 
 			c.lastValid = true; c.lastTo = tile + e;
 			c.lastHash = (u32)__builtin_amdgcn_readlane( pH, e); c.lastLen = (u32)__builtin_amdgcn_readlane( pLen, e);
 		}
+		// ---- a full batch, or ends about to lose the bytes before them from the ring: probe
+		const bool pressure = nEnds && tile + 64u - firstTile > (u32)WORD_RING - 192u;
+		while (!w.err && (nEnds >= 64u || (pressure && nEnds)))
+		{
+			const u32 count = nEnds < 64u ? nEnds : 64u;
+			const u32 ringLo = tile + 64u > w0 + (u32)WORD_RING ? tile + 64u - (u32)WORD_RING : w0;
+			// (what is behind the batch is read before the candidates of the batch are written over it... it lies behind them: entries 64..)
+			wordsFlush<LDS>( w, P, T, ring, ringLo, ends, count, nVar);
+			const u32 rest = nEnds - count;
+			u32 keep[ WORD_ENDWORDS];
+			if (LANE < rest) { _Pragma("unroll") for (int k=0; k<WORD_ENDWORDS; ++k) keep[ k] = ends[ WORD_ENDWORDS*(64u + LANE) + k]; }
+			__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+			if (LANE < rest) { _Pragma("unroll") for (int k=0; k<WORD_ENDWORDS; ++k) ends[ WORD_ENDWORDS*LANE + k] = keep[ k]; }
+			__builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront");
+			nEnds = rest; firstTile = tile;
+		}
+	}
+	// the ends that still wait (the ring holds the bytes up to the last tile)
+	if (!w.err && nEnds)
+	{
+		const u32 doneTo = tile;	// (one behind the last tile's first byte + 64... the loop has stepped past it)
+		const u32 ringLo = doneTo > w0 + (u32)WORD_RING ? doneTo - (u32)WORD_RING : w0;
+		wordsFlush<LDS>( w, P, T, ring, ringLo, ends, nEnds, nVar);
 	}
 }
 
 template <bool LDS>
-__device__ void wordsDocuments( const L1Params& P)
+__device__ __forceinline__ void wordsDocuments( const L1Params& P)
 {
 	if (!P.wordsKernel) return;
 	LexTab<LDS> T;
