@@ -465,13 +465,14 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 				for (u32 q=0; q<tot; ++q)
 				{
 					const u32 tid = tidNext;
-					if (q+1 < tot) tidNext = (u32)L.rq[ qoff + q + 1];		// (requested beside this step's reads)
+					{ const u32 nx = qoff + q + 1u; tidNext = (u32)L.rq[ nx < (u32)FAST_RQCAP ? nx : (u32)FAST_RQCAP - 1u]; }	// (requested beside this step's reads; unused after the last step)
 					const u32 pos = ldLink<SP>( L, w, P, tid >> 2, tid & 3u) & 0xFFFu;	// (an earlier removal of this replay may have moved it)
 					const u32 last = size - 1u;
 					const uint2 m = ldEnt<SP>( L, w, P, h, meta, last);
-					if (pos != last)
+					if (!SP || pos != last)
 					{
-						// cpp:133-152: the bucket's last entry moves into the hole
+						// cpp:133-152: the bucket's last entry moves into the hole (LDS-only instance: also when the hole IS the last
+						// entry -- it writes the entry onto itself and the link of a trigger that is gone; a branch costs more)
 						stEnt<SP>( L, w, P, h, meta, pos, m.x, m.y);
 						stLink<SP>( L, w, P, (m.y & 0xFFFFu) >> 2, m.y & 3u, (h << 12) | pos);
 					}
