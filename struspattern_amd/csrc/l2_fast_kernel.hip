@@ -388,13 +388,18 @@ static __device__ __forceinline__ void fireSignal( LR L, Wave& w, KP P, u32 tsv,
 // step is two dependent LDS reads and two stores by one lane.  (Round 2 let every rule's lane wait for its
 // trigger's turn: as many rounds of the whole wave as the fullest bucket has removals, 5 per event on the
 // pipeline workload -- the sentence delimiter's bucket holds a trigger of every *_struct instance.)
-template <bool SP, bool EXPROW>
-static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 n, u32 row, bool freeIds)
+template <bool SP>
+static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, const u32 nD, const u32 nE, const u32 row)
 {
+	// the first nD rules: the dispose list of the transition just done; behind them the nE rules of an expiry row, last defined first.
+	// (Nothing looks at the buckets between the end of a transition and the expiry of the next position, so the two lists go through
+	// ONE batch: the fixed cost of a batch -- ranks, queue offsets, the replay -- is paid once per event instead of twice.)
+	const u32 n = nD + nE;
 	for (u32 base=0; base<n && !w.err; base+=64)
 	{
 		const u32 nb = (n - base) < 64u ? (n - base) : 64u;
 		const bool have = LANE < nb;
+		const bool isExp = base + LANE >= nD;
 		u32 r = 0, hw = 0;
 #if defined(SPA_PROF) && !defined(SPA_PROF_INSTALL)
 		u64 pd0 = __builtin_amdgcn_s_memtime();
@@ -404,10 +409,11 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 #endif
 		if (have)
 		{
-			r = EXPROW ? ldExp<SP>( L, w, P, row, n - 1u - (base + LANE)) : ldList<SP>( L, w, P, base + LANE);
+			r = isExp ? ldExp<SP>( L, w, P, row, nE - 1u - (base + LANE - nD)) : ldList<SP>( L, w, P, base + LANE);
 			hw = ldHot<SP>( L, w, P, r);
 		}
-		const bool act = have && (hw & H_ACTIVE);
+		// (a rule of the row that is still active AND listed sits in the dispose list of this very batch: that lane removes its triggers)
+		const bool act = have && (hw & H_ACTIVE) && !(isExp && (hw & H_LISTED));
 		const u32 mask = act ? ((hw >> H_TMASK_SHIFT) & H_TMASK_MASK) : 0u;
 		if (act) stHot<SP>( L, w, P, r, hw & ~(H_ACTIVE | (H_TMASK_MASK << H_TMASK_SHIFT)));
 		if (__ballot( mask != 0))
@@ -489,15 +495,17 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 			w.prof[ 8] += (u32)__builtin_amdgcn_readlane( waveScanMax( tot), 63); w.prof[ 9] += 1; w.prof[ 10] += nb;
 #endif
 		}
-		if (freeIds)
+		if (nE)
 		{
-			const u64 mL = __ballot( have && r < (u32)R);
-			if (have && r < (u32)R) L.freeS[ w.freeN + (u32)__popcll( mL & lanesBelow())] = (typename FreeId<(R <= 256)>::type)r;
+			// disposeRule (cpp:704-708): the ids of the row's rules are free again
+			const bool fr = have && isExp;
+			const u64 mL = __ballot( fr && r < (u32)R);
+			if (fr && r < (u32)R) L.freeS[ w.freeN + (u32)__popcll( mL & lanesBelow())] = (typename FreeId<(R <= 256)>::type)r;
 			w.freeN += (u32)__popcll( mL);
 			if (SP)
 			{
-				const u64 mS = __ballot( have && r >= (u32)R);
-				if (have && r >= (u32)R) w.sp[ P.spill.oFree + w.sFreeN + (u32)__popcll( mS & lanesBelow())] = r - R;
+				const u64 mS = __ballot( fr && r >= (u32)R);
+				if (fr && r >= (u32)R) w.sp[ P.spill.oFree + w.sFreeN + (u32)__popcll( mS & lanesBelow())] = r - R;
 				w.sFreeN += (u32)__popcll( mS);
 			}
 		}
@@ -508,6 +516,7 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, u32 
 // ---------------------------------------------------------------- expiry (cpp:1084-1135, window part: ranges are <= 63)
 static __device__ __forceinline__ void setCurrentPos( LR L, Wave& w, KP P, u32 pos)
 {
+	// (the dispose list of the transition before, w.nDispose rules, is still to be deactivated: it joins the first row that holds rules)
 	if (w.curpos == pos) return;
 	const u32 W = 1u << P.expShift;			// every live rule expires within the next W positions: one row per position
 	u32 wcnt = 0;
@@ -518,7 +527,14 @@ static __device__ __forceinline__ void setCurrentPos( LR L, Wave& w, KP P, u32 p
 		if (n)
 		{
 			// the rules of this position, last defined first (the reference's list is LIFO)
-			if (w.spill) deactivateList<true,true>( L, w, P, n, row, true); else deactivateList<false,true>( L, w, P, n, row, true);
+			u32 nD = w.nDispose;
+			if (nD && nD + n > 64u)
+			{
+				if (w.spill) deactivateList<true>( L, w, P, nD, 0, 0); else deactivateList<false>( L, w, P, nD, 0, 0);
+				nD = 0;
+			}
+			w.nDispose = 0;
+			if (w.spill) deactivateList<true>( L, w, P, nD, n, row); else deactivateList<false>( L, w, P, nD, n, row);
 			if (LANE == 0) L.expCnt[ row] = 0;
 			if (LANE == row) w.expCntV = 0;
 			WAVE_FENCE();
@@ -531,7 +547,7 @@ static __device__ __forceinline__ void setCurrentPos( LR L, Wave& w, KP P, u32 p
 		bool over = false;
 		if (LANE < 16u) over = w.bsizeV > (w.bmetaV >> 16);
 		if (w.expCntV > ((u32)FAST_EXPCAP >> P.expShift)) over = true;
-		if (!__ballot( over) && w.sFreeN == w.usedS) { w.spill = 0; w.sFreeN = 0; w.usedS = 0; }
+		if (!__ballot( over) && w.sFreeN == w.usedS && w.nDispose <= (u32)FAST_LISTCAP) { w.spill = 0; w.sFreeN = 0; w.usedS = 0; }
 	}
 }
 
@@ -622,6 +638,7 @@ static __device__ __forceinline__ void installBatchT( LR L, Wave& w, KP P, u32 k
 		hw |= end ? ((end & 0xFFu) << H_END_SHIFT) : (u32)H_ENDZERO;
 		if (done) hw |= H_DONE;
 		if (hasStart) hw |= H_HASSTART;
+		if (del || fin) hw |= H_LISTED;
 		stHot<SP>( L, w, P, r, hw);
 		u32* cold = &w.sp[ P.spill.oCold + 8*r];
 		st4( cold, handle, fmt, startLex, it0);
@@ -1154,8 +1171,22 @@ static __device__ __forceinline__ void runKernel()
 				const u32 origpos = __builtin_amdgcn_readlane( lx.z, k), origsize = __builtin_amdgcn_readlane( lx.w, k);
 				const u32 origseg = __builtin_amdgcn_readlane( seg, k);
 				// PatternMatcherContext::putInput (patternMatcher.cpp:131-162)
+				if (w.nDispose >= 64u)
+				{
+					// (a dispose list that no expiry row can take along -- it may reach into the spill area -- goes first)
+					if (w.spill) deactivateList<true>( L, w, P, w.nDispose, 0, 0); else deactivateList<false>( L, w, P, w.nDispose, 0, 0);
+					w.nDispose = 0;
+					if (w.err) break;
+				}
 				if (curPosition > ordpos) { w.err = SPD_ERR_ORDER; break; }
 				else if (curPosition < ordpos) { curPosition = ordpos; w.posLexems = 0; setCurrentPos( L, w, P, ordpos); PROF_ADD( 3); if (w.err) break; }
+				// the rules the transition before has finished or deleted (cpp:1030-1034), unless an expiry row has taken them along
+				if (w.nDispose)
+				{
+					if (w.spill) deactivateList<true>( L, w, P, w.nDispose, 0, 0); else deactivateList<false>( L, w, P, w.nDispose, 0, 0);
+					w.nDispose = 0;
+					if (w.err) break;
+				}
 				else if (origsize >= 0x7FFFFFFFu || origseg >= 0x7FFFFFFFu || origpos >= 0x7FFFFFFFu) { w.err = SPD_ERR_RANGE; break; }
 				if (id >= (1u<<29)) { w.err = SPD_ERR_RANGE; break; }
 				w.lbase = (u32)(tile - lbeg) + k;
@@ -1166,7 +1197,6 @@ static __device__ __forceinline__ void runKernel()
 					if (lo < w.openLo) w.openHi += 1;
 					w.openLo = lo;
 				}
-				w.nDispose = 0;
 				// the programs keyed by this event: their (compact) install lines are requested now and read after the bucket scan
 				const u32 kb = __builtin_amdgcn_readlane( kBegin, k), kc = __builtin_amdgcn_readlane( kCount, k);
 				const u32 stopIdx = __builtin_amdgcn_readlane( kStop, k);
@@ -1181,12 +1211,8 @@ static __device__ __forceinline__ void runKernel()
 				if (kc) installBatch( L, w, P, kb, kc, ordpos, pc0, pc1);
 				PROF_ADD( 1);
 				if (w.err) break;
-				// deactivate rules that finished or were deleted
-				if (w.nDispose)
-				{
-					WAVE_FENCE();
-					if (w.spill) deactivateList<true,false>( L, w, P, w.nDispose, 0, false); else deactivateList<false,false>( L, w, P, w.nDispose, 0, false);
-				}
+				// (the rules that finished or were deleted are deactivated at the top of the next event, together with the rules that expire there)
+				WAVE_FENCE();
 				if (stopIdx)
 				{
 					if (LANE == stopIdx-1u) { w.stopLex = w.lbase; w.stopOrd = ordpos; w.stopTs = w.timestamp + 1u; }

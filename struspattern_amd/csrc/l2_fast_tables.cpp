@@ -147,7 +147,7 @@ std::string buildFastTables( const FlatTables& ft, std::vector<FastKeyInst>& out
 				ki.ranksA = (rangeCnt[ range] & 0xFFu) | ((resTotal & 0xFFu) << 16) | ((dispTotal & 0xFFu) << 24);
 				rangeCnt[ range] += 1; rangeLast[ range] = l;
 				if (resultNow) { ki.flags |= FKF_RESULT_NOW; resTotal += 1; itemsTotal += sim.nItems; }
-				if (disposeNow) { ki.flags |= FKF_DISPOSE_NOW; dispTotal += 1; }
+				if (disposeNow) { ki.flags |= FKF_DISPOSE_NOW; dispTotal += 1; ki.hw0 |= (uint32_t)H_LISTED; }	// (listed: the expiry row that meets the rule in the dispose list's batch leaves it alone)
 				ki.items = (sim.it0 >> 24) | ((sim.it1 >> 24) << 8) | ((sim.it2 >> 24) << 16);
 				firesTotal += sim.nFires;
 			}
