@@ -516,25 +516,30 @@ static __device__ __forceinline__ void deactivateList( LR L, Wave& w, KP P, cons
 // ---------------------------------------------------------------- expiry (cpp:1084-1135, window part: ranges are <= 63)
 static __device__ __forceinline__ void setCurrentPos( LR L, Wave& w, KP P, u32 pos)
 {
-	// (the dispose list of the transition before, w.nDispose rules, is still to be deactivated: it joins the first row that holds rules)
-	if (w.curpos == pos) return;
+	// Called at the top of every event.  The dispose list of the transition before (w.nDispose rules, cpp:1030-1034) is still to be
+	// deactivated: it joins the first expiry row that holds rules -- one deactivation batch per event --, or goes alone when the
+	// position does not advance, no row holds rules, or the two together do not fit a batch.  (One call site: eight inlined copies of
+	// the deactivation were a quarter of the kernel's code.)
 	const u32 W = 1u << P.expShift;			// every live rule expires within the next W positions: one row per position
 	u32 wcnt = 0;
-	for (; wcnt < W && w.curpos < pos && !w.err; ++wcnt, ++w.curpos)
+	while (!w.err)
 	{
-		const u32 row = w.curpos & (W-1u);
-		const u32 n = (u32)__builtin_amdgcn_readlane( w.expCntV, row);
+		// the next position with rules to expire, if the position advances that far
+		u32 n = 0, row = 0;
+		while (wcnt < W && w.curpos < pos && !n)
+		{
+			row = w.curpos & (W-1u);
+			n = (u32)__builtin_amdgcn_readlane( w.expCntV, row);
+			++wcnt; ++w.curpos;
+		}
+		u32 nD = w.nDispose;
+		if (!n && !nD) break;
+		if (nD && n && nD + n > 64u) { n = 0; --wcnt; --w.curpos; }		// (the dispose list alone first; the row comes round again)
+		w.nDispose = 0;
+		// the rules of the row go last defined first (the reference's list is LIFO)
+		if (w.spill) deactivateList<true>( L, w, P, nD, n, row); else deactivateList<false>( L, w, P, nD, n, row);
 		if (n)
 		{
-			// the rules of this position, last defined first (the reference's list is LIFO)
-			u32 nD = w.nDispose;
-			if (nD && nD + n > 64u)
-			{
-				if (w.spill) deactivateList<true>( L, w, P, nD, 0, 0); else deactivateList<false>( L, w, P, nD, 0, 0);
-				nD = 0;
-			}
-			w.nDispose = 0;
-			if (w.spill) deactivateList<true>( L, w, P, nD, n, row); else deactivateList<false>( L, w, P, nD, n, row);
 			if (LANE == 0) L.expCnt[ row] = 0;
 			if (LANE == row) w.expCntV = 0;
 			WAVE_FENCE();
@@ -547,7 +552,7 @@ static __device__ __forceinline__ void setCurrentPos( LR L, Wave& w, KP P, u32 p
 		bool over = false;
 		if (LANE < 16u) over = w.bsizeV > (w.bmetaV >> 16);
 		if (w.expCntV > ((u32)FAST_EXPCAP >> P.expShift)) over = true;
-		if (!__ballot( over) && w.sFreeN == w.usedS && w.nDispose <= (u32)FAST_LISTCAP) { w.spill = 0; w.sFreeN = 0; w.usedS = 0; }
+		if (!__ballot( over) && w.sFreeN == w.usedS) { w.spill = 0; w.sFreeN = 0; w.usedS = 0; }
 	}
 }
 
@@ -1171,23 +1176,11 @@ static __device__ __forceinline__ void runKernel()
 				const u32 origpos = __builtin_amdgcn_readlane( lx.z, k), origsize = __builtin_amdgcn_readlane( lx.w, k);
 				const u32 origseg = __builtin_amdgcn_readlane( seg, k);
 				// PatternMatcherContext::putInput (patternMatcher.cpp:131-162)
-				if (w.nDispose >= 64u)
-				{
-					// (a dispose list that no expiry row can take along -- it may reach into the spill area -- goes first)
-					if (w.spill) deactivateList<true>( L, w, P, w.nDispose, 0, 0); else deactivateList<false>( L, w, P, w.nDispose, 0, 0);
-					w.nDispose = 0;
-					if (w.err) break;
-				}
 				if (curPosition > ordpos) { w.err = SPD_ERR_ORDER; break; }
-				else if (curPosition < ordpos) { curPosition = ordpos; w.posLexems = 0; setCurrentPos( L, w, P, ordpos); PROF_ADD( 3); if (w.err) break; }
-				// the rules the transition before has finished or deleted (cpp:1030-1034), unless an expiry row has taken them along
-				if (w.nDispose)
-				{
-					if (w.spill) deactivateList<true>( L, w, P, w.nDispose, 0, 0); else deactivateList<false>( L, w, P, w.nDispose, 0, 0);
-					w.nDispose = 0;
-					if (w.err) break;
-				}
+				else if (curPosition < ordpos) { curPosition = ordpos; w.posLexems = 0; }
 				else if (origsize >= 0x7FFFFFFFu || origseg >= 0x7FFFFFFFu || origpos >= 0x7FFFFFFFu) { w.err = SPD_ERR_RANGE; break; }
+				// expiry up to the event's position + the rules the transition before has finished or deleted
+				if (w.curpos != ordpos || w.nDispose) { setCurrentPos( L, w, P, ordpos); PROF_ADD( 3); if (w.err) break; }
 				if (id >= (1u<<29)) { w.err = SPD_ERR_RANGE; break; }
 				w.lbase = (u32)(tile - lbeg) + k;
 				if (++w.posLexems > 60u) { FALLBACK( FB_POSLEXEMS); break; }	// (key lexems are kept modulo 4096: ldKl)
