@@ -80,7 +80,8 @@ enum {
 	H_DONE=1u<<18, H_ACTIVE=1u<<19, H_TMASK_SHIFT=20, H_TMASK_MASK=0x7u, H_NITEMS_SHIFT=23, H_NITEMS_MASK=0x3u, H_HASSTART=1u<<25,
 	H_COLD=1u<<26,			// start of the match and captured items are in the rule's record in HBM (else: the key lexem + the static line)
 	H_LISTED=1u<<27,		// already in the dispose list of the current transition
-	H_VISIBLE=1u<<28		// the pattern has a result handle: completing the rule emits a result (static lines only; else the record tells)
+	H_VISIBLE=1u<<28,		// the pattern has a result handle: completing the rule emits a result (static lines only; else the record tells)
+	H_MARK=1u<<31			// set while a lane of fireBatch works on the rule: a second hit on the same rule in one scan step sees it
 };
 
 // ---- a fresh slot while its program is being installed: the alternative-key replay and the key triggers fire before

@@ -376,6 +376,159 @@ static __device__ __forceinline__ void fireSignal( LR L, Wave& w, KP P, u32 tsv,
 	if (LANE == 0) stHot<SP>( L, w, P, r, hw);
 }
 
+// ---------------------------------------------------------------- fireSignal for all hits of a bucket scan step at once
+// The hits of one step are triggers of different rules almost always: then the fires do not see each other, and what they share
+// -- the staged results, the dispose list, the counters -- is placed by ballot rank in hit order.  Lane = hit; the same statements
+// as fireSignal per lane.  Returns false with nothing changed when two hits of the step belong to one rule (programs with two
+// equal terms) or the dispose list would leave LDS: the caller fires them one after the other.  LDS-only instance.
+static __device__ __forceinline__ bool fireBatch( LR L, Wave& w, KP P, const u64 m, const u32 tsv, const u32 sord)
+{
+	const bool hit = ((m >> LANE) & 1ull) != 0;
+	const u32 nh = (u32)__popcll( m);
+	if (w.nDispose + nh > (u32)FAST_LISTCAP) return false;
+	const u32 tid = tsv & 0xFFFFu, r = hit ? (tid >> 2) : 0u;
+	const u32 sigval = (tsv >> 16) & 0xFu, sigtype = (tsv >> 20) & 0x7u, hasVar = (tsv >> 23) & 1u, variable = tsv >> 24;
+	u32 hw = 0;
+	if (hit) hw = __hip_atomic_fetch_or( &L.hot[ r], (u32)H_MARK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	if (__ballot( hit && (hw & (u32)H_MARK)))
+	{
+		if (hit) __hip_atomic_fetch_and( &L.hot[ r], ~(u32)H_MARK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		WAVE_FENCE();
+		return false;
+	}
+	u32 value = hw & H_VALUE_MASK, count = (hw >> H_COUNT_SHIFT) & H_COUNT_MASK;
+	bool match = false, take = false, fin = false;
+	const bool isDel = hit && sigtype != (u32)SIG_ANY && sigtype != (u32)SIG_SEQUENCE && sigtype != (u32)SIG_SEQUENCE_IMM && sigtype != (u32)SIG_WITHIN;
+	if (hit && !isDel)
+	{
+		if (sigtype == (u32)SIG_ANY)
+		{
+			take = true;
+			if (count > 0) { match = true; --count; fin = (count == 0); hw = withEnd( hw, sord+1); }
+		}
+		else if (sigtype == (u32)SIG_WITHIN)
+		{
+			if ((sigval & value) != 0 && endLE( hw, sord))
+			{
+				hw = withEnd( hw, sord+1); value &= ~sigval;
+				if (count > 0) { --count; match = (count == 0); } else match = true;
+				take = true;
+			}
+		}
+		else if (sigval == value && (sigtype == (u32)SIG_SEQUENCE ? endLE( hw, sord) : endEQ( hw, sord)))
+		{
+			hw = withEnd( hw, sord+1); value = sigval-1;
+			if (count > 0) { --count; match = (count == 0); } else match = true;
+			fin = (value == 0); take = true;
+		}
+	}
+	if (isDel) hw &= ~(H_VALUE_MASK | (H_COUNT_MASK << H_COUNT_SHIFT));
+	const bool done = (hw & H_DONE) != 0;
+	u32 nItems = (hw >> H_NITEMS_SHIFT) & H_NITEMS_MASK;
+	bool newItem = false, newStart = false;
+	u32 why = 0;
+	if (take)
+	{
+		if (hasVar && P.withItems)
+		{
+			if (done) { if (nItems) why = FB_ITEM_AFTER_RESULT; }
+			else if (nItems < 3u) newItem = true;
+			else why = FB_ITEMS;
+		}
+		newStart = !(hw & H_HASSTART);
+	}
+	const bool live = hit && !isDel && !done;
+	const bool lineCase = live && match && !(hw & H_COLD);					// completes with what its install line tells
+	const bool recCase = live && !lineCase && (match || newItem || newStart);		// needs what the rule has captured
+	// ---- what the rule has captured: its record, or the key lexem + the install line
+	u32 handle = 0, fmt = 0, startLex = 0, it0 = 0, it1 = 0, it2 = 0, kl = 0, lx = 0;
+	if ((lineCase && (hw & H_VISIBLE)) || (recCase && !(hw & H_COLD))) { kl = L.kl[ r]; lx = keyLexemOf( kl, w.lbase); }
+	u32* cold = &w.sp[ P.spill.oCold + 8*r];
+	u32 nItemsOut = nItems;
+	if (recCase)
+	{
+		if (hw & H_COLD)
+		{
+			const uint4 c0 = ld4( cold); const uint2 c1 = *(const uint2*)(cold + 4);		// written by this wave (same-wave store -> load)
+			handle = c0.x; fmt = c0.y; startLex = c0.z; it0 = c0.w; it1 = c1.x; it2 = c1.y;
+		}
+		else
+		{
+			const u32* K = (const u32*)&P.keyinst[ kl & 0xFFFFFu];
+			handle = K[ 0]; fmt = K[ 1];
+			const u32 vars = K[ 14];
+			startLex = lx;
+			it0 = lx | ((vars & 0xFFu) << 24); it1 = lx | (((vars >> 8) & 0xFFu) << 24); it2 = lx | (((vars >> 16) & 0xFFu) << 24);
+		}
+		if (newItem)
+		{
+			const u32 item = w.lbase | (variable << 24);
+			if (nItems == 0) it0 = item; else if (nItems == 1) it1 = item; else it2 = item;
+			nItemsOut = nItems + 1u;
+		}
+		if (newStart) startLex = w.lbase;
+	}
+	else if (lineCase && newItem) nItemsOut = nItems + 1u;
+	// ---- results in hit order
+	const bool resLine = lineCase && (hw & H_VISIBLE) != 0, resRec = recCase && match && handle != 0;
+	const u64 resM = __ballot( resLine || resRec);
+	const u32 nres = (u32)__popcll( resM);
+	// ---- dispose list in hit order (a rule is listed once per transition)
+	const bool listNow = hit && !(hw & H_LISTED) && (isDel || (match && fin));
+	const u64 listM = __ballot( listNow);
+	const u32 nlist = (u32)__popcll( listM);
+	{
+		const u64 whyM = __ballot( why != 0);
+		u32 fb = 0;
+		if (whyM) fb = (u32)__builtin_amdgcn_readlane( why, (u32)__builtin_ctzll( whyM));
+		else if (w.nStaged + nres > P.spill.maxStaged) fb = FB_STAGED;
+		else if (w.nDispose + nlist > P.spill.maxRules) fb = FB_DISPOSE;
+		if (fb) { FALLBACK( fb); return true; }
+	}
+	w.nSignals += nh;
+	if (nres)
+	{
+		const u32 at = w.nStaged + (u32)__popcll( resM & lanesBelow());
+		if (resLine) stageLineResult( w, P, at, kl & 0xFFFFFu, newStart ? w.lbase : lx, w.lbase, nItems, newItem ? 1u : 0u, variable, lx);
+		if (resRec)
+		{
+			// items latest first
+			const u32 ia = nItemsOut == 3 ? it2 : nItemsOut == 2 ? it1 : it0;
+			const u32 ib = nItemsOut == 3 ? it1 : it0;
+			const u32 ic = it0;
+			const u32 vars = nItemsOut == 0 ? 0u : nItemsOut == 1 ? (ia >> 24) : nItemsOut == 2 ? ((ia >> 24) | ((ib >> 24) << 8)) : ((ia >> 24) | ((ib >> 24) << 8) | ((ic >> 24) << 16));
+			stageResult( w, P, at, handle, fmt, startLex, w.lbase, nItemsOut, vars, ia & 0xFFFFFFu, ib & 0xFFFFFFu, ic & 0xFFFFFFu);
+		}
+		w.nStaged += nres;
+		const u32 itemsIncl = waveScanAdd( (resLine || resRec) ? nItemsOut : 0u);
+		w.nStagedItems += (u32)__builtin_amdgcn_readlane( itemsIncl, 63);
+	}
+	if (recCase && !match)
+	{
+		// the rule goes on waiting with more than its install line tells: its record takes over
+		st4( cold, handle, fmt, startLex, it0); *(uint2*)(cold + 4) = make_uint2( it1, it2);
+		hw |= H_COLD;
+	}
+	if (nlist)
+	{
+		if (listNow) L.list[ w.nDispose + (u32)__popcll( listM & lanesBelow())] = (u16)r;
+		w.nDispose += nlist;
+	}
+	if (hit)
+	{
+		if (listNow) hw |= H_LISTED;
+		if (!isDel)
+		{
+			if (newStart && sord) hw |= H_HASSTART;		// (a start at ordinal position 0 counts as unset, cpp:919)
+			hw = (hw & ~(H_VALUE_MASK | (H_COUNT_MASK << H_COUNT_SHIFT) | (H_NITEMS_MASK << H_NITEMS_SHIFT))) | value | (count << H_COUNT_SHIFT) | ((live ? nItemsOut : nItems) << H_NITEMS_SHIFT);
+			if (match && !done) hw |= H_DONE;
+		}
+		L.hot[ r] = hw & ~(u32)H_MARK;
+	}
+	WAVE_FENCE();
+	return true;
+}
+
 // ---------------------------------------------------------------- deactivation of a list of rules
 // deactivateRule (cpp:679-702) for n rules in list order; freeIds: disposeRule (cpp:704-708).  The list is the
 // dispose list of the transition (EXPROW = false; a rule is listed once, H_LISTED) or, last defined first, the
@@ -1084,6 +1237,11 @@ static __device__ __forceinline__ void scanAndFire( LR L, Wave& w, KP P, u32 id,
 		uint2 en = make_uint2( 0, 0);
 		if (i < n) en = ldEnt<SP>( L, w, P, h, meta, i);		// (whole entries: a hit's trigger word comes out of the lane's register, not out of a second read)
 		u64 m = __ballot( i < n && en.x == id);
+		if (!SP && (m & (m - 1ull)) != 0)
+		{
+			// several hits: all at once, a lane each
+			if (fireBatch( L, w, P, m, en.y, ordpos)) m = 0;
+		}
 		while (m && !w.err)
 		{
 			const u32 p = (u32)__builtin_ctzll( m);
