@@ -357,8 +357,9 @@ def pmc_traffic(kernel_prefix, wl, args, kernel_ms):
 
 def canonical_order_mode(wl, rules, head, d_lex, local_rank, m, nbytes):
     """NOT part of `value`: the rule stage of the same step on the opt-in join prototype (csrc/l2_join.h, SPA_L2_JOIN=1), which
-    yields the same result SETS without materialising rule instances but not the reference's order of the results inside a
-    document (tests/test_l2_join_gpu.py checks the sets against the oracle).  Reported beside the exact engine's time."""
+    evaluates the rules' meaning without materialising rule instances: the oracle's result SETS for rule sets that were not
+    compile()d (tests/test_l2_join_gpu.py), not the reference's order of the results inside a document, and not the optimizer's
+    alternative keys (the counts of the two engines are reported side by side).  Reported beside the exact engine's time."""
     try:
         import torch
         import struspattern_amd as spa
@@ -385,7 +386,8 @@ def canonical_order_mode(wl, rules, head, d_lex, local_rank, m, nbytes):
             ms.append(jctx.lastKernelMs())
         l2 = float(np.mean(ms))
         out = {"available": True, "l2_ms": l2, "events_per_s": c["events"] / (l2 * 1e-3), "results": int(c["results"]),
-               "results_of_the_exact_engine": m["results"], "note": "result sets only, order inside a document not the reference's; never part of `value`"}
+               "results_of_the_exact_engine": m["results"], "note": "result sets only, order inside a document not the reference's; pinned against the oracle for rule sets WITHOUT compile() only -- "
+                       "the optimizer's alternative keys are not modelled, hence the two counts differ slightly; never part of `value`"}
         if wl == "pipeline":
             out["pipeline_GBps_with_it"] = nbytes / ((m["l1_ms"] + l2) * 1e-3) / 1e9
         return out

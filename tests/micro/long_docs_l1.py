@@ -21,7 +21,7 @@ for chunk in ("1073741824", None):
         c = ctx.batchCounters()
         if c["failed_docs"]:
             ctx.reserveOutput(int(c["lexems"]*1.2)+1024); ctx.growArena(); continue
-        a, b = ctx.lastKernelMsSplit()
-        best = (a, b) if best is None or a + b < sum(best) else best
-    print("%s: %d docs x %.1f MB: scan %.1f ms post %.1f ms, %d units, %d documents scanned again, %d lexems" % (
-        "one wave per document" if chunk else "32 KiB chunks", ndocs, docbytes/1e6, best[0], best[1], c["scan_units"], c["rescanned_docs"], c["lexems"]), flush=True)
+        a, w_, b = ctx.lastKernelMsSplit3()
+        best = (a, w_, b) if best is None or a + w_ + b < sum(best) else best
+    print("%s: %d docs x %.1f MB: scan %.1f ms words %.1f ms post %.1f ms, %d units, %d documents scanned again, %d lexems" % (
+        "one wave per document" if chunk else "32 KiB chunks", ndocs, docbytes/1e6, best[0], best[1], best[2], c["scan_units"], c["rescanned_docs"], c["lexems"]), flush=True)
