@@ -15,7 +15,7 @@
 
 namespace spa {
 bool l1ScanByLanes( const L1Params& PS, const L1Params& P);
-hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned laneBlocks, unsigned wordBlocks, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords);
+hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned laneBlocks, unsigned wordBlocks, unsigned wordWaves, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords);
 }
 using namespace spa;
 
@@ -471,8 +471,10 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	if (PS.nofPasses == 0) HIP_CHECK( hipMemsetAsync( c->dReportCount.ptr, 0, (maxUnits+1)*sizeof(uint32_t), stream));
 	// words kernel: a wave per unit, workgroups of 16 waves that share one LDS copy of the image of all passes when it fits
 	L1Params PW = P;
-	PW.ldsWords = ((size_t)c->imgWords*8 + L1_WORDS_STATIC_LDS <= 160*1024 && T.nofShapes) ? c->imgWords : 0u;
-	unsigned wordBlocks = (unsigned)((maxUnits + L1_WORD_WAVES-1) / L1_WORD_WAVES < (uint64_t)c->numCUs ? (maxUnits + L1_WORD_WAVES-1) / L1_WORD_WAVES : (uint64_t)c->numCUs);
+	// (16 waves per workgroup while the image leaves room for their rings and run ends, else 12; SPA_L1_WORD_WAVES=12: A/B runs)
+	unsigned wordWaves = ((size_t)c->imgWords*8 + (size_t)L1_WORD_WAVES_SMALL*L1_WORDS_LDS_PER_WAVE <= 160*1024 && !getenv( "SPA_L1_WORD_WAVES")) ? (unsigned)L1_WORD_WAVES_SMALL : (unsigned)L1_WORD_WAVES;
+	PW.ldsWords = ((size_t)c->imgWords*8 + (size_t)wordWaves*L1_WORDS_LDS_PER_WAVE <= 160*1024 && T.nofShapes) ? c->imgWords : 0u;
+	unsigned wordBlocks = (unsigned)((maxUnits + wordWaves-1) / wordWaves < (uint64_t)c->numCUs ? (maxUnits + wordWaves-1) / wordWaves : (uint64_t)c->numCUs);
 	if (wordBlocks == 0) wordBlocks = 1;
 	// (scanWords = 0 keeps the batch off the lane-per-stream scan kernel: an expression that can stay live across blanks would
 	//  fail the warm-up proof of most pieces, SPA_L1_NO_LANES: tests)
@@ -481,7 +483,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	// lane-per-stream scan kernel (a few automaton words left to scan): a wave per unit, workgroups of four waves
 	unsigned laneBlocks = (unsigned)((maxUnits + 3) / 4 < (uint64_t)c->numCUs*4 ? (maxUnits + 3) / 4 : (uint64_t)c->numCUs*4);
 	if (laneBlocks == 0) laneBlocks = 1;
-	HIP_CHECK( launchL1Lex( PS, PW, P, nblocks, c->blockThreads, laneBlocks, wordBlocks, nwaves, stream, c->evMid, c->evWords));
+	HIP_CHECK( launchL1Lex( PS, PW, P, nblocks, c->blockThreads, laneBlocks, wordBlocks, wordWaves, nwaves, stream, c->evMid, c->evWords));
 	if (P.nofApprox) std::snprintf( c->scanKernel, sizeof(c->scanKernel), "spa_l1_approx_kernel");
 	else if (l1ScanByLanes( PS, P)) std::snprintf( c->scanKernel, sizeof(c->scanKernel), "spa_l1_scan_lanes_kernel");
 	else if (PS.nofPasses == 0) std::snprintf( c->scanKernel, sizeof(c->scanKernel), "(none)");

@@ -1213,13 +1213,13 @@ __device__ __forceinline__ u32 runStartBefore( const L1Params& P, const unsigned
 // The backward walk of leftmostStart for a candidate of the words kernel: class and context of the bytes it visits come from the
 // wave's ring in LDS (the last 128 bytes of the text, written a tile at a time), the automaton's rows from the LDS image -- two
 // LDS round trips per byte instead of four dependent global loads.  A walk that leaves the ring goes on with leftmostStart.
-enum {WORD_RING=512, WORD_WAVES=L1_WORD_WAVES, WORD_ENDS=96, WORD_ENDWORDS=5};
-__shared__ unsigned short wordRing[ WORD_WAVES][ WORD_RING];
+enum {WORD_RING=512, WORD_ENDS=96, WORD_ENDWORDS=5};
+// (per wave: a ring of class | context << 8 of the last 512 bytes, wordRing, and wordEnds -- both declared in wordsDocuments, one pair
+//  of arrays per workgroup size)
 // the run ends that wait for their probes, {end offset, start of the run, hash of the run, hash of the word before it, length | length of
 // the word before << 8} each; while a batch of them is worked on (they are in registers then) the first 1 KB holds the candidates
 // {end offset, pattern | L1_LITERAL_FLAG for a literal, start of the run, -}: a lane each for the walks
-__shared__ __attribute__((aligned(16))) u32 wordEnds[ WORD_WAVES][ WORD_ENDS*WORD_ENDWORDS];
-static_assert( sizeof(wordRing) + sizeof(wordEnds) <= L1_WORDS_STATIC_LDS, "static LDS of the words kernel");
+static_assert( WORD_RING*2 + WORD_ENDS*WORD_ENDWORDS*4 == L1_WORDS_LDS_PER_WAVE, "static LDS of the words kernel");
 static_assert( 64*WORD_ENDWORDS*4 >= 64*16, "the candidates lie over the ends of the batch");
 template <bool LDS>
 __device__ __forceinline__ u32 confirmWalk( const unsigned char* doc, u32 docLen, const L1Params& P, const LexTab<LDS>& T, const unsigned short* ring, u32 ringLo,
@@ -1473,12 +1473,9 @@ __device__ __forceinline__ void wordsFlush( LexWave& w, const L1Params& P, const
 // the word before it.  Only one byte in six ends a run, so the ends are collected -- up to 64 of them, over several tiles -- before
 // they are probed with a lane each (wordsFlush).
 template <bool LDS>
-__device__ __forceinline__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, const u32 segBeg, const u32 segEnd)
+__device__ __forceinline__ void wordsUnit( LexWave& w, const L1Params& P, const LexTab<LDS>& T, const u32 segBeg, const u32 segEnd, unsigned short* ring, u32* ends)
 {
 	const u32 len = w.docLen;
-	const u32 wv = uni( threadIdx.x >> 6);
-	unsigned short* ring = wordRing[ wv];
-	u32* ends = wordEnds[ wv];
 	u32 ctxReg = 0, clsReg = 0;		// byte -> context, class: lane l keeps the entries of bytes 4l..4l+3
 	for (u32 k=0; k<4; ++k) { const u32 cl = P.byteClass[ 4*LANE + k]; clsReg |= cl << (8*k); ctxReg |= (u32)P.classCtx[ cl] << (8*k); }
 	auto isWordAt = [&]( u32 pos) -> bool { return P.classCtx[ P.byteClass[ uni( (u32)w.doc[ pos])]] == (u32)CTX_WORD; };
@@ -1592,7 +1589,7 @@ __device__ __forceinline__ void wordsUnit( LexWave& w, const L1Params& P, const 
 }
 
 template <bool LDS>
-__device__ __forceinline__ void wordsDocuments( const L1Params& P)
+__device__ __forceinline__ void wordsDocuments( const L1Params& P, unsigned short* ring, u32* ends)
 {
 	if (!P.wordsKernel) return;
 	LexTab<LDS> T;
@@ -1627,7 +1624,7 @@ __device__ __forceinline__ void wordsDocuments( const L1Params& P)
 		w.queue = P.wordQueue + 4*qb;
 		w.queueCap = (u32)(queueBase( P, beg + segEnd, unit + 1) - qb);
 		w.nQueue = 0; w.err = 0;
-		wordsUnit<LDS>( w, P, T, segBeg, segEnd);
+		wordsUnit<LDS>( w, P, T, segBeg, segEnd, ring, ends);
 		if (LANE == 0)
 		{
 			P.wordCount[ unit] = w.err ? 0u : w.nQueue;
@@ -2532,8 +2529,18 @@ extern "C" __global__ __launch_bounds__(256) void spa_l1_scan_lanes_kernel( L1Pa
 {
 	if (P.scanWords <= 1) scanDocumentsLanes<1>( P); else if (P.scanWords == 2) scanDocumentsLanes<2>( P); else scanDocumentsLanes<4>( P);
 }
-extern "C" __global__ __launch_bounds__(64*WORD_WAVES) void spa_l1_words_kernel( L1Params P) { if (P.ldsWords) wordsDocuments<true>( P); else wordsDocuments<false>( P); }
-// the post-processing kernel reads the automaton's tables from global memory (start of match only)
+// (12 waves: the table image of a large expression set leaves room for no more; 16 waves -- what 114 registers allow -- for small sets)
+#define SPA_L1_WORDS_KERNEL( NAME, WAVES) \
+extern "C" __global__ __launch_bounds__(64*WAVES) void NAME( L1Params P) \
+{ \
+	__shared__ unsigned short wordRing[ WAVES][ WORD_RING]; \
+	__shared__ __attribute__((aligned(16))) u32 wordEnds[ WAVES][ WORD_ENDS*WORD_ENDWORDS]; \
+	const u32 wv = threadIdx.x >> 6; \
+	if (P.ldsWords) wordsDocuments<true>( P, wordRing[ wv], wordEnds[ wv]); else wordsDocuments<false>( P, wordRing[ wv], wordEnds[ wv]); \
+}
+SPA_L1_WORDS_KERNEL( spa_l1_words_kernel, L1_WORD_WAVES)
+SPA_L1_WORDS_KERNEL( spa_l1_words_kernel_w16, L1_WORD_WAVES_SMALL)
+
 enum {POST_WAVES=4};
 // The post-processing kernel is bound by the latency of its dependent chains, not by issue slots: it gains from
 // more resident waves as long as the register budget does not spill much.  Measured on 12288 x 64 KiB documents
@@ -2557,7 +2564,7 @@ bool l1ScanByLanes( const L1Params& PS, const L1Params& P)
 	return PS.nofPasses == 1 && PS.scanWords >= 1 && PS.scanWords <= 4 && PS.reportsOrdered && !P.cpBlocks && !P.nofNullable && PS.ldsWords && (size_t)PS.ldsWords * 8 <= 65536;
 }
 
-hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned laneBlocks, unsigned wordBlocks, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords)
+hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& P, unsigned nblocks, unsigned nthreads, unsigned laneBlocks, unsigned wordBlocks, unsigned wordWaves, unsigned postWaves, hipStream_t stream, hipEvent_t betweenKernels, hipEvent_t afterWords)
 {
 	if (P.nofApprox)
 	{
@@ -2614,8 +2621,16 @@ hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& 
 	{
 		// (its own copy of the parameters: the image of ALL passes staged in LDS when it fits, PW.ldsWords)
 		const size_t wlds = (size_t)PW.ldsWords * 8;
-		if (wlds > 65536) { e = hipFuncSetAttribute( (const void*)spa_l1_words_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); if (e != hipSuccess) return e; }
-		hipLaunchKernelGGL( spa_l1_words_kernel, dim3( wordBlocks), dim3( 64*WORD_WAVES), wlds, stream, PW);
+		if (wordWaves == (unsigned)L1_WORD_WAVES_SMALL)
+		{
+			if (wlds > 65536) { e = hipFuncSetAttribute( (const void*)spa_l1_words_kernel_w16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); if (e != hipSuccess) return e; }
+			hipLaunchKernelGGL( spa_l1_words_kernel_w16, dim3( wordBlocks), dim3( 64*L1_WORD_WAVES_SMALL), wlds, stream, PW);
+		}
+		else
+		{
+			if (wlds > 65536) { e = hipFuncSetAttribute( (const void*)spa_l1_words_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); if (e != hipSuccess) return e; }
+			hipLaunchKernelGGL( spa_l1_words_kernel, dim3( wordBlocks), dim3( 64*L1_WORD_WAVES), wlds, stream, PW);
+		}
 		e = hipGetLastError();
 		if (e != hipSuccess) return e;
 	}

@@ -453,3 +453,61 @@ def test_handler_clusters_against_the_oracle(mode, monkeypatch):
     assert np.array_equal(gpu.status, np.zeros(len(docs), np.int32))
     assert np.array_equal(gpu.doc_offsets, roffs)
     assert np.array_equal(gpu.lexems, ref)
+
+
+# The words kernel collects run ends over several tiles and probes them 64 at a time (wordsFlush); this set drives its corners: tiles
+# where every second byte ends a run (32 ends per tile, several candidates each: more than 64 candidates per batch, several rounds of
+# walks), ends so sparse that the batch is flushed because the 512-byte ring is about to lose the bytes before them, words longer
+# than the ring (the confirming walk leaves it), table entries that hold several patterns (list merge instead of the sorting network).
+@pytest.mark.parametrize("chunk", [None, "2048"])
+def test_words_kernel_batches_against_the_oracle(chunk, monkeypatch):
+    if chunk:
+        monkeypatch.setenv("SPA_L1_CHUNK_BYTES", chunk)
+    rng = random.Random(4242)
+
+    def build(x):
+        x.defineOption("DOTALL")
+        lid = 1
+        for pre in ("a", "ab", "b", "ba", "abc"):
+            x.defineLexem(lid, "\\b%s[a-z]*\\b" % pre, 0, 1 + lid % 3, "content"); lid += 1
+        for suf in ("a", "b", "ab", "ba", "cab"):
+            x.defineLexem(lid, "[a-z]+%s\\b" % suf, 0, 1 + lid % 3, "content"); lid += 1
+        # the same shape key twice (one table entry, a list of two patterns), the same word in a literal and in two alternations
+        x.defineLexem(lid, "\\bab[a-z]*\\b", 0, 3, "predecessor"); lid += 1
+        x.defineLexem(lid, "\\b[a-z]+ab\\b", 0, 2, "content"); lid += 1
+        x.defineLexem(lid, "\\bab\\b", 0, 2, "content"); lid += 1
+        x.defineLexem(lid, "\\b(ab|ba|zz)\\b", 0, 1, "content"); lid += 1
+        x.defineLexem(lid, "\\b(ab|a|b)\\b", 0, 4, "successor"); lid += 1
+        for w in ("a", "ab", "b"):
+            x.defineLexem(lid, "\\b%s\\s\\w+\\b" % w, 0, 1 + lid % 4, "content"); lid += 1
+        x.defineLexem(lid, "[0-9]+[.][0-9]+", 0, 2, "content"); lid += 1      # (keeps an automaton pass to scan)
+        x.compile()
+    lx, o = _both(build)
+    from tests.l1_table_sim import Tables
+    assert Tables(lx.dumpTables()).nof_shapes >= 8
+    docs = []
+    docs.append(("a b " * 3000).encode())                                            # 32 run ends per tile
+    docs.append(("ab ba " * 2500).encode())
+    docs.append(b"".join(b"ab" + b" " * rng.randint(300, 900) for _ in range(60)))  # sparse ends
+    docs.append(("ab" + "c" * 700 + "ab " + "b" * 600 + "a" + " " * 40).encode() * 6)  # words longer than the ring
+    for _ in range(12):
+        toks = []
+        for _ in range(rng.randint(50, 700)):
+            u = rng.random()
+            if u < 0.6:
+                toks.append(rng.choice(["a", "b", "ab", "ba", "abc", "cab", "abab", "zz", "bab", "abcab"]))
+            elif u < 0.7:
+                toks.append("%d.%d" % (rng.randint(0, 99), rng.randint(0, 99)))
+            else:
+                toks.append("".join(rng.choice("abc") for _ in range(rng.randint(1, 30))))
+            toks.append(rng.choice([" ", " ", "  ", ". ", "\n", " " * rng.randint(1, 200)]))
+        docs.append("".join(toks).encode())
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.uint64)
+    text = b"".join(docs)
+    ctx = lx.createContext()
+    gpu = ctx.matchDocs(text, offs)
+    assert ctx.batchCounters()["word_reports"] > 10000
+    ref, roffs = o.matchDocs(text, offs, nthreads=8)
+    assert np.array_equal(gpu.status, np.zeros(len(docs), np.int32))
+    assert np.array_equal(gpu.doc_offsets, roffs)
+    assert np.array_equal(gpu.lexems, ref)
