@@ -219,6 +219,7 @@ def main():
                 "l1_scan_ms": float(np.mean(scan_ms)) if scan_ms else 0.0, "l1_words_ms": float(np.mean(words_ms)) if words_ms else 0.0, "l1_post_ms": float(np.mean(post_ms)) if post_ms else 0.0,
                 "word_reports": int(lcount.get("word_reports", 0)), "l2_kernel": (mctx.kernelName() if mctx is not None else None),
                 "scan_kernel": (lctx.scanKernelName() if lctx is not None and scan_ms else None),
+                "words_kernel": (lctx.wordsKernelName() if lctx is not None and scan_ms else None),
                 "raw_reports": int(lcount["raw_reports"]), "lexems": int(lcount["lexems"]), "events": int(mcount["events"]), "results": int(mcount["results"]), "items": int(mcount["items"])}
 
     # secondary shapes first (short, no barrier), the headline shape last so that its outputs are the
@@ -278,12 +279,13 @@ def report(args, wl, world, pats, head, m, tot, dt, secondary, nbytes, h2d_ms):
     b_l2 = 16.0 * m["events"] + 36.0 * m["results"]
     roofs = {}
     scanname = m.get("scan_kernel") or "spa_l1_scan_kernel"
+    wordsname = m.get("words_kernel") or "spa_l1_words_kernel"
     if m["l1_ms"] > 0:
         roofs[scanname] = roofline_of(scanname, m["l1_scan_ms"], float(nbytes) + 16.0 * m["raw_reports"],
                                       *pmc_traffic(scanname, wl, args, m["l1_scan_ms"]))
         if m["l1_words_ms"] > 0.05:
-            roofs["spa_l1_words_kernel"] = roofline_of("spa_l1_words_kernel", m["l1_words_ms"], float(nbytes) + 16.0 * m["word_reports"],
-                                                       *pmc_traffic("spa_l1_words_kernel", wl, args, m["l1_words_ms"]))
+            roofs[wordsname] = roofline_of(wordsname, m["l1_words_ms"], float(nbytes) + 16.0 * m["word_reports"],
+                                           *pmc_traffic(wordsname, wl, args, m["l1_words_ms"]))
             post_bytes = 16.0 * (m["raw_reports"] + m["word_reports"]) + 16.0 * m["lexems"]
         else:
             post_bytes = float(nbytes) + 16.0 * m["raw_reports"] + 16.0 * m["lexems"]
@@ -313,7 +315,7 @@ def report(args, wl, world, pats, head, m, tot, dt, secondary, nbytes, h2d_ms):
         "matches_per_s": gresults * steps / dt,
         "events_per_s": gevents * steps / dt,
         "lexems_per_s": glexems * steps / dt,
-        "kernel_ms": {scanname: m["l1_scan_ms"], "spa_l1_words_kernel": m["l1_words_ms"], "spa_l1_post_kernel": m["l1_post_ms"], l2name: m["l2_ms"]},
+        "kernel_ms": {scanname: m["l1_scan_ms"], wordsname: m["l1_words_ms"], "spa_l1_post_kernel": m["l1_post_ms"], l2name: m["l2_ms"]},
         "roofline": dominant,
         "roofline_all": roofs,
     }

@@ -317,6 +317,8 @@ int sp_lexer_ctx_last_kernel_ms_split(sp_lexer_ctx_t* c, double* scan_ms, double
 int sp_lexer_ctx_last_kernel_ms_split3(sp_lexer_ctx_t* c, double* scan_ms, double* words_ms, double* post_ms);
 /* name of the scan kernel the last launch of this context went through ("(none)" before the first launch) */
 const char* sp_lexer_ctx_scan_kernel_name(const sp_lexer_ctx_t* c);
+/* the same for the words kernel (whole-word literals and word shapes): its 12- or 16-wave instance, "(none)" for tables it does not take */
+const char* sp_lexer_ctx_words_kernel_name(const sp_lexer_ctx_t* c);
 int sp_lexer_ctx_reserve_output(sp_lexer_ctx_t* c, uint64_t lexems);
 int sp_lexer_ctx_grow_arena(sp_lexer_ctx_t* c);
 

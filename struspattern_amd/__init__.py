@@ -456,6 +456,10 @@ class PatternLexerContext:
             raise PatternError("no timed launch")
         return a.value, b.value, d.value
 
+    def wordsKernelName(self):
+        """the instance of the words kernel the last launch went through"""
+        return self._L.sp_lexer_ctx_words_kernel_name(self._h).decode()
+
     def scanKernelName(self):
         """the scan kernel the last launch went through"""
         return self._L.sp_lexer_ctx_scan_kernel_name(self._h).decode()

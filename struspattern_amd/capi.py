@@ -134,6 +134,7 @@ SIGNATURES = {
     "sp_lexer_ctx_last_kernel_ms": (ctypes.c_double, [c_vp]),
     "sp_lexer_ctx_last_kernel_ms_split": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "sp_lexer_ctx_scan_kernel_name": (ctypes.c_char_p, [c_vp]),
+    "sp_lexer_ctx_words_kernel_name": (ctypes.c_char_p, [c_vp]),
     "sp_lexer_ctx_last_kernel_ms_split3": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "sp_lexer_ctx_reserve_output": (ctypes.c_int, [c_vp, c_u64]),
     "sp_lexer_ctx_grow_arena": (ctypes.c_int, [c_vp]),

@@ -42,9 +42,10 @@ struct sp_lexer_ctx
 	int device;
 	std::string lasterror;
 	DeviceBuffer dByteClass, dClassCtx, dCharMask, dStartMask, dAcceptMask, dShiftDst, dSelfLoop, dExSrc, dExDst, dExCount,
-		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dPatOfBit, dApprox, dCharCp, dCharPos, dCpBlocks, dCpPages, dUnitStart, dDocSequential, dNullable,
+		dPatterns, dSymbols, dSymbolText, dLiterals, dLiteralText, dLitPats, dTableImage, dWordsImage, dPatOfBit, dApprox, dCharCp, dCharPos, dCpBlocks, dCpPages, dUnitStart, dDocSequential, dNullable,
 		dScanImage, dShapes, dShapePats;
 	uint32_t ldsWords, ldsAccept, ldsStart, ldsShift, ldsSelf, ldsExSrc, ldsExDst; unsigned blockThreads;
+	uint32_t wChar, wAccept, wStart, wShift, wSelf, wExSrc, wExDst, wShapeFp, wWords;	// the words kernel's image: the passes behind the scanned ones + the shape table; offsets biased by what is left out
 	uint32_t imgShapeFp, imgWords, imgAccept, imgStart, imgShift, imgSelf, imgExSrc, imgExDst;	// offsets inside the image of all passes (dTableImage); lds*: inside the image of the scanned passes
 	bool wordsKernel;		// plain tables: literals and word shapes are found by the words kernel
 	DeviceBuffer dArena, dCounters, dText, dDocOffsets, dLexems, dDocRange, dDocStatus, dQueue, dReportCount, dWordQueue, dWordCount;
@@ -55,12 +56,13 @@ struct sp_lexer_ctx
 	unsigned numCUs;
 	hipEvent_t evStart, evMid, evWords, evStop; bool evValid;
 	char scanKernel[ 48] = "(none)";
+	const char* wordsKernelName = "(none)";
 	hipStream_t lastStream; size_t lastNdocs;
 	hipStream_t own;		// the context's own stream (non-blocking): the host-buffer entry points of different contexts -- one per host thread,
 				// the reference's threading model -- copy and launch side by side instead of queueing on the null stream
 	sp_lexer_ctx() :inst(0),device(0),ldsWords(0),ldsAccept(0),ldsStart(0),ldsShift(0),ldsSelf(0),ldsExSrc(0),ldsExDst(0),blockThreads(256),queueMul(8),queueCap(4096),eventCap(32768),arenaWaves(0),arenaWords(0),lexemCapacity(0),minLexemCapacity(0)
 		,numCUs(256),evStart(0),evMid(0),evWords(0),evStop(0),evValid(false),lastStream(0),lastNdocs(0),own(0)
-		,imgShapeFp(0),imgWords(0),imgAccept(0),imgStart(0),imgShift(0),imgSelf(0),imgExSrc(0),imgExDst(0),wordsKernel(false){}
+		,wChar(0),wAccept(0),wStart(0),wShift(0),wSelf(0),wExSrc(0),wExDst(0),wShapeFp(0),wWords(0),imgShapeFp(0),imgWords(0),imgAccept(0),imgStart(0),imgShift(0),imgSelf(0),imgExSrc(0),imgExDst(0),wordsKernel(false){}
 };
 
 extern "C" {
@@ -237,6 +239,32 @@ sp_lexer_ctx_t* sp_lexer_ctx_create( const sp_lexer_t* l, int device)
 			c->imgShapeFp = (uint32_t)img.size(); img.insert( img.end(), T.shapeFp.begin(), T.shapeFp.end());	// (the compact shape table rides along: staged in LDS with the rest)
 			c->dTableImage.upload( img.data(), img.size()*8);
 			c->imgWords = (uint32_t)img.size();
+		}
+		if (c->wordsKernel)
+		{
+			// image of the words kernel: it walks the patterns of the passes BEHIND the scanned ones only, so those passes and the compact
+			// shape table are all it stages in LDS (the 10k set: 101 KB instead of 124: room for 16 waves per workgroup).  The kernel
+			// indexes by absolute pass: the offsets carry the bias (modulo 2^32).
+			const size_t sp = T.scanPasses, mx = T.maxExceptions;
+			auto tail = [&]( std::vector<uint64_t>& img, const std::vector<uint64_t>& v, size_t perPass) -> uint32_t
+			{
+				size_t skip = sp*perPass < v.size() ? sp*perPass : v.size();
+				uint32_t off = (uint32_t)img.size() - (uint32_t)skip;
+				img.insert( img.end(), v.begin() + skip, v.end());
+				return off;
+			};
+			std::vector<uint64_t> img;
+			c->wChar = tail( img, T.charMask, (size_t)T.nofClasses*64);
+			c->wAccept = tail( img, T.acceptMask, (size_t)CTX_COUNT*64);
+			c->wStart = tail( img, T.startMask, (size_t)CTX_COUNT*64);
+			c->wShift = tail( img, T.shiftDst, 64);
+			c->wSelf = tail( img, T.selfLoop, 64);
+			c->wExSrc = tail( img, T.exSrc, mx*64);
+			c->wExDst = tail( img, T.exDst, mx*64);
+			c->wShapeFp = (uint32_t)img.size(); img.insert( img.end(), T.shapeFp.begin(), T.shapeFp.end());
+			if (img.empty()) img.push_back( 0);
+			c->dWordsImage.upload( img.data(), img.size()*8);
+			c->wWords = (uint32_t)img.size();
 		}
 		{
 			// LDS image of the scan kernel: the passes it runs (the word shapes' passes behind them are never scanned), when it fits
@@ -460,7 +488,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
 	// the kernels that walk an automaton backwards read the image of all passes from global memory ...
 	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = 0;
-	P.ldsAccept = c->imgAccept; P.ldsStart = c->imgStart; P.ldsShift = c->imgShift; P.ldsSelf = c->imgSelf;
+	P.ldsChar = 0; P.ldsAccept = c->imgAccept; P.ldsStart = c->imgStart; P.ldsShift = c->imgShift; P.ldsSelf = c->imgSelf;
 	P.ldsExSrc = c->imgExSrc; P.ldsExDst = c->imgExDst;
 	// ... the scan kernel stages the image of the passes it runs in LDS
 	L1Params PS = P;
@@ -472,8 +500,14 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	// words kernel: a wave per unit, workgroups of 16 waves that share one LDS copy of the image of all passes when it fits
 	L1Params PW = P;
 	// (16 waves per workgroup while the image leaves room for their rings and run ends, else 12; SPA_L1_WORD_WAVES=12: A/B runs)
-	unsigned wordWaves = ((size_t)c->imgWords*8 + (size_t)L1_WORD_WAVES_SMALL*L1_WORDS_LDS_PER_WAVE <= 160*1024 && !getenv( "SPA_L1_WORD_WAVES")) ? (unsigned)L1_WORD_WAVES_SMALL : (unsigned)L1_WORD_WAVES;
-	PW.ldsWords = ((size_t)c->imgWords*8 + (size_t)wordWaves*L1_WORDS_LDS_PER_WAVE <= 160*1024 && T.nofShapes) ? c->imgWords : 0u;
+	unsigned wordWaves = ((size_t)c->wWords*8 + (size_t)L1_WORD_WAVES_SMALL*L1_WORDS_LDS_PER_WAVE <= 160*1024 && !getenv( "SPA_L1_WORD_WAVES")) ? (unsigned)L1_WORD_WAVES_SMALL : (unsigned)L1_WORD_WAVES;
+	if (c->wordsKernel)
+	{
+		PW.tableImage = (const uint64_t*)c->dWordsImage.ptr;
+		PW.ldsChar = c->wChar; PW.ldsAccept = c->wAccept; PW.ldsStart = c->wStart; PW.ldsShift = c->wShift; PW.ldsSelf = c->wSelf;
+		PW.ldsExSrc = c->wExSrc; PW.ldsExDst = c->wExDst; PW.shapeFpOffset = c->wShapeFp;
+	}
+	PW.ldsWords = ((size_t)c->wWords*8 + (size_t)wordWaves*L1_WORDS_LDS_PER_WAVE <= 160*1024 && T.nofShapes) ? c->wWords : 0u;
 	unsigned wordBlocks = (unsigned)((maxUnits + wordWaves-1) / wordWaves < (uint64_t)c->numCUs ? (maxUnits + wordWaves-1) / wordWaves : (uint64_t)c->numCUs);
 	if (wordBlocks == 0) wordBlocks = 1;
 	// (scanWords = 0 keeps the batch off the lane-per-stream scan kernel: an expression that can stay live across blanks would
@@ -484,6 +518,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	unsigned laneBlocks = (unsigned)((maxUnits + 3) / 4 < (uint64_t)c->numCUs*4 ? (maxUnits + 3) / 4 : (uint64_t)c->numCUs*4);
 	if (laneBlocks == 0) laneBlocks = 1;
 	HIP_CHECK( launchL1Lex( PS, PW, P, nblocks, c->blockThreads, laneBlocks, wordBlocks, wordWaves, nwaves, stream, c->evMid, c->evWords));
+	c->wordsKernelName = !c->wordsKernel || P.nofApprox ? "(none)" : (wordWaves == (unsigned)L1_WORD_WAVES_SMALL ? "spa_l1_words_kernel_w16" : "spa_l1_words_kernel");
 	if (P.nofApprox) std::snprintf( c->scanKernel, sizeof(c->scanKernel), "spa_l1_approx_kernel");
 	else if (l1ScanByLanes( PS, P)) std::snprintf( c->scanKernel, sizeof(c->scanKernel), "spa_l1_scan_lanes_kernel");
 	else if (PS.nofPasses == 0) std::snprintf( c->scanKernel, sizeof(c->scanKernel), "(none)");
@@ -559,6 +594,11 @@ int sp_lexer_ctx_last_kernel_ms_split( sp_lexer_ctx_t* c, double* scan_ms, doubl
 const char* sp_lexer_ctx_scan_kernel_name( const sp_lexer_ctx_t* c)
 {
 	return c->scanKernel;
+}
+
+const char* sp_lexer_ctx_words_kernel_name( const sp_lexer_ctx_t* c)
+{
+	return c->wordsKernelName;
 }
 
 // the same with the words kernel on its own (round 3: automaton scan | literals + word shapes | start of match + handler + ordinal positions)

@@ -97,6 +97,7 @@ struct L1Params
 	uint32_t shapeFpOffset;		// the compact shape table (l1_tables.h) lies at this word offset of the table image (LDS or global, like the rest)
 	uint32_t shapeSalt;
 	uint32_t scanWords;		// automaton words the scanned passes use: up to 4 words in one pass take the lane-per-stream scan kernel
+	uint32_t ldsChar;		// offset of the character rows in the image (0; the words kernel's image leaves the scanned passes out: biased, as the other offsets)
 	uint32_t postClusters;		// 1: the handler runs a cluster of reports per lane (postDocumentClusters); 0: one report after the other
 };
 

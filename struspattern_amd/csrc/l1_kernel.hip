@@ -64,7 +64,7 @@ template <bool LDS>
 struct LexTab
 {
 	const u64* g;		// global image
-	u32 oAccept, oStart, oShift, oSelf, oExSrc, oExDst;
+	u32 oChar, oAccept, oStart, oShift, oSelf, oExSrc, oExDst;	// (offsets may be biased, modulo 2^32, by the passes an image leaves out: the words kernel's)
 	__device__ __forceinline__ u64 at( u32 off) const { if (LDS) return ldsImage[ off]; else return g[ off]; }
 };
 
@@ -232,7 +232,7 @@ __device__ __forceinline__ u32 leftmostStart( const unsigned char* doc, u32 docL
 		}
 		u32 cls = P.byteClass[ doc[ j-2]];
 		if (CP && P.cpBlocks && doc[ j-2] >= 0x80u) { int cx; classCtxAt( P, doc, docLen, j-2, cls, cx); }
-		R = Rp & mask & T.at( (pass*P.nofClasses + cls)*64 + ln);
+		R = Rp & mask & T.at( T.oChar + (pass*P.nofClasses + cls)*64 + ln);
 		--j;
 	}
 	return from;
@@ -1229,7 +1229,7 @@ __device__ __forceinline__ u32 confirmWalk( const unsigned char* doc, u32 docLen
 	const u32 pass = word >> 6, ln = word & 63u;
 	const u32 ccLast = ring[ (to-1u) & (WORD_RING-1)];
 	const u32 nextctx = to < docLen ? ((u32)ring[ to & (WORD_RING-1)] >> 8) : (u32)CTX_EDGE;
-	u64 R = mask & T.at( T.oAccept + (pass*CTX_COUNT + nextctx)*64 + ln) & T.at( (pass*P.nofClasses + (ccLast & 0xFFu))*64 + ln);
+	u64 R = mask & T.at( T.oAccept + (pass*CTX_COUNT + nextctx)*64 + ln) & T.at( T.oChar + (pass*P.nofClasses + (ccLast & 0xFFu))*64 + ln);
 	if (!R) return to;
 	const u64 shiftDst = T.at( T.oShift + pass*64 + ln), selfLoop = T.at( T.oSelf + pass*64 + ln);
 	const u32 nEx = P.exCount[ pass];
@@ -1253,7 +1253,7 @@ __device__ __forceinline__ u32 confirmWalk( const unsigned char* doc, u32 docLen
 			const u64 es = T.at( T.oExSrc + at), ed = T.at( T.oExDst + at);
 			Rp |= (R & ed) ? es : 0ull;
 		}
-		R = Rp & mask & T.at( (pass*P.nofClasses + (cc & 0xFFu))*64 + ln);
+		R = Rp & mask & T.at( T.oChar + (pass*P.nofClasses + (cc & 0xFFu))*64 + ln);
 		--j;
 	}
 	return from;
@@ -2325,7 +2325,7 @@ __device__ void approxDocuments( const L1Params& P)
 template <bool LDS>
 __device__ __forceinline__ void stageTables( const L1Params& P, LexTab<LDS>& T)
 {
-	T.g = P.tableImage; T.oAccept = P.ldsAccept; T.oStart = P.ldsStart; T.oShift = P.ldsShift; T.oSelf = P.ldsSelf;
+	T.g = P.tableImage; T.oChar = P.ldsChar; T.oAccept = P.ldsAccept; T.oStart = P.ldsStart; T.oShift = P.ldsShift; T.oSelf = P.ldsSelf;
 	T.oExSrc = P.ldsExSrc; T.oExDst = P.ldsExDst;
 	if (LDS)
 	{
