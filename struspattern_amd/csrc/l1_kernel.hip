@@ -993,9 +993,12 @@ __shared__ unsigned short laneCc[ 256];		// byte -> class | context << 8
 enum {LANE_PARK=SPA_L1_LANE_PARK};		// 16-byte blocks of a lane's piece parked per refill (8 = a whole 128-byte line: 33 KB per workgroup, 8 waves per CU beside the table image; 4: 16 waves)
 __shared__ uint4 laneText[ 4][ LANE_PARK*64];		// per wave: the next bytes of every lane's piece of the text
 template <int W>
-__device__ void scanUnitLanes( LexWave& w, const L1Params& P, const LexTab<true>& T, const u32 segBeg, const u32 segEnd)
+__device__ __forceinline__ void scanUnitLanes( LexWave& w, const L1Params& P, const LexTab<true>& T, const u32 segBeg, const u32 segEnd)
 {
-	enum {WARM=256};
+#ifndef SPA_L1_LANE_WARM
+#define SPA_L1_LANE_WARM 256
+#endif
+	enum {WARM=SPA_L1_LANE_WARM};
 	const u32 len = w.docLen;
 	const u32 nofClasses = uni( P.nofClasses), maxEx = uni( P.maxExceptions), nEx = uni( P.exCount[ 0]);
 	const u32 span = segEnd - segBeg;
@@ -1033,12 +1036,36 @@ __device__ void scanUnitLanes( LexWave& w, const L1Params& P, const LexTab<true>
 #pragma unroll
 		for (int x=0; x<W; ++x) F[ x] = ~0ull;
 		prevctx = q ? ((u32)laneCc[ w.doc[ q-1]] >> 8) : (u32)CTX_EDGE;
-		for (u32 i=q; i<b0; ++i)
+		// (16 bytes per load: a byte per load was 256 dependent global loads per lane)
+#pragma unroll 1
+		for (u32 i=q; i<b0; i+=16)
 		{
-			const u32 cc = laneCc[ w.doc[ i]];
-			stepWords( F, cc & 0xFFu, prevctx, false);
-			stepWords( S, cc & 0xFFu, prevctx, true);
-			prevctx = cc >> 8;
+			uint4 v = make_uint4( 0,0,0,0);
+			if (i + 16u <= len) v = ld128u( w.doc + i);
+			else
+			{
+				// (the document's last bytes: one at a time through the lane's parking place, nothing is read behind the text)
+				uint4* pk = laneText[ threadIdx.x >> 6] + LANE;
+				pk[ 0] = make_uint4( 0,0,0,0);
+				for (u32 k=0; k<16u && i+k<len; ++k) ((unsigned char*)pk)[ k] = w.doc[ i+k];
+				v = pk[ 0];
+			}
+#pragma unroll 1
+			for (u32 dw=0; dw<4u; ++dw)
+			{
+				const u32 x = dw == 0 ? v.x : (dw == 1 ? v.y : (dw == 2 ? v.z : v.w));
+#pragma unroll
+				for (int k=0; k<4; ++k)
+				{
+					if (i + 4u*dw + (u32)k < b0)
+					{
+						const u32 cc = laneCc[ (x >> (8*k)) & 0xFFu];
+						stepWords( F, cc & 0xFFu, prevctx, false);
+						stepWords( S, cc & 0xFFu, prevctx, true);
+						prevctx = cc >> 8;
+					}
+				}
+			}
 		}
 		if (q)
 		{
@@ -1134,7 +1161,7 @@ __device__ void scanUnitLanes( LexWave& w, const L1Params& P, const LexTab<true>
 }
 
 template <int W>
-__device__ void scanDocumentsLanes( const L1Params& P)
+__device__ __forceinline__ void scanDocumentsLanes( const L1Params& P)
 {
 	LexTab<true> T;
 	for (u32 k=threadIdx.x; k<256u; k+=blockDim.x) { const u32 cl = P.byteClass[ k]; laneCc[ k] = (unsigned short)(cl | ((u32)P.classCtx[ cl] << 8)); }
