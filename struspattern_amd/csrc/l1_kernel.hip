@@ -1757,7 +1757,10 @@ __device__ void postDocumentMerged( LexWave& w, const L1Params& P, const LexTab<
 // the other, as before: the reports in front of the window's first boundary (they may reach into the array), a cluster that leaves more
 // than LOC_CAP events or holds a symbol lookup, a cluster as long as the window.  The last cluster of a window waits for the next one
 // unless the input has ended (its last reports may still be to come).
-enum {WIN_CAP=192, LOC_CAP=6, REC_SYMBOL=1u<<16, REC_SIZEERR=1u<<31};
+#ifndef SPA_L1_POST_LOC_CAP
+#define SPA_L1_POST_LOC_CAP 6
+#endif
+enum {WIN_CAP=192, LOC_CAP=SPA_L1_POST_LOC_CAP, REC_SYMBOL=1u<<16, REC_SIZEERR=1u<<31};
 
 __device__ __forceinline__ u32 waveSuffixMin( u32 v)		// inclusive, identity ~0
 {
@@ -2583,7 +2586,10 @@ enum {POST_WAVES=4};
 #endif
 #define SPA_L1_POST_OCC __attribute__((amdgpu_waves_per_eu( SPA_L1_POST_WAVES_PER_EU, SPA_L1_POST_WAVES_PER_EU)))
 // (the two instances with the cluster-per-lane handler hold 9 KB of LDS per wave: 16 waves per CU)
-#define SPA_L1_POST_OCC4 __attribute__((amdgpu_waves_per_eu( 4, 4)))
+#ifndef SPA_L1_POST_CLUSTER_WAVES_PER_EU
+#define SPA_L1_POST_CLUSTER_WAVES_PER_EU 4
+#endif
+#define SPA_L1_POST_OCC4 __attribute__((amdgpu_waves_per_eu( SPA_L1_POST_CLUSTER_WAVES_PER_EU, SPA_L1_POST_CLUSTER_WAVES_PER_EU)))
 extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC4 void spa_l1_post_kernel( L1Params P) { postDocuments<false,false,false>( P); }
 extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC4 void spa_l1_post_kernel_ch( L1Params P) { postDocuments<false,false,true>( P); }
 extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_l1_post_kernel_cp( L1Params P) { postDocuments<false,true,true>( P); }
