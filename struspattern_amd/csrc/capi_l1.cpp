@@ -486,7 +486,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	P.shapeFpOffset = c->imgShapeFp; P.shapeSalt = T.shapeSalt;
 	P.wordQueue = (uint32_t*)c->dWordQueue.ptr; P.wordCount = (uint32_t*)c->dWordCount.ptr; P.wordsKernel = c->wordsKernel ? 1u : 0u;
 	HIP_CHECK( hipEventRecord( c->evStart, stream));
-	// the kernels that walk an automaton backwards read the image of all passes from global memory ...
+	// the post-processing kernel, which walks the scanned patterns backwards, reads the image of all passes from global memory ...
 	P.tableImage = (const uint64_t*)c->dTableImage.ptr; P.ldsWords = 0;
 	P.ldsChar = 0; P.ldsAccept = c->imgAccept; P.ldsStart = c->imgStart; P.ldsShift = c->imgShift; P.ldsSelf = c->imgSelf;
 	P.ldsExSrc = c->imgExSrc; P.ldsExDst = c->imgExDst;
@@ -497,7 +497,7 @@ void launchLex( sp_lexer_ctx* c, const void* d_text, const void* d_doc_offsets, 
 	PS.ldsAccept = c->ldsAccept; PS.ldsStart = c->ldsStart; PS.ldsShift = c->ldsShift; PS.ldsSelf = c->ldsSelf;
 	PS.ldsExSrc = c->ldsExSrc; PS.ldsExDst = c->ldsExDst;
 	if (PS.nofPasses == 0) HIP_CHECK( hipMemsetAsync( c->dReportCount.ptr, 0, (maxUnits+1)*sizeof(uint32_t), stream));
-	// words kernel: a wave per unit, workgroups of 16 waves that share one LDS copy of the image of all passes when it fits
+	// words kernel: a wave per unit, workgroups of 16 (12) waves that share one LDS copy of ITS image -- the passes behind the scanned ones + the shape table -- when it fits
 	L1Params PW = P;
 	// (16 waves per workgroup while the image leaves room for their rings and run ends, else 12; SPA_L1_WORD_WAVES=12: A/B runs)
 	unsigned wordWaves = ((size_t)c->wWords*8 + (size_t)L1_WORD_WAVES_SMALL*L1_WORDS_LDS_PER_WAVE <= 160*1024 && !getenv( "SPA_L1_WORD_WAVES")) ? (unsigned)L1_WORD_WAVES_SMALL : (unsigned)L1_WORD_WAVES;

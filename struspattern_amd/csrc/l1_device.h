@@ -11,7 +11,7 @@ enum {L1C_LEXEMS=0, L1C_BYTES=1, L1C_RAW=2, L1C_FAILED=3, L1C_COUNT=8, L1C_CURSO
       L1C_CURSOR4=14 /*unit cursor of the words kernel*/, L1C_WORDREPORTS=15 /*records the words kernel wrote*/,
       L1C_OVER_QUEUE=16 /*units whose slice of a report queue was too small*/, L1C_OVER_EVENTS=17 /*documents whose event array was too small*/, L1C_ALLOC=18};
 
-// words kernel: waves of a workgroup, static LDS it declares (ring + run ends per wave); the table image takes the rest of the 160 KB
+// words kernel: waves of a workgroup (12, or 16 while its table image leaves room), static LDS per wave (ring + run ends); the image takes the rest of the 160 KB
 enum {L1_WORD_WAVES=12, L1_WORD_WAVES_SMALL=16, L1_WORDS_LDS_PER_WAVE=512*2 + 96*5*4};
 
 struct L1Params

@@ -2596,7 +2596,7 @@ extern "C" __global__ __launch_bounds__(64*POST_WAVES) SPA_L1_POST_OCC void spa_
 
 namespace spa {
 // PS: the parameters of the scan kernel (its table image holds the scanned passes only; nofPasses = 0: nothing to scan);
-// PW: of the words kernel (all passes, in LDS when they fit); P: of the other kernels (all passes, read from global memory)
+// PW: of the words kernel (the passes it walks + the shape table, in LDS when they fit; offsets biased); P: of the other kernels (all passes, read from global memory)
 bool l1ScanByLanes( const L1Params& PS, const L1Params& P)
 {
 	return PS.nofPasses == 1 && PS.scanWords >= 1 && PS.scanWords <= 4 && PS.reportsOrdered && !P.cpBlocks && !P.nofNullable && PS.ldsWords && (size_t)PS.ldsWords * 8 <= 65536;
@@ -2657,7 +2657,7 @@ hipError_t launchL1Lex( const L1Params& PS, const L1Params& PW, const L1Params& 
 	if (betweenKernels) { e = hipEventRecord( betweenKernels, stream); if (e != hipSuccess) return e; }
 	if (P.wordsKernel)
 	{
-		// (its own copy of the parameters: the image of ALL passes staged in LDS when it fits, PW.ldsWords)
+		// (its own copy of the parameters: its image staged in LDS when it fits, PW.ldsWords; 16 or 12 waves per workgroup by what the image leaves)
 		const size_t wlds = (size_t)PW.ldsWords * 8;
 		if (wordWaves == (unsigned)L1_WORD_WAVES_SMALL)
 		{
